@@ -1,0 +1,651 @@
+// C-ABI orchestration of the Rater hot path on gfx950 (see include/keraslm_hip.h).
+//
+// The library owns no device memory: parameters, gradients, optimizer moments,
+// state rows and workspaces all belong to the caller.  This file lays out the
+// workspaces, derives the bf16 operand copies, and issues the launch sequences:
+//
+//   forward   P1 = table gather (layer-0 input contraction as look-ups) ->
+//             layer wavefront of thin fused cell steps (one launch per diagonal:
+//             layer l runs time d-l) -> tied-embedding logits -> softmax/CE
+//   backward  dH = dlogits.E -> reverse layer wavefront of fused backward cell
+//             steps -> weight gradients as big K=B*T GEMMs over transposed
+//             activations -> layer-0/embedding gradients through one-hot^T
+//             segment sums -> regularisers
+//   step      L launches + logits + softmax for n hypotheses with pool slots
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "kl_common.h"
+#include "kl_kernels.h"
+
+namespace {
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline int round_up_i(int x, int a) { return (x + a - 1) / a * a; }
+
+// bump allocator; with base == nullptr it only measures
+struct Carver {
+  unsigned char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base(reinterpret_cast<unsigned char*>(b)) {}
+  template <typename T>
+  T* take(size_t count) {
+    off = align_up(off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+struct Derived {
+  std::vector<bf16_t*> UT_hi, UT_lo, KT_hi, KT_lo, Un, Kn;   // per layer (KT/Kn of layer 0 = rows [0,W) of K0)
+  bf16_t *E_hi = nullptr, *E_lo = nullptr, *ET = nullptr;
+  float* EK = nullptr;
+  std::vector<float*> CtxK;
+};
+
+struct WindowWs {
+  float* P1;
+  std::vector<void*> H;        // [(T+1)B][W]  f32 (inference) or bf16 (training)
+  std::vector<float*> C;       // [(T+1)B][W]
+  float* logits;               // [BT][V]
+  // training only
+  std::vector<bf16_t*> G, dZ, Hd;
+  bf16_t *dZT, *HT, *dlogits, *dlogitsT, *OHT, *dEKT_bf, *dEK_bf;
+  std::vector<bf16_t*> OHC;
+  float *dH, *dEKT;
+  std::vector<float*> dc0, dc1, dCtxKT;
+};
+
+}  // namespace
+
+struct kl_handle {
+  kl_config cfg;
+  int Vp;                       // voc_size rounded up to 32
+  size_t n_params;
+  std::vector<size_t> off_K, off_U, off_b, off_Ctx;
+  size_t off_E;
+  float* params = nullptr;
+  void* derived_ws = nullptr;
+  size_t derived_bytes = 0;
+  Derived d;
+  int precision = 0;            // 0 = not prepared
+};
+
+namespace {
+
+void layout(kl_handle* h) {
+  const kl_config& c = h->cfg;
+  const size_t W = c.width;
+  size_t off = 0;
+  h->off_E = off;
+  off += (size_t)c.voc_size * W;
+  h->off_Ctx.clear();
+  for (int n = 0; n < c.n_ctx; ++n) {
+    h->off_Ctx.push_back(off);
+    off += (size_t)c.ctx_vocab * c.ctx_dim;
+  }
+  h->off_K.clear();
+  h->off_U.clear();
+  h->off_b.clear();
+  for (int l = 0; l < c.depth; ++l) {
+    const size_t D = l == 0 ? W + (size_t)c.ctx_dim * c.n_ctx : W;
+    h->off_K.push_back(off);
+    off += D * 4 * W;
+    h->off_U.push_back(off);
+    off += W * 4 * W;
+    h->off_b.push_back(off);
+    off += 4 * W;
+  }
+  h->n_params = off;
+  h->Vp = round_up_i(c.voc_size, 32);
+}
+
+bool config_ok(const kl_config* c) {
+  if (!c) return false;
+  if (c->depth < 1 || c->depth > 16) return false;
+  if (c->width < 32 || (c->width & 31)) return false;
+  if (c->voc_size < 1) return false;
+  if (c->n_ctx < 0 || c->n_ctx > 8) return false;
+  if (c->ctx_vocab < 2 || c->ctx_dim < 1) return false;
+  return true;
+}
+
+size_t carve_derived(const kl_handle* h, void* base, Derived* d) {
+  const kl_config& c = h->cfg;
+  const size_t W = c.width, V = c.voc_size, Vp = h->Vp;
+  Carver cv(base);
+  Derived tmp;
+  Derived& o = d ? *d : tmp;
+  o.UT_hi.assign(c.depth, nullptr); o.UT_lo.assign(c.depth, nullptr);
+  o.KT_hi.assign(c.depth, nullptr); o.KT_lo.assign(c.depth, nullptr);
+  o.Un.assign(c.depth, nullptr); o.Kn.assign(c.depth, nullptr);
+  for (int l = 0; l < c.depth; ++l) {
+    o.UT_hi[l] = cv.take<bf16_t>(4 * W * W);
+    o.UT_lo[l] = cv.take<bf16_t>(4 * W * W);
+    o.KT_hi[l] = cv.take<bf16_t>(4 * W * W);
+    o.KT_lo[l] = cv.take<bf16_t>(4 * W * W);
+    o.Un[l] = cv.take<bf16_t>(4 * W * W);
+    o.Kn[l] = cv.take<bf16_t>(4 * W * W);
+  }
+  o.E_hi = cv.take<bf16_t>(Vp * W);
+  o.E_lo = cv.take<bf16_t>(Vp * W);
+  o.ET = cv.take<bf16_t>(W * Vp);
+  o.EK = cv.take<float>(V * 4 * W);
+  o.CtxK.assign(c.n_ctx, nullptr);
+  for (int n = 0; n < c.n_ctx; ++n) o.CtxK[n] = cv.take<float>((size_t)c.ctx_vocab * 4 * W);
+  return align_up(cv.off, 256);
+}
+
+size_t carve_window(const kl_handle* h, void* base, int B, int T, int training, WindowWs* out) {
+  const kl_config& c = h->cfg;
+  const size_t W = c.width, V = c.voc_size, Vp = h->Vp, L = c.depth;
+  const size_t BT = (size_t)B * T, BTp = round_up_i((int)BT, 8);
+  Carver cv(base);
+  WindowWs tmp;
+  WindowWs& o = out ? *out : tmp;
+  o.P1 = cv.take<float>(BT * 4 * W);
+  o.H.assign(L, nullptr);
+  o.C.assign(L, nullptr);
+  for (size_t l = 0; l < L; ++l) {
+    o.H[l] = training ? (void*)cv.take<bf16_t>((BT + B) * W) : (void*)cv.take<float>((BT + B) * W);
+    o.C[l] = cv.take<float>((BT + B) * W);
+  }
+  o.logits = cv.take<float>(BT * V);
+  if (training) {
+    o.G.assign(L, nullptr); o.dZ.assign(L, nullptr); o.Hd.assign(L, nullptr);
+    o.dc0.assign(L, nullptr); o.dc1.assign(L, nullptr);
+    for (size_t l = 0; l < L; ++l) {
+      o.G[l] = cv.take<bf16_t>(BT * 4 * W);
+      o.dZ[l] = cv.take<bf16_t>(BT * 4 * W);
+      o.Hd[l] = l > 0 ? cv.take<bf16_t>(BT * W) : nullptr;
+      o.dc0[l] = cv.take<float>((size_t)B * W);
+      o.dc1[l] = cv.take<float>((size_t)B * W);
+    }
+    o.dZT = cv.take<bf16_t>(4 * W * BTp);
+    o.HT = cv.take<bf16_t>(W * BTp);
+    o.dlogits = cv.take<bf16_t>(BT * Vp);
+    o.dlogitsT = cv.take<bf16_t>(Vp * BTp);
+    o.OHT = cv.take<bf16_t>(Vp * BTp);
+    o.OHC.assign(c.n_ctx, nullptr);
+    o.dCtxKT.assign(c.n_ctx, nullptr);
+    for (int n = 0; n < c.n_ctx; ++n) {
+      o.OHC[n] = cv.take<bf16_t>((size_t)c.ctx_vocab * BTp);
+      o.dCtxKT[n] = cv.take<float>(4 * W * (size_t)c.ctx_vocab);
+    }
+    o.dH = cv.take<float>(BT * W);
+    o.dEKT = cv.take<float>(4 * W * Vp);
+    o.dEKT_bf = cv.take<bf16_t>(4 * W * Vp);
+    o.dEK_bf = cv.take<bf16_t>(Vp * 4 * W);
+  }
+  return align_up(cv.off, 256);
+}
+
+#define KL_TRY(expr)            \
+  do {                          \
+    int _e = (expr);            \
+    if (_e != 0) return _e;     \
+  } while (0)
+
+int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : KL_ERR_LAUNCH; }
+
+int prepare_impl(kl_handle* h, int precision, hipStream_t s) {
+  const kl_config& c = h->cfg;
+  const int W = c.width, V = c.voc_size, Vp = h->Vp;
+  const float* P = h->params;
+  Derived& d = h->d;
+  const bool split = precision == KL_PREC_SPLIT;
+  for (int l = 0; l < c.depth; ++l) {
+    const float* K = P + h->off_K[l];   // layer 0: rows [0,W) are the char-embedding part
+    const float* U = P + h->off_U[l];
+    KL_TRY(kl_launch_f32_to_bf16_t(U, 4 * W, W, 4 * W, d.UT_hi[l], split ? d.UT_lo[l] : nullptr, W, 1, s));
+    KL_TRY(kl_launch_f32_to_bf16_t(K, 4 * W, W, 4 * W, d.KT_hi[l], split ? d.KT_lo[l] : nullptr, W, 1, s));
+    KL_TRY(kl_launch_f32_to_bf16_t(U, 4 * W, W, 4 * W, d.Un[l], nullptr, 4 * W, 0, s));
+    KL_TRY(kl_launch_f32_to_bf16_t(K, 4 * W, W, 4 * W, d.Kn[l], nullptr, 4 * W, 0, s));
+  }
+  const float* E = P + h->off_E;
+  KL_TRY(hip_ok(hipMemsetAsync(d.E_hi, 0, (size_t)Vp * W * sizeof(bf16_t), s)));
+  KL_TRY(hip_ok(hipMemsetAsync(d.E_lo, 0, (size_t)Vp * W * sizeof(bf16_t), s)));
+  KL_TRY(hip_ok(hipMemsetAsync(d.ET, 0, (size_t)W * Vp * sizeof(bf16_t), s)));
+  KL_TRY(kl_launch_f32_to_bf16_t(E, W, V, W, d.E_hi, split ? d.E_lo : nullptr, W, 0, s));
+  KL_TRY(kl_launch_f32_to_bf16_t(E, W, V, W, d.ET, nullptr, Vp, 1, s));
+  // layer-0 look-up tables: EK = E . K0[:W] ; CtxK_n = Ctx_n . K0[W+10n ..]
+  KlOperand op;
+  memset(&op, 0, sizeof(op));
+  op.A = E; op.lda = W; op.a_is_f32 = 1;
+  op.WT_hi = d.KT_hi[0]; op.WT_lo = split ? d.KT_lo[0] : nullptr; op.ldw = W; op.K = W;
+  KL_TRY(kl_launch_thin_gemm(&op, V, 4 * W, d.EK, 4 * W, nullptr, precision, s));
+  for (int n = 0; n < c.n_ctx; ++n) {
+    const float* Kc = P + h->off_K[0] + (size_t)(W + n * c.ctx_dim) * 4 * W;
+    KL_TRY(kl_launch_small_table(P + h->off_Ctx[n], c.ctx_vocab, c.ctx_dim, Kc, 4 * W, 4 * W, d.CtxK[n], 4 * W, s));
+  }
+  h->precision = precision;
+  return 0;
+}
+
+// forward over one window; fills ws (activations) and states
+int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, float* states, const float* masks,
+                 int training, WindowWs& w, hipStream_t s) {
+  const kl_config& c = h->cfg;
+  const int W = c.width, L = c.depth;
+  const size_t BW = (size_t)B * W;
+  const float* P = h->params;
+  Derived& d = h->d;
+  const int split = training ? 1 : h->precision;
+  std::vector<const float*> ctxk(c.n_ctx);
+  for (int n = 0; n < c.n_ctx; ++n) ctxk[n] = d.CtxK[n];
+  KL_TRY(kl_launch_p1_gather(d.EK, ctxk.data(), c.n_ctx, P + h->off_b[0], idx, ctx, B, T, 4 * W, w.P1, s));
+  for (int l = 0; l < L; ++l)
+    KL_TRY(kl_launch_state_to_rows(states, B, W, L, l, training ? (bf16_t*)w.H[l] : nullptr,
+                                   training ? nullptr : (float*)w.H[l], w.C[l], s));
+  auto hrow = [&](int l, int block) -> const void* {
+    return training ? (const void*)((bf16_t*)w.H[l] + (size_t)block * BW) : (const void*)((float*)w.H[l] + (size_t)block * BW);
+  };
+  for (int dgl = 0; dgl < T + L - 1; ++dgl) {
+    KlFwdStep steps[4];
+    int ns = 0;
+    for (int l = 0; l < L; ++l) {
+      const int t = dgl - l;
+      if (t < 0 || t >= T) continue;
+      KlFwdStep& S = steps[ns++];
+      memset(&S, 0, sizeof(S));
+      S.n_rows = B; S.W = W; S.split = split;
+      int p = 0;
+      if (l > 0) {
+        KlOperand& o = S.op[p++];
+        const bool masked_in = training && masks != nullptr && (l - 1) > 0;
+        if (masked_in) {
+          o.A = w.Hd[l - 1] + (size_t)t * BW; o.a_is_f32 = 0;
+        } else {
+          o.A = hrow(l - 1, t + 1); o.a_is_f32 = training ? 0 : 1;
+        }
+        o.lda = W; o.WT_hi = d.KT_hi[l]; o.WT_lo = split == 3 ? d.KT_lo[l] : nullptr; o.ldw = W; o.K = W;
+        S.bias = P + h->off_b[l];
+      } else {
+        S.T1 = w.P1 + (size_t)t * B * 4 * W; S.t1_ld = 4 * W;
+      }
+      {
+        KlOperand& o = S.op[p++];
+        o.A = hrow(l, t); o.a_is_f32 = training ? 0 : 1; o.lda = W;
+        o.WT_hi = d.UT_hi[l]; o.WT_lo = split == 3 ? d.UT_lo[l] : nullptr; o.ldw = W; o.K = W;
+      }
+      S.n_ops = p;
+      S.c_prev = w.C[l] + (size_t)t * BW; S.c_prev_ld = W;
+      S.c_out = w.C[l] + (size_t)(t + 1) * BW; S.c_out_ld = W;
+      if (training) {
+        S.h_out_bf16 = (bf16_t*)w.H[l] + (size_t)(t + 1) * BW; S.h_out_bf16_ld = W;
+        S.gates_out = w.G[l] + (size_t)t * B * 4 * W; S.gates_ld = 4 * W;
+        if (l > 0 && masks != nullptr) {
+          S.hmask = masks + (size_t)l * BW; S.hmask_ld = W;
+          S.hd_out_bf16 = w.Hd[l] + (size_t)t * BW; S.hd_out_ld = W;
+        }
+      } else {
+        S.h_out_f32 = (float*)w.H[l] + (size_t)(t + 1) * BW; S.h_out_f32_ld = W;
+      }
+    }
+    // a launch packs at most 4 independent steps
+    for (int i = 0; i < ns; i += 4) KL_TRY(kl_launch_fwd_steps(steps + i, ns - i < 4 ? ns - i : 4, s));
+  }
+  for (int l = 0; l < L; ++l)
+    KL_TRY(kl_launch_rows_to_state(hrow(l, T), training ? 0 : 1, w.C[l] + (size_t)T * BW, B, W, L, l, states, s));
+  return 0;
+}
+
+__global__ void state_dist2_kernel(const float* __restrict__ pool, long slot_stride, int W, int k,
+                                   const int* __restrict__ a, const int* __restrict__ b, int n,
+                                   float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const float* pa = pool + (long)a[i] * slot_stride + (long)k * W;
+  const float* pb = pool + (long)b[i] * slot_stride + (long)k * W;
+  float acc = 0.f;
+  for (int u = lane; u < W; u += 64) { const float q = pa[u] - pb[u]; acc += q * q; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) out[i] = acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kl_abi_version(void) { return KL_ABI_VERSION; }
+
+const char* kl_error_string(int code) {
+  switch (code) {
+    case KL_OK: return "ok";
+    case KL_ERR_SHAPE: return "unsupported or inconsistent dimensions";
+    case KL_ERR_LAUNCH: return "HIP launch/runtime error";
+    case KL_ERR_STATE: return "call order violated (bind/prepare first)";
+    case KL_ERR_WORKSPACE: return "workspace too small";
+    case KL_ERR_ARG: return "null or invalid argument";
+    default: return "unknown error";
+  }
+}
+
+size_t kl_param_count(const kl_config* cfg) {
+  if (!config_ok(cfg)) return 0;
+  kl_handle tmp;
+  tmp.cfg = *cfg;
+  layout(&tmp);
+  return tmp.n_params;
+}
+
+int kl_param_layout(const kl_config* cfg, int index, char* name, size_t name_cap, size_t* offset, size_t* rows,
+                    size_t* cols) {
+  if (!config_ok(cfg) || index < 0) return KL_ERR_ARG;
+  kl_handle t;
+  t.cfg = *cfg;
+  layout(&t);
+  const size_t W = cfg->width;
+  char buf[32];
+  size_t off, r, c;
+  const int n_emb = 1 + cfg->n_ctx;
+  if (index == 0) {
+    snprintf(buf, sizeof buf, "E"); off = t.off_E; r = cfg->voc_size; c = W;
+  } else if (index < n_emb) {
+    snprintf(buf, sizeof buf, "Ctx%d", index - 1); off = t.off_Ctx[index - 1]; r = cfg->ctx_vocab; c = cfg->ctx_dim;
+  } else {
+    const int j = index - n_emb, l = j / 3, k = j % 3;
+    if (l >= cfg->depth) return KL_ERR_ARG;
+    const size_t D = l == 0 ? W + (size_t)cfg->ctx_dim * cfg->n_ctx : W;
+    if (k == 0) { snprintf(buf, sizeof buf, "K%d", l); off = t.off_K[l]; r = D; c = 4 * W; }
+    else if (k == 1) { snprintf(buf, sizeof buf, "U%d", l); off = t.off_U[l]; r = W; c = 4 * W; }
+    else { snprintf(buf, sizeof buf, "b%d", l); off = t.off_b[l]; r = 1; c = 4 * W; }
+  }
+  if (name && name_cap) { strncpy(name, buf, name_cap - 1); name[name_cap - 1] = 0; }
+  if (offset) *offset = off;
+  if (rows) *rows = r;
+  if (cols) *cols = c;
+  return 0;
+}
+
+kl_handle* kl_create(const kl_config* cfg) {
+  if (!config_ok(cfg)) return nullptr;
+  kl_handle* h = new kl_handle();
+  h->cfg = *cfg;
+  layout(h);
+  return h;
+}
+
+void kl_destroy(kl_handle* h) { delete h; }
+
+size_t kl_derived_bytes(const kl_handle* h) { return h ? carve_derived(h, nullptr, nullptr) : 0; }
+
+int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
+  if (!h || !params || !derived) return KL_ERR_ARG;
+  if (derived_bytes < carve_derived(h, nullptr, nullptr)) return KL_ERR_WORKSPACE;
+  h->params = params;
+  h->derived_ws = derived;
+  h->derived_bytes = derived_bytes;
+  carve_derived(h, derived, &h->d);
+  h->precision = 0;
+  return 0;
+}
+
+int kl_prepare(kl_handle* h, int precision, void* stream) {
+  if (!h) return KL_ERR_ARG;
+  if (!h->params) return KL_ERR_STATE;
+  if (precision != KL_PREC_BF16 && precision != KL_PREC_SPLIT) return KL_ERR_ARG;
+  return prepare_impl(h, precision, (hipStream_t)stream);
+}
+
+size_t kl_window_workspace_bytes(const kl_handle* h, int B, int T, int training) {
+  if (!h || B < 1 || T < 1) return 0;
+  return carve_window(h, nullptr, B, T, training, nullptr);
+}
+
+int kl_forward_window(kl_handle* h, int B, int T, const int32_t* idx, const int32_t* ctx, const int32_t* tgt,
+                      float* states, float* probs, float* loss_acc, void* ws, size_t ws_bytes, void* stream) {
+  if (!h || !idx || !states || !ws || B < 1 || T < 1) return KL_ERR_ARG;
+  if (h->cfg.n_ctx > 0 && !ctx) return KL_ERR_ARG;
+  if (!h->precision) return KL_ERR_STATE;
+  hipStream_t s = (hipStream_t)stream;
+  WindowWs w;
+  if (ws_bytes < carve_window(h, ws, B, T, 0, &w)) return KL_ERR_WORKSPACE;
+  const int W = h->cfg.width, V = h->cfg.voc_size, L = h->cfg.depth;
+  KL_TRY(forward_impl(h, B, T, idx, ctx, states, nullptr, 0, w, s));
+  KlOperand op;
+  memset(&op, 0, sizeof(op));
+  op.A = (float*)w.H[L - 1] + (size_t)B * W; op.lda = W; op.a_is_f32 = 1;
+  op.WT_hi = h->d.E_hi; op.WT_lo = h->precision == 3 ? h->d.E_lo : nullptr; op.ldw = W; op.K = W;
+  KL_TRY(kl_launch_thin_gemm(&op, B * T, V, w.logits, V, nullptr, h->precision, s));
+  KL_TRY(kl_launch_softmax_ce(w.logits, V, B * T, V, tgt, B, T, 1.0f / ((float)B * T), nullptr, 0,
+                              tgt ? loss_acc : nullptr, 1, s));
+  if (probs) {
+    if (B == 1) KL_TRY(hip_ok(hipMemcpyAsync(probs, w.logits, (size_t)T * V * sizeof(float), hipMemcpyDeviceToDevice, s)));
+    else KL_TRY(kl_launch_rows_tm_to_bm(w.logits, V, probs, B, T, V, s));
+  }
+  return 0;
+}
+
+int kl_train_window(kl_handle* h, int B, int T, const int32_t* idx, const int32_t* ctx, const int32_t* tgt,
+                    float* states, const float* masks, float* grads, float* loss_acc, void* ws, size_t ws_bytes,
+                    void* stream) {
+  if (!h || !idx || !tgt || !states || !grads || !ws || B < 1 || T < 1) return KL_ERR_ARG;
+  if (h->cfg.n_ctx > 0 && !ctx) return KL_ERR_ARG;
+  if (h->precision != KL_PREC_BF16) return KL_ERR_STATE;
+  hipStream_t s = (hipStream_t)stream;
+  WindowWs w;
+  if (ws_bytes < carve_window(h, ws, B, T, 1, &w)) return KL_ERR_WORKSPACE;
+  const kl_config& c = h->cfg;
+  const int W = c.width, V = c.voc_size, Vp = h->Vp, L = c.depth;
+  const int BT = B * T, BTp = round_up_i(BT, 8);
+  const size_t BW = (size_t)B * W;
+  const float* P = h->params;
+  Derived& d = h->d;
+  const int ksplit = BT >= 4096 ? 8 : (BT >= 1024 ? 4 : 1);
+
+  KL_TRY(hip_ok(hipMemsetAsync(grads, 0, h->n_params * sizeof(float), s)));
+  KL_TRY(forward_impl(h, B, T, idx, ctx, states, masks, 1, w, s));
+
+  // F5/F6: logits over the (masked) top-layer outputs, softmax, CE, dlogits
+  const bool top_masked = masks != nullptr && L > 1;
+  const bf16_t* Htop = top_masked ? w.Hd[L - 1] : (const bf16_t*)w.H[L - 1] + BW;
+  KL_TRY(kl_launch_gemm_tn(Htop, d.E_hi, w.logits, nullptr, BT, V, W, W, W, V, 0, 1, 1.f, s));
+  KL_TRY(kl_launch_softmax_ce(w.logits, V, BT, V, tgt, B, T, 1.0f / (float)BT, w.dlogits, Vp, loss_acc, 1, s));
+  // B1: dH = dlogits . E ; dE += dlogits^T . Htop
+  KL_TRY(kl_launch_gemm_tn(w.dlogits, d.ET, w.dH, nullptr, BT, W, Vp, Vp, Vp, W, 0, 1, 1.f, s));
+  if (BTp != BT) {
+    KL_TRY(hip_ok(hipMemsetAsync(w.dlogitsT, 0, (size_t)Vp * BTp * sizeof(bf16_t), s)));
+    KL_TRY(hip_ok(hipMemsetAsync(w.HT, 0, (size_t)W * BTp * sizeof(bf16_t), s)));
+    KL_TRY(hip_ok(hipMemsetAsync(w.dZT, 0, (size_t)4 * W * BTp * sizeof(bf16_t), s)));
+  }
+  KL_TRY(kl_launch_transpose_bf16(w.dlogits, Vp, w.dlogitsT, BTp, BT, Vp, s));
+  KL_TRY(kl_launch_transpose_bf16(Htop, W, w.HT, BTp, BT, W, s));
+  KL_TRY(kl_launch_gemm_tn(w.dlogitsT, w.HT, grads + h->off_E, nullptr, V, W, BTp, BTp, BTp, W, 2, ksplit, 1.f, s));
+
+  // B3: reverse layer wavefront
+  for (int dgl = 0; dgl < T + L - 1; ++dgl) {
+    KlBwdStep steps[4];
+    int ns = 0;
+    for (int j = 0; j < L; ++j) {
+      const int l = L - 1 - j;
+      const int t = T - 1 - (dgl - j);
+      if (t < 0 || t >= T) continue;
+      KlBwdStep& S = steps[ns++];
+      memset(&S, 0, sizeof(S));
+      S.n_rows = B; S.W = W;
+      int p = 0;
+      if (l < L - 1) {   // gradient from the layer above: dZ_{l+1}[t] . K_{l+1}^T
+        KlOperand& o = S.op[p++];
+        o.A = w.dZ[l + 1] + (size_t)t * B * 4 * W; o.lda = 4 * W; o.a_is_f32 = 0;
+        o.WT_hi = d.Kn[l + 1]; o.ldw = 4 * W; o.K = 4 * W;
+        if (masks != nullptr && l > 0) { S.op0_mask = masks + (size_t)l * BW; S.op0_mask_ld = W; }
+      } else {
+        S.dh_in = w.dH + (size_t)t * BW; S.dh_in_ld = W;
+        if (top_masked) { S.dh_mask = masks + (size_t)l * BW; S.dh_mask_ld = W; }
+      }
+      if (t < T - 1) {   // recurrent: dZ_l[t+1] . U_l^T
+        KlOperand& o = S.op[p++];
+        o.A = w.dZ[l] + (size_t)(t + 1) * B * 4 * W; o.lda = 4 * W; o.a_is_f32 = 0;
+        o.WT_hi = d.Un[l]; o.ldw = 4 * W; o.K = 4 * W;
+        // an op0 mask must only scale the from-above contribution: keep that one first
+      }
+      S.n_ops = p;
+      if (S.op0_mask && !(l < L - 1)) S.op0_mask = nullptr;
+      S.gates = w.G[l] + (size_t)t * B * 4 * W; S.gates_ld = 4 * W;
+      S.c = w.C[l] + (size_t)(t + 1) * BW; S.c_ld = W;
+      S.c_prev = w.C[l] + (size_t)t * BW; S.c_prev_ld = W;
+      float* dc_rd = (t & 1) ? w.dc1[l] : w.dc0[l];
+      float* dc_wr = (t & 1) ? w.dc0[l] : w.dc1[l];
+      if (t < T - 1) { S.dc_in = dc_rd; S.dc_in_ld = W; }
+      S.dc_out = dc_wr; S.dc_out_ld = W;
+      S.dz_out = w.dZ[l] + (size_t)t * B * 4 * W; S.dz_ld = 4 * W;
+    }
+    for (int i = 0; i < ns; i += 4) KL_TRY(kl_launch_bwd_steps(steps + i, ns - i < 4 ? ns - i : 4, s));
+  }
+
+  // B4/B5: weight gradients, K = B*T contractions over transposed activations
+  for (int l = L - 1; l >= 0; --l) {
+    KL_TRY(kl_launch_transpose_bf16(w.dZ[l], 4 * W, w.dZT, BTp, BT, 4 * W, s));
+    // dU_l = Hprev^T . dZ   (Hprev = H blocks 0..T-1)
+    KL_TRY(kl_launch_transpose_bf16((const bf16_t*)w.H[l], W, w.HT, BTp, BT, W, s));
+    KL_TRY(kl_launch_gemm_tn(w.HT, w.dZT, grads + h->off_U[l], nullptr, W, 4 * W, BTp, BTp, BTp, 4 * W, 2, ksplit, 1.f, s));
+    KL_TRY(kl_launch_colsum_bf16(w.dZ[l], 4 * W, BT, 4 * W, grads + h->off_b[l], s));
+    if (l > 0) {
+      // dK_l = X^T . dZ with X = (masked) outputs of layer l-1
+      const bool masked_in = masks != nullptr && (l - 1) > 0;
+      const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
+      KL_TRY(kl_launch_transpose_bf16(X, W, w.HT, BTp, BT, W, s));
+      KL_TRY(kl_launch_gemm_tn(w.HT, w.dZT, grads + h->off_K[l], nullptr, W, 4 * W, BTp, BTp, BTp, 4 * W, 2, ksplit, 1.f, s));
+    } else {
+      // layer 0 through the look-up tables: dEK^T = dZ^T . OneHot ; dCtxK_n^T likewise
+      KL_TRY(hip_ok(hipMemsetAsync(w.OHT, 0, (size_t)Vp * BTp * sizeof(bf16_t), s)));
+      KL_TRY(kl_launch_onehot_t(idx, B, T, V, 0, 1, w.OHT, BTp, s));
+      KL_TRY(hip_ok(hipMemsetAsync(w.dEKT, 0, (size_t)4 * W * Vp * sizeof(float), s)));
+      KL_TRY(kl_launch_gemm_tn(w.dZT, w.OHT, w.dEKT, nullptr, 4 * W, Vp, BTp, BTp, BTp, Vp, 2, ksplit, 1.f, s));
+      KL_TRY(kl_launch_f32_to_bf16_t(w.dEKT, Vp, 4 * W, Vp, w.dEKT_bf, nullptr, Vp, 0, s));
+      KL_TRY(kl_launch_f32_to_bf16_t(w.dEKT, Vp, 4 * W, Vp, w.dEK_bf, nullptr, 4 * W, 1, s));
+      // dK0[:W] = E^T . dEK      (C[W][4W] = ET[W][Vp] . dEKT[4W][Vp]^T)
+      KL_TRY(kl_launch_gemm_tn(d.ET, w.dEKT_bf, grads + h->off_K[0], nullptr, W, 4 * W, Vp, Vp, Vp, 4 * W, 0, 1, 1.f, s));
+      // dE += dEK . K0[:W]^T     (C[V][W] = dEK[V][4W] . Kn0[W][4W]^T)
+      KL_TRY(kl_launch_gemm_tn(w.dEK_bf, d.Kn[0], grads + h->off_E, nullptr, V, W, 4 * W, 4 * W, 4 * W, W, 2, 1, 1.f, s));
+      for (int n = 0; n < c.n_ctx; ++n) {
+        KL_TRY(hip_ok(hipMemsetAsync(w.OHC[n], 0, (size_t)c.ctx_vocab * BTp * sizeof(bf16_t), s)));
+        KL_TRY(kl_launch_onehot_t(ctx, B, T, c.ctx_vocab, n, c.n_ctx, w.OHC[n], BTp, s));
+        KL_TRY(hip_ok(hipMemsetAsync(w.dCtxKT[n], 0, (size_t)4 * W * c.ctx_vocab * sizeof(float), s)));
+        KL_TRY(kl_launch_gemm_tn(w.dZT, w.OHC[n], w.dCtxKT[n], nullptr, 4 * W, c.ctx_vocab, BTp, BTp, BTp,
+                                 c.ctx_vocab, 2, ksplit, 1.f, s));
+        const size_t krow = (size_t)(W + n * c.ctx_dim) * 4 * W;
+        KL_TRY(kl_launch_ctx_grads(P + h->off_Ctx[n], P + h->off_K[0] + krow, 4 * W, c.ctx_vocab, c.ctx_dim,
+                                   w.dCtxKT[n], c.ctx_vocab, 4 * W, grads + h->off_K[0] + krow, 4 * W,
+                                   grads + h->off_Ctx[n], s));
+      }
+    }
+  }
+  // F7: embedding regularisers (training phase only)
+  std::vector<const float*> ctabs(c.n_ctx);
+  std::vector<float*> gctabs(c.n_ctx);
+  for (int n = 0; n < c.n_ctx; ++n) { ctabs[n] = P + h->off_Ctx[n]; gctabs[n] = grads + h->off_Ctx[n]; }
+  KL_TRY(kl_launch_regulariser_grads(P + h->off_E, V, W, ctabs.data(), c.n_ctx, c.ctx_vocab, c.ctx_dim,
+                                     grads + h->off_E, gctabs.data(), loss_acc, s));
+  return 0;
+}
+
+int kl_adam_step(kl_handle* h, const float* grads, float* m, float* v, int t, float lr, float b1, float b2,
+                 float eps, float clip, void* stream) {
+  if (!h || !grads || !m || !v || t < 1) return KL_ERR_ARG;
+  if (!h->params) return KL_ERR_STATE;
+  hipStream_t s = (hipStream_t)stream;
+  const double lr_t = (double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
+  KL_TRY(kl_launch_adam(h->params, grads, m, v, h->n_params, (float)lr_t, b1, b2, eps, clip, s));
+  return prepare_impl(h, h->precision ? h->precision : KL_PREC_BF16, s);
+}
+
+size_t kl_step_workspace_bytes(const kl_handle* h, int n) {
+  if (!h || n < 1) return 0;
+  Carver cv(nullptr);
+  cv.take<float>((size_t)n * 4 * h->cfg.width);   // P rows when n_ctx != 1
+  return align_up(cv.off, 256);
+}
+
+int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, float* pool, const int32_t* slot_in,
+                  const int32_t* slot_out, float* probs, void* ws, size_t ws_bytes, void* stream) {
+  if (!h || !idx || !pool || !slot_in || !slot_out || !probs || n < 1) return KL_ERR_ARG;
+  if (h->cfg.n_ctx > 0 && !ctx) return KL_ERR_ARG;
+  if (!h->precision) return KL_ERR_STATE;
+  hipStream_t s = (hipStream_t)stream;
+  const kl_config& c = h->cfg;
+  const int W = c.width, L = c.depth, V = c.voc_size;
+  const long slot_ld = (long)2 * L * W;
+  const float* P = h->params;
+  Derived& d = h->d;
+  const int split = h->precision;
+  float* prow = nullptr;
+  if (c.n_ctx != 1) {
+    if (!ws || ws_bytes < kl_step_workspace_bytes(h, n)) return KL_ERR_WORKSPACE;
+    prow = reinterpret_cast<float*>(ws);
+    std::vector<const float*> ctxk(c.n_ctx);
+    for (int k = 0; k < c.n_ctx; ++k) ctxk[k] = d.CtxK[k];
+    // rows are hypotheses: treat as B = n streams, T = 1
+    KL_TRY(kl_launch_p1_gather(d.EK, ctxk.data(), c.n_ctx, P + h->off_b[0], idx, ctx, n, 1, 4 * W, prow, s));
+  }
+  for (int l = 0; l < L; ++l) {
+    KlFwdStep S;
+    memset(&S, 0, sizeof(S));
+    S.n_rows = n; S.W = W; S.split = split;
+    int p = 0;
+    if (l == 0) {
+      if (prow) {
+        S.T1 = prow; S.t1_ld = 4 * W;
+      } else {
+        S.T1 = d.EK; S.i1 = idx; S.t1_ld = 4 * W;
+        S.T2 = d.CtxK[0]; S.i2 = ctx; S.t2_ld = 4 * W;
+        S.bias = P + h->off_b[0];
+      }
+    } else {
+      KlOperand& o = S.op[p++];
+      o.A = pool + (size_t)2 * (l - 1) * W; o.lda = slot_ld; o.row_index = slot_out; o.a_is_f32 = 1;
+      o.WT_hi = d.KT_hi[l]; o.WT_lo = split == 3 ? d.KT_lo[l] : nullptr; o.ldw = W; o.K = W;
+      S.bias = P + h->off_b[l];
+    }
+    {
+      KlOperand& o = S.op[p++];
+      o.A = pool + (size_t)2 * l * W; o.lda = slot_ld; o.row_index = slot_in; o.a_is_f32 = 1;
+      o.WT_hi = d.UT_hi[l]; o.WT_lo = split == 3 ? d.UT_lo[l] : nullptr; o.ldw = W; o.K = W;
+    }
+    S.n_ops = p;
+    S.c_prev = pool + (size_t)(2 * l + 1) * W; S.c_prev_ld = slot_ld; S.c_prev_index = slot_in;
+    S.out_index = slot_out;
+    S.c_out = pool + (size_t)(2 * l + 1) * W; S.c_out_ld = slot_ld;
+    S.h_out_f32 = pool + (size_t)2 * l * W; S.h_out_f32_ld = slot_ld;
+    KL_TRY(kl_launch_fwd_steps(&S, 1, s));
+  }
+  KlOperand op;
+  memset(&op, 0, sizeof(op));
+  op.A = pool + (size_t)2 * (L - 1) * W; op.lda = slot_ld; op.row_index = slot_out; op.a_is_f32 = 1;
+  op.WT_hi = d.E_hi; op.WT_lo = split == 3 ? d.E_lo : nullptr; op.ldw = W; op.K = W;
+  KL_TRY(kl_launch_thin_gemm(&op, n, V, probs, V, nullptr, split, s));
+  KL_TRY(kl_launch_softmax_ce(probs, V, n, V, nullptr, n, 1, 1.f, nullptr, 0, nullptr, 0, s));
+  return 0;
+}
+
+int kl_state_dist2(const kl_handle* h, int n, const float* pool, const int32_t* a, const int32_t* b, int k, float* out,
+                   void* stream) {
+  if (!h || !pool || !a || !b || !out || n < 1) return KL_ERR_ARG;
+  if (k < 0 || k >= 2 * h->cfg.depth) return KL_ERR_ARG;
+  const int W = h->cfg.width;
+  hipLaunchKernelGGL(state_dist2_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, pool,
+                     (long)2 * h->cfg.depth * W, W, k, a, b, n, out);
+  return hip_ok(hipGetLastError());
+}
+
+int kl_test_gemm_tn(const uint16_t* A, const uint16_t* B, void* C, const float* bias, int M, int N, int K, long lda,
+                    long ldb, long ldc, int out_mode, int splits, void* stream) {
+  return kl_launch_gemm_tn(A, B, C, bias, M, N, K, lda, ldb, ldc, out_mode, splits, 1.f, (hipStream_t)stream);
+}
+
+int kl_test_thin_gemm(const float* A, long lda, const uint16_t* WT_hi, const uint16_t* WT_lo, long ldw, int M, int N,
+                      int K, float* C, long ldc, int split, void* stream) {
+  KlOperand op;
+  memset(&op, 0, sizeof(op));
+  op.A = A; op.lda = lda; op.a_is_f32 = 1; op.WT_hi = WT_hi; op.WT_lo = WT_lo; op.ldw = ldw; op.K = K;
+  return kl_launch_thin_gemm(&op, M, N, C, ldc, nullptr, split, (hipStream_t)stream);
+}
+
+}  // extern "C"

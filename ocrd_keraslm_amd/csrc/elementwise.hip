@@ -1,0 +1,343 @@
+// HBM-bound helper kernels around the contractions: embedding gather (F1),
+// layout transposes, f32->bf16 weight preparation (hi/lo split), softmax +
+// cross-entropy + dlogits (F5/F6/B1), one-hot builders for the embedding
+// gradients (B7), embedding regularisers (F7), clip+Adam (O1).
+// All accesses are 16-byte vectors where the layout allows it.
+#include "kl_common.h"
+#include "kl_kernels.h"
+
+namespace {
+
+// ---- F1: X[t*B+b] = bf16([E[idx[b,t]] | Ctx_n[ctx[b,t,n]] ... | 0 pad]) ----------
+struct CtxTabs { const float* t[8]; };
+
+__global__ void embed_gather_kernel(const float* __restrict__ E, CtxTabs tabs, int n_ctx, int ctx_dim, int W,
+                                    const int* __restrict__ idx, const int* __restrict__ ctx, int B, int T,
+                                    bf16_t* __restrict__ X, long ldx, int Dp) {
+  const int chunks = Dp >> 3;
+  const long total = (long)B * T * chunks;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % chunks);
+    const long row = e / chunks;          // time-major row = t*B + b
+    const int b = (int)(row % B), t = (int)(row / B);
+    const int id = idx[(long)b * T + t];
+    frag16 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int d = c * 8 + j;
+      float v = 0.f;
+      if (d < W) {
+        v = E[(long)id * W + d];
+      } else if (d < W + n_ctx * ctx_dim) {
+        const int n = (d - W) / ctx_dim, dd = (d - W) % ctx_dim;
+        const int cid = ctx[((long)b * T + t) * n_ctx + n];
+        v = tabs.t[n][(long)cid * ctx_dim + dd];
+      }
+      o.s[j] = f2bf(v);
+    }
+    *reinterpret_cast<uint4*>(X + row * ldx + c * 8) = o.u;
+  }
+}
+
+// ---- bf16 transpose through LDS: out[c][r] = in[r][c] -----------------------------
+__global__ void transpose_bf16_kernel(const bf16_t* __restrict__ in, long ld_in, bf16_t* __restrict__ out,
+                                      long ld_out, int rows, int cols) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 256 threads: 4 rows per pass
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? in[(long)r * ld_in + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) out[(long)c * ld_out + r] = tile[tx][i];
+  }
+}
+
+// ---- f32 -> bf16 (hi [+ lo]) with optional transpose -----------------------------
+__global__ void f32_to_bf16_kernel(const float* __restrict__ in, long ld_in, int rows, int cols,
+                                   bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, long ld_out,
+                                   int transpose) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? in[(long)r * ld_in + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    int orow, ocol;
+    float v;
+    if (transpose) {
+      orow = c0 + i; ocol = r0 + tx; v = tile[tx][i];
+      if (orow >= cols || ocol >= rows) continue;
+    } else {
+      orow = r0 + i; ocol = c0 + tx; v = tile[i][tx];
+      if (orow >= rows || ocol >= cols) continue;
+    }
+    bf16_t hi, lo;
+    split_bf16(v, hi, lo);
+    out_hi[(long)orow * ld_out + ocol] = hi;
+    if (out_lo) out_lo[(long)orow * ld_out + ocol] = lo;
+  }
+}
+
+// ---- softmax + Keras categorical_crossentropy + accuracy + dlogits ---------------
+// one wave per row.  Rows are time-major (row = t*B + b) when time_major != 0,
+// targets are [B][T] with -1 = all-zero one-hot row (padded tail).
+__global__ void softmax_ce_kernel(float* __restrict__ logits, long ld, int rows, int V, const int* __restrict__ tgt,
+                                  int B, int T, float inv_count, bf16_t* __restrict__ dlogits, long ld_dl,
+                                  float* __restrict__ loss_acc, int time_major) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* x = logits + (long)row * ld;
+  float mx = -INFINITY;
+  int amax = 0;
+  for (int v = lane; v < V; v += 64) {
+    const float a = x[v];
+    if (a > mx) { mx = a; amax = v; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(mx, off);
+    const int oi = __shfl_xor(amax, off);
+    if (o > mx || (o == mx && oi < amax)) { mx = o; amax = oi; }
+  }
+  float sum = 0.f;
+  for (int v = lane; v < V; v += 64) sum += expf(x[v] - mx);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  const float inv = 1.f / sum;
+  int t = -2;
+  if (tgt) {
+    const int b = time_major ? row % B : row / T;
+    const int tt = time_major ? row / B : row % T;
+    t = tgt[(long)b * T + tt];
+  }
+  float pt = 0.f;
+  for (int v = lane; v < V; v += 64) {
+    const float p = expf(x[v] - mx) * inv;
+    x[v] = p;
+    if (v == t) pt = p;
+  }
+  if (!tgt) return;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) pt += __shfl_xor(pt, off);
+  const bool valid = t >= 0;
+  const bool active = valid && pt >= 1e-7f && pt <= 1.f - 1e-7f;
+  if (dlogits) {
+    bf16_t* d = dlogits + (long)row * ld_dl;
+    for (int v = lane; v < ld_dl; v += 64) {   // pad columns [V, ld_dl) are written as zeros
+      float g = (active && v < V) ? x[v] : 0.f;
+      if (active && v == t) g -= 1.f;
+      d[v] = f2bf(g * inv_count);
+    }
+  }
+  if (lane == 0 && loss_acc) {
+    if (valid) {
+      const float pc = fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f);
+      atomicAdd(loss_acc + 0, -logf(pc) * inv_count);
+    }
+    const int tsafe = valid ? t : 0;
+    if (amax == tsafe) atomicAdd(loss_acc + 1, inv_count);
+  }
+}
+
+// ---- clip + Adam (Keras 2.3.1 formula; lr_t carries the bias correction) ---------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps, float clip) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    gi = fminf(fmaxf(gi, -clip), clip);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+// ---- one-hot^T builder: out[ids[b,t,col]][t*B+b] = 1 (buffer pre-zeroed) ----------
+__global__ void onehot_t_kernel(const int* __restrict__ ids, int B, int T, int n_classes, int col, int n_cols,
+                                bf16_t* __restrict__ out, long ld) {
+  const long total = (long)B * T;
+  for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < total; r += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(r % B), t = (int)(r / B);
+    const int id = ids[((long)b * T + t) * n_cols + col];
+    if (id >= 0 && id < n_classes) out[(long)id * ld + r] = 0x3F80;   // bf16(1.0)
+  }
+}
+
+// ---- embedding regularisers: gradient (+=) and value ------------------------------
+// mode 0 = chars (rating.py:222-246), mode 1 = contexts (rating.py:187-220).
+// Single block; the tables are tiny ([V,W], [200,10]).
+__global__ void reg_table_kernel(const float* __restrict__ X, int R, int D, float* __restrict__ gX, int mode,
+                                 float* __restrict__ loss_acc) {
+  extern __shared__ float sm[];
+  float* mean = sm;            // [D] mean over rows 1..R-1
+  float* s1 = sm + D;          // [D] sum rows 1..R-2
+  float* s2 = sm + 2 * D;      // [D] sum rows 2..R-1
+  float* nr = sm + 3 * D;      // [R] squared norms
+  float* red = nr + R;         // [blockDim] scratch
+  const int tid = threadIdx.x, nt = blockDim.x;
+  if (R < 2) return;
+  for (int d = tid; d < D; d += nt) {
+    float a = 0.f;
+    for (int r = 1; r < R; ++r) a += X[(long)r * D + d];
+    mean[d] = a / (float)(R - 1);
+    s1[d] = a - X[(long)(R - 1) * D + d];
+    s2[d] = a - X[(long)1 * D + d];
+  }
+  for (int r = tid; r < R; r += nt) {
+    float a = 0.f;
+    for (int d = 0; d < D; ++d) { const float x = X[(long)r * D + d]; a += x * x; }
+    nr[r] = a;
+  }
+  __syncthreads();
+  const float c_low = mode == 0 ? 0.01f : 0.02f;
+  float loss = 0.f;
+  // low-rank term on every row
+  for (long e = tid; e < (long)R * D; e += nt) {
+    const int r = (int)(e / D);
+    gX[e] += -4.f * c_low * (1.f - nr[r]) * X[e];
+  }
+  for (int r = tid; r < R; r += nt) { const float q = 1.f - nr[r]; loss += c_low * q * q; }
+  __syncthreads();
+  if (mode == 0) {
+    for (int d = tid; d < D; d += nt) {
+      const float q = X[d] - mean[d];
+      gX[d] += 2.f * q;
+      loss += q * q;
+    }
+  } else {
+    // smoothness: 0.2 * sum_d s1[d]*s2[d]; gradient 0.2*s1 on rows 2..R-1
+    for (long e = tid + 2L * D; e < (long)R * D; e += nt) gX[e] += 0.2f * s1[e % D];
+    __syncthreads();
+    for (int d = tid; d < D; d += nt) loss += 0.2f * s1[d] * s2[d];
+    // underspecification: 2 * sum_{r>=1} sum_d (C0d - n_r m_d)^2
+    float N1 = 0.f, N2 = 0.f;
+    for (int r = 1; r < R; ++r) { N1 += nr[r]; N2 += nr[r] * nr[r]; }
+    const float Rp = (float)(R - 1);
+    for (int d = tid; d < D; d += nt) {
+      const float c0 = X[d], md = mean[d];
+      gX[d] += 4.f * (Rp * c0 - N1 * md);
+      loss += 2.f * (Rp * c0 * c0 - 2.f * c0 * md * N1 + md * md * N2);
+    }
+  }
+  red[tid] = loss;
+  __syncthreads();
+  for (int s = nt >> 1; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0 && loss_acc) atomicAdd(loss_acc + 2, red[0]);
+}
+
+// ---- carried state (slot layout [B][2L][W] f32) -> bf16 h rows + f32 c rows -------
+__global__ void state_to_rows_kernel(const float* __restrict__ states, int B, int W, int L, int layer,
+                                     bf16_t* __restrict__ h_bf16, float* __restrict__ h_f32,
+                                     float* __restrict__ c_f32) {
+  const long total = (long)B * W;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(e / W), u = (int)(e % W);
+    const float* s = states + ((long)b * 2 * L + 2 * layer) * W;
+    if (h_bf16) h_bf16[e] = f2bf(s[u]);
+    if (h_f32) h_f32[e] = s[u];
+    if (c_f32) c_f32[e] = s[W + u];
+  }
+}
+
+__global__ void fill_f32_kernel(float* p, size_t n, float v) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+inline int grid_for(long total, int block) {
+  long g = (total + block - 1) / block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+inline int ok() { return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH; }
+
+}  // namespace
+
+int kl_launch_embed_gather(const float* E, const float* const* ctx_tabs, int n_ctx, int ctx_dim, int W,
+                           const int* idx, const int* ctx, int B, int T, bf16_t* X, long ldx, int Dp,
+                           hipStream_t stream) {
+  if (n_ctx > 8 || (Dp & 7) || (ldx & 7)) return KL_ERR_SHAPE;
+  CtxTabs tabs;
+  for (int i = 0; i < 8; ++i) tabs.t[i] = i < n_ctx ? ctx_tabs[i] : nullptr;
+  const long total = (long)B * T * (Dp >> 3);
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, E, tabs, n_ctx, ctx_dim,
+                     W, idx, ctx, B, T, X, ldx, Dp);
+  return ok();
+}
+
+int kl_launch_transpose_bf16(const bf16_t* in, long ld_in, bf16_t* out, long ld_out, int rows, int cols,
+                             hipStream_t stream) {
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, stream, in, ld_in, out, ld_out, rows, cols);
+  return ok();
+}
+
+int kl_launch_f32_to_bf16_t(const float* in, long ld_in, int rows, int cols, bf16_t* out_hi, bf16_t* out_lo,
+                            long ld_out, int transpose, hipStream_t stream) {
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  hipLaunchKernelGGL(f32_to_bf16_kernel, grid, dim3(256), 0, stream, in, ld_in, rows, cols, out_hi, out_lo, ld_out,
+                     transpose);
+  return ok();
+}
+
+int kl_launch_softmax_ce(float* logits, long ld, int rows, int V, const int* tgt, int B, int T, float inv_count,
+                         bf16_t* dlogits, long ld_dl, float* loss_acc, int time_major, hipStream_t stream) {
+  dim3 grid((rows + 3) / 4);
+  hipLaunchKernelGGL(softmax_ce_kernel, grid, dim3(256), 0, stream, logits, ld, rows, V, tgt, B, T, inv_count,
+                     dlogits, ld_dl, loss_acc, time_major);
+  return ok();
+}
+
+int kl_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
+                   float eps, float clip, hipStream_t stream) {
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for((long)n, 256)), dim3(256), 0, stream, p, g, m, v, n, lr_t, b1, b2,
+                     eps, clip);
+  return ok();
+}
+
+int kl_launch_onehot_t(const int* ids, int B, int T, int n_classes, int col, int n_cols, bf16_t* out, long ld,
+                       hipStream_t stream) {
+  hipLaunchKernelGGL(onehot_t_kernel, dim3(grid_for((long)B * T, 256)), dim3(256), 0, stream, ids, B, T, n_classes,
+                     col, n_cols, out, ld);
+  return ok();
+}
+
+int kl_launch_regulariser_grads(const float* E, int V, int W, const float* const* ctx_tabs, int n_ctx, int ctx_vocab,
+                                int ctx_dim, float* gE, float* const* gCtx, float* loss_acc, hipStream_t stream) {
+  const int nt = 1024;
+  if (V >= 2) {
+    size_t lds = (size_t)(3 * W + V + nt) * sizeof(float);
+    if (lds > 64 * 1024) return KL_ERR_SHAPE;
+    hipLaunchKernelGGL(reg_table_kernel, dim3(1), dim3(nt), lds, stream, E, V, W, gE, 0, loss_acc);
+  }
+  for (int n = 0; n < n_ctx; ++n) {
+    size_t lds = (size_t)(3 * ctx_dim + ctx_vocab + nt) * sizeof(float);
+    hipLaunchKernelGGL(reg_table_kernel, dim3(1), dim3(nt), lds, stream, ctx_tabs[n], ctx_vocab, ctx_dim, gCtx[n], 1,
+                       loss_acc);
+  }
+  return ok();
+}
+
+int kl_launch_state_to_rows(const float* states, int B, int W, int L, int layer, bf16_t* h_bf16, float* h_f32,
+                            float* c_f32, hipStream_t stream) {
+  hipLaunchKernelGGL(state_to_rows_kernel, dim3(grid_for((long)B * W, 256)), dim3(256), 0, stream, states, B, W, L,
+                     layer, h_bf16, h_f32, c_f32);
+  return ok();
+}
+
+int kl_launch_fill_f32(float* p, size_t n, float v, hipStream_t stream) {
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for((long)n, 256)), dim3(256), 0, stream, p, n, v);
+  return ok();
+}

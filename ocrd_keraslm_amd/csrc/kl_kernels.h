@@ -1,0 +1,100 @@
+// Internal launcher interface between the C-ABI (api.hip) and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "keraslm_hip.h"   // error codes + public ABI (include/)
+
+typedef unsigned short bf16_t;
+
+// ---- gemm.hip -----------------------------------------------------------
+int kl_launch_gemm_tn(const bf16_t* A, const bf16_t* B, void* C, const float* bias, int M, int N, int K,
+                      long lda, long ldb, long ldc, int out_mode, int splits, float alpha, hipStream_t stream);
+
+// ---- lstm_step.hip ------------------------------------------------------
+// One (activation, weight) operand pair of a thin fused step: rows of A are
+// contracted with rows of WT (both K-contiguous).
+struct KlOperand {
+  const void* A;         // [rows][K] f32 (a_is_f32) or bf16
+  long lda;              // elements
+  const int* row_index;  // optional gather of A rows (state-pool slots); null = identity
+  const bf16_t* WT_hi;   // [n_out_rows][K] bf16
+  const bf16_t* WT_lo;   // residual (split mode) or null
+  long ldw;              // row stride of WT (elements, >= K)
+  int K;
+  int a_is_f32;
+};
+
+// forward cell step (F2+F3 fused; S1 when rows are hypotheses)
+struct KlFwdStep {
+  KlOperand op[2];
+  int n_ops;
+  int n_rows, W;
+  int split;                 // 1 = bf16, 3 = split-bf16 (hi*hi + lo*hi + hi*lo)
+  const float* T1; const int* i1; long t1_ld;   // z init: T1[i1[r]] (i1 null = identity rows)
+  const float* T2; const int* i2; long t2_ld;   // + T2[i2[r]]
+  const float* bias;                            // + bias[4W]
+  const float* c_prev; long c_prev_ld; const int* c_prev_index;
+  const int* out_index;                         // scatter of output rows (slots); null = identity
+  float* c_out; long c_out_ld;
+  float* h_out_f32; long h_out_f32_ld;
+  bf16_t* h_out_bf16; long h_out_bf16_ld;
+  bf16_t* gates_out; long gates_ld;             // [rows][4W] post-activation i,f,g,o (training)
+  const float* hmask; long hmask_ld;            // optional dropout keep-mask (scaled) for the copy below
+  bf16_t* hd_out_bf16; long hd_out_ld;          // h * hmask, what the layer above / softmax consumes
+};
+int kl_launch_fwd_steps(const KlFwdStep* steps, int n_steps, hipStream_t stream);
+
+// backward cell step (B3 fused: dh = dh_in + sum_p A_p . WT_p^T ; gate derivatives)
+struct KlBwdStep {
+  KlOperand op[2];
+  int n_ops;
+  int n_rows, W;
+  const float* op0_mask; long op0_mask_ld;      // optional dropout mask on the op[0] contribution
+  const float* dh_in; long dh_in_ld;            // gradient from above (softmax side), optional
+  const float* dh_mask; long dh_mask_ld;        // optional dropout mask multiplying dh_in
+  const bf16_t* gates; long gates_ld;           // [rows][4W] i,f,g,o of this step
+  const float* c; long c_ld;                    // c_t
+  const float* c_prev; long c_prev_ld;          // c_{t-1}
+  const float* dc_in; long dc_in_ld;            // dc carried from t+1 (already times f_{t+1}), optional
+  float* dc_out; long dc_out_ld;                // dc_t * f_t
+  bf16_t* dz_out; long dz_ld;                   // [rows][4W]
+};
+int kl_launch_bwd_steps(const KlBwdStep* steps, int n_steps, hipStream_t stream);
+
+// thin split-precision contraction C[M,N] = A[M,K] . WT[N,K]^T (+bias) for
+// small M (tables, inference logits)
+int kl_launch_thin_gemm(const KlOperand* op, int M, int N, float* C, long ldc, const float* bias, int split,
+                        hipStream_t stream);
+
+// ---- elementwise.hip ----------------------------------------------------
+int kl_launch_embed_gather(const float* E, const float* const* ctx_tabs, int n_ctx, int ctx_dim, int W,
+                           const int* idx, const int* ctx, int B, int T, bf16_t* X, long ldx, int Dp,
+                           hipStream_t stream);
+int kl_launch_transpose_bf16(const bf16_t* in, long ld_in, bf16_t* out, long ld_out, int rows, int cols,
+                             hipStream_t stream);
+int kl_launch_f32_to_bf16_t(const float* in, long ld_in, int rows, int cols, bf16_t* out_hi, bf16_t* out_lo,
+                            long ld_out, int transpose, hipStream_t stream);
+int kl_launch_softmax_ce(float* logits, long ld, int rows, int V, const int* tgt, int B, int T, float inv_count,
+                         bf16_t* dlogits, long ld_dl, float* loss_acc, int time_major_to_bt, hipStream_t stream);
+int kl_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
+                   float eps, float clip, hipStream_t stream);
+int kl_launch_onehot_t(const int* ids, int B, int T, int n_classes, int col, int n_cols, bf16_t* out, long ld,
+                       hipStream_t stream);
+int kl_launch_regulariser_grads(const float* E, int V, int W, const float* const* ctx_tabs, int n_ctx, int ctx_vocab,
+                                int ctx_dim, float* gE, float* const* gCtx, float* loss_acc, hipStream_t stream);
+int kl_launch_state_to_rows(const float* states, int B, int W, int L, int layer, bf16_t* h_bf16, float* h_f32,
+                            float* c_f32, hipStream_t stream);
+int kl_launch_fill_f32(float* p, size_t n, float v, hipStream_t stream);
+
+// ---- tables.hip ---------------------------------------------------------
+int kl_launch_small_table(const float* A, int R, int D, const float* Kmat, long ldk, int N, float* C, long ldc,
+                          hipStream_t stream);
+int kl_launch_p1_gather(const float* EK, const float* const* ctxk, int n_ctx, const float* bias, const int* idx,
+                        const int* ctx, int B, int T, int N, float* P, hipStream_t stream);
+int kl_launch_colsum_bf16(const bf16_t* in, long ld, int rows, int cols, float* out, hipStream_t stream);
+int kl_launch_rows_to_state(const void* h_rows, int h_is_f32, const float* c_rows, int B, int W, int L, int layer,
+                            float* states, hipStream_t stream);
+int kl_launch_ctx_grads(const float* Ctx, const float* K0rows, long ldk, int R, int D, const float* dT, long ldt, int N,
+                        float* gK, long ldg, float* gCtx, hipStream_t stream);
+int kl_launch_rows_tm_to_bm(const float* in, long ld_in, float* out, int B, int T, int V, hipStream_t stream);

@@ -1,0 +1,267 @@
+"""HipLM: the MI355X engine behind `Rater.model`.
+
+Plays the role the compiled Keras model plays in the reference
+(ocrd_keraslm/lib/rating.py:56, 171-178): it owns the weights, the optimizer
+moments, the implicit LSTM state of stateful streams and the state pool of
+incremental hypotheses -- all as torch tensors in HBM -- and runs every
+contraction through the hand-written gfx950 kernels behind the C ABI
+(include/keraslm_hip.h).  torch is used for device memory, streams and (in
+`distributed.py`) the RCCL all-reduce only.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import hipabi
+
+CTX_VOCAB = 200   # rating.py:111
+CTX_DIM = 10
+DROPOUT_RATE = 0.1  # rating.py:152
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class HipLM:
+    def __init__(self, depth, width, voc_size, n_ctx=1, device="cuda:0"):
+        import torch
+        if not torch.cuda.is_available():
+            raise hipabi.KlError("no GPU visible: the Rater hot path runs on MI355X only (no CPU fallback)")
+        self.torch = torch
+        self.lib = hipabi.load()
+        self.device = torch.device(device)
+        self.depth, self.width, self.voc_size, self.n_ctx = int(depth), int(width), int(voc_size), int(n_ctx)
+        if self.width % 32:
+            raise hipabi.KlError("width must be a multiple of 32 on the HIP path (got %d)" % self.width)
+        self.cfg = hipabi.KlConfig(self.depth, self.width, self.voc_size, self.n_ctx, CTX_VOCAB, CTX_DIM)
+        self.handle = self.lib.kl_create(C.byref(self.cfg))
+        if not self.handle:
+            raise hipabi.KlError("kl_create rejected configuration depth=%d width=%d voc=%d"
+                                 % (self.depth, self.width, self.voc_size))
+        self.n_params = self.lib.kl_param_count(C.byref(self.cfg))
+        self.layout = self._read_layout()
+        with torch.cuda.device(self.device):
+            self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+            nbytes = self.lib.kl_derived_bytes(self.handle)
+            self.derived = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+            hipabi.check(self.lib.kl_bind(self.handle, _ptr(self.params), _ptr(self.derived), nbytes), "kl_bind")
+        self.precision = 0
+        self.grads = None
+        self.adam_m = None
+        self.adam_v = None
+        self.adam_t = 0
+        self.loss_acc = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self._ws = None
+        self._ws_key = None
+        self.states = None          # [B][2L][W] implicit state of the stateful streams
+        self.pool = None            # [slots][2L][W] explicit states of hypotheses
+        self._step_ws = None
+        self._rng = np.random.default_rng(0)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.kl_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def _read_layout(self):
+        out = []
+        i = 0
+        name = C.create_string_buffer(32)
+        off, rows, cols = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        while self.lib.kl_param_layout(C.byref(self.cfg), i, name, 32, C.byref(off), C.byref(rows), C.byref(cols)) == 0:
+            out.append((name.value.decode(), off.value, rows.value, cols.value))
+            i += 1
+        return out
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def get_weights(self):
+        """dict name -> float32 array in Keras shapes (E, Ctx0.., K0, U0, b0, ...)."""
+        flat = self.params.detach().cpu().numpy()
+        out = {}
+        for name, off, rows, cols in self.layout:
+            a = flat[off:off + rows * cols]
+            out[name] = a.reshape(cols) .copy() if name.startswith("b") else a.reshape(rows, cols).copy()
+        return out
+
+    def set_weights(self, weights, precision=None):
+        flat = np.empty(self.n_params, dtype=np.float32)
+        for name, off, rows, cols in self.layout:
+            a = np.asarray(weights[name], dtype=np.float32)
+            if a.size != rows * cols:
+                raise ValueError("weight %s has %d elements, expected %d x %d" % (name, a.size, rows, cols))
+            flat[off:off + rows * cols] = a.reshape(-1)
+        self.params.copy_(self.torch.from_numpy(flat))
+        self.prepare(precision or self.precision or hipabi.KL_PREC_SPLIT)
+
+    def init_weights(self, seed=None, emb_std=0.001):
+        """Keras initialisers of rating.py:104-114 + LSTM defaults (glorot_uniform kernel,
+        orthogonal recurrent kernel, zero bias with unit forget gate)."""
+        rng = np.random.default_rng(seed)
+        W = self.width
+        w = {}
+        for name, off, rows, cols in self.layout:
+            if name == "E" or name.startswith("Ctx"):
+                w[name] = (rng.standard_normal((rows, cols)) * emb_std).astype(np.float32)
+            elif name.startswith("K"):
+                lim = math.sqrt(6.0 / (rows + cols))
+                w[name] = rng.uniform(-lim, lim, (rows, cols)).astype(np.float32)
+            elif name.startswith("U"):
+                a = rng.standard_normal((cols, rows))
+                q, r = np.linalg.qr(a)
+                q = q * np.sign(np.diag(r))
+                w[name] = q.T.astype(np.float32)
+            else:
+                b = np.zeros(cols, dtype=np.float32)
+                b[W:2 * W] = 1.0
+                w[name] = b
+        self.set_weights(w, self.precision or hipabi.KL_PREC_SPLIT)
+
+    def prepare(self, precision):
+        with self.torch.cuda.device(self.device):
+            hipabi.check(self.lib.kl_prepare(self.handle, int(precision), self._stream()), "kl_prepare")
+        self.precision = int(precision)
+
+    # ------------------------------------------------------------------ windows
+    def _workspace(self, B, T, training):
+        key = (B, T, bool(training))
+        if self._ws_key != key:
+            n = self.lib.kl_window_workspace_bytes(self.handle, B, T, 1 if training else 0)
+            self._ws = None
+            self._ws = self.torch.empty(n, dtype=self.torch.uint8, device=self.device)
+            self._ws_key = key
+        return self._ws
+
+    def reset_states(self, B=None, rows=None):
+        """Keras reset_states (rating.py:475, 555; callbacks.py:58, 69)."""
+        if self.states is None or (B is not None and self.states.shape[0] != B):
+            self.states = self.torch.zeros((B or 1, 2 * self.depth, self.width), dtype=self.torch.float32,
+                                           device=self.device)
+        elif rows is None:
+            self.states.zero_()
+        else:
+            self.states[self.torch.as_tensor(rows, device=self.device, dtype=self.torch.long)] = 0
+
+    def _dev_i32(self, a):
+        if isinstance(a, self.torch.Tensor):
+            return a.to(device=self.device, dtype=self.torch.int32).contiguous()
+        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
+
+    def forward_window(self, idx, ctx, tgt=None, want_probs=True):
+        """idx [B,T], ctx [B,T,n_ctx], tgt [B,T] (-1 = padded) or None.
+        Returns probs [B,T,V] (numpy) or None; with tgt also accumulates loss_acc."""
+        torch = self.torch
+        idx_d = self._dev_i32(idx)
+        B, T = idx_d.shape
+        ctx_d = self._dev_i32(ctx) if self.n_ctx else None
+        tgt_d = self._dev_i32(tgt) if tgt is not None else None
+        if self.states is None or self.states.shape[0] != B:
+            self.reset_states(B)
+        if self.precision == 0:
+            raise hipabi.KlError("weights not prepared")
+        ws = self._workspace(B, T, False)
+        probs = torch.empty((B, T, self.voc_size), dtype=torch.float32, device=self.device) if want_probs else None
+        with torch.cuda.device(self.device):
+            hipabi.check(self.lib.kl_forward_window(self.handle, B, T, _ptr(idx_d), _ptr(ctx_d), _ptr(tgt_d),
+                                                    _ptr(self.states), _ptr(probs), _ptr(self.loss_acc), _ptr(ws),
+                                                    ws.numel(), self._stream()), "kl_forward_window")
+        return probs
+
+    def draw_dropout_masks(self, B):
+        """Inverted-dropout keep masks [L][B][W], time-constant per window (rating.py:146-152)."""
+        keep = self._rng.random((self.depth, B, self.width)) >= DROPOUT_RATE
+        m = (keep / (1.0 - DROPOUT_RATE)).astype(np.float32)
+        m[0] = 1.0
+        return m
+
+    def ensure_training_buffers(self):
+        torch = self.torch
+        if self.grads is None:
+            self.grads = torch.zeros_like(self.params)
+            self.adam_m = torch.zeros_like(self.params)
+            self.adam_v = torch.zeros_like(self.params)
+            self.adam_t = 0
+
+    def train_window(self, idx, ctx, tgt, masks=None):
+        """forward + backward of one batch of B stateful windows; fills self.grads."""
+        torch = self.torch
+        self.ensure_training_buffers()
+        if self.precision != hipabi.KL_PREC_BF16:
+            self.prepare(hipabi.KL_PREC_BF16)
+        idx_d = self._dev_i32(idx)
+        B, T = idx_d.shape
+        ctx_d = self._dev_i32(ctx) if self.n_ctx else None
+        tgt_d = self._dev_i32(tgt)
+        if self.states is None or self.states.shape[0] != B:
+            self.reset_states(B)
+        masks_d = None
+        if masks is not None:
+            masks_d = masks if isinstance(masks, torch.Tensor) else torch.from_numpy(
+                np.ascontiguousarray(masks, dtype=np.float32)).to(self.device)
+        ws = self._workspace(B, T, True)
+        with torch.cuda.device(self.device):
+            hipabi.check(self.lib.kl_train_window(self.handle, B, T, _ptr(idx_d), _ptr(ctx_d), _ptr(tgt_d),
+                                                  _ptr(self.states), _ptr(masks_d), _ptr(self.grads),
+                                                  _ptr(self.loss_acc), _ptr(ws), ws.numel(), self._stream()),
+                         "kl_train_window")
+
+    def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7, clip=1.0):
+        """Keras-2.3 Adam(clipvalue=1.0) (rating.py:178)."""
+        self.adam_t += 1
+        with self.torch.cuda.device(self.device):
+            hipabi.check(self.lib.kl_adam_step(self.handle, _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
+                                               self.adam_t, lr, b1, b2, eps, clip, self._stream()), "kl_adam_step")
+
+    def read_loss(self, reset=True):
+        """(CE mean, accuracy, regulariser) accumulated since the last reset."""
+        v = self.loss_acc.detach().cpu().numpy().copy()
+        if reset:
+            self.loss_acc.zero_()
+        return float(v[0]), float(v[1]), float(v[2])
+
+    # ------------------------------------------------------------------ incremental
+    def ensure_pool(self, n_slots):
+        torch = self.torch
+        if self.pool is None or self.pool.shape[0] < n_slots:
+            new = torch.zeros((n_slots, 2 * self.depth, self.width), dtype=torch.float32, device=self.device)
+            if self.pool is not None:
+                new[:self.pool.shape[0]] = self.pool
+            self.pool = new
+        return self.pool
+
+    def step_slots(self, idx, ctx, slot_in, slot_out):
+        """One LSTM step for n hypotheses whose states live in pool slots
+        (device-resident variant of rating.py:578-639).  Returns probs tensor [n,V]."""
+        torch = self.torch
+        idx_d = self._dev_i32(idx).reshape(-1)
+        n = idx_d.numel()
+        ctx_d = self._dev_i32(ctx).reshape(n, -1) if self.n_ctx else None
+        si = self._dev_i32(slot_in).reshape(-1)
+        so = self._dev_i32(slot_out).reshape(-1)
+        probs = torch.empty((n, self.voc_size), dtype=torch.float32, device=self.device)
+        nws = self.lib.kl_step_workspace_bytes(self.handle, n)
+        if self._step_ws is None or self._step_ws.numel() < nws:
+            self._step_ws = torch.empty(nws, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            hipabi.check(self.lib.kl_step_batch(self.handle, n, _ptr(idx_d), _ptr(ctx_d), _ptr(self.pool), _ptr(si),
+                                                _ptr(so), _ptr(probs), _ptr(self._step_ws), self._step_ws.numel(),
+                                                self._stream()), "kl_step_batch")
+        return probs
+
+    def state_dist2(self, a, b, k):
+        torch = self.torch
+        a_d, b_d = self._dev_i32(a).reshape(-1), self._dev_i32(b).reshape(-1)
+        out = torch.empty(a_d.numel(), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            hipabi.check(self.lib.kl_state_dist2(self.handle, a_d.numel(), _ptr(self.pool), _ptr(a_d), _ptr(b_d), int(k),
+                                                 _ptr(out), self._stream()), "kl_state_dist2")
+        return out

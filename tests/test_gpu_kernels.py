@@ -1,0 +1,245 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every test calls the HIP path
+through the C ABI (ocrd_keraslm_amd/libkeraslm_hip.so) and compares with the numpy
+oracle (oracle/lstm_oracle.py) on the same seeded inputs.
+
+Tolerances: north_star asks for probabilities within 1e-3 of the reference; the
+split-bf16 inference path is held to 2e-5, the bf16 training path to bf16-level
+relative error on gradients (stated per test)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import lstm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def bf16_bits(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def bits_to_f32(b):
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def dev(a):
+    torch = _torch()
+    if a.dtype == np.uint16:
+        return torch.from_numpy(a.view(np.int16)).cuda()
+    return torch.from_numpy(a).cuda()
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+@pytest.mark.parametrize("M,N,K,out_mode,splits", [
+    (128, 128, 64, 0, 1), (200, 136, 72, 0, 1), (64, 2048, 512, 1, 1), (1, 16, 8, 0, 1),
+    (512, 2048, 4096, 2, 8), (130, 70, 200, 2, 3), (4096, 256, 512, 0, 1)])
+def test_gemm_tn(M, N, K, out_mode, splits):
+    torch = _torch()
+    from ocrd_keraslm_amd.lib import hipabi
+    lib = hipabi.load()
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = bf16_bits(rng.standard_normal((M, K)).astype(np.float32))
+    B = bf16_bits(rng.standard_normal((N, K)).astype(np.float32) * (1 + np.arange(N)[:, None] % 5))
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = bits_to_f32(A).astype(np.float64) @ bits_to_f32(B).astype(np.float64).T + bias
+    Ad, Bd, biasd = dev(A), dev(B), dev(bias)
+    if out_mode == 1:
+        Cd = torch.zeros((M, N), dtype=torch.int16, device="cuda")
+    else:
+        Cd = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    hipabi.check(lib.kl_test_gemm_tn(ptr(Ad), ptr(Bd), ptr(Cd), ptr(biasd), M, N, K, K, K, N, out_mode, splits, None))
+    torch.cuda.synchronize()
+    if out_mode == 1:
+        got = bits_to_f32(Cd.cpu().numpy().view(np.uint16))
+        tol = 1e-2
+    else:
+        got = Cd.cpu().numpy()
+        tol = 1e-5
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= tol * scale, (np.abs(got - ref).max(), scale)
+
+
+@pytest.mark.parametrize("M,N,K,split", [(5, 20, 64, 3), (33, 256, 512, 3), (256, 100, 128, 1), (64, 2048, 512, 3)])
+def test_thin_gemm(M, N, K, split):
+    torch = _torch()
+    from ocrd_keraslm_amd.lib import hipabi
+    lib = hipabi.load()
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Wt = (rng.standard_normal((N, K)) * (1 + np.arange(N)[:, None] % 3)).astype(np.float32)
+    hi = bf16_bits(Wt)
+    lo = bf16_bits(Wt - bits_to_f32(hi))
+    Ad, hid, lod = dev(A), dev(hi), dev(lo)
+    Cd = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    hipabi.check(lib.kl_test_thin_gemm(ptr(Ad), K, ptr(hid), ptr(lod), K, M, N, K, ptr(Cd), N, split, None))
+    torch.cuda.synchronize()
+    got = Cd.cpu().numpy()
+    if split == 3:
+        ref = A.astype(np.float64) @ Wt.astype(np.float64).T
+        tol = 3e-5
+    else:
+        ref = bits_to_f32(bf16_bits(A)).astype(np.float64) @ bits_to_f32(hi).astype(np.float64).T
+        tol = 1e-5
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+
+
+def make_model(depth, width, voc, n_ctx=1, seed=4, emb_std=0.5):
+    from ocrd_keraslm_amd.lib.engine import HipLM
+    cfg = O.ModelConfig(depth, width, voc, n_ctx)
+    w = O.init_weights(cfg, seed=seed, emb_std=emb_std, dtype=np.float32)
+    lm = HipLM(depth, width, voc, n_ctx)
+    return cfg, w, lm
+
+
+@pytest.mark.parametrize("depth,width,voc,n,n_ctx", [(2, 64, 50, 5, 1), (2, 512, 256, 70, 1), (1, 128, 40, 33, 1),
+                                                     (3, 96, 30, 17, 2)])
+def test_step_batch_parity(depth, width, voc, n, n_ctx):
+    """S1 (rating.py:578-639): chained incremental steps through pool slots."""
+    torch = _torch()
+    from ocrd_keraslm_amd.lib import hipabi
+    cfg, w, lm = make_model(depth, width, voc, n_ctx)
+    lm.set_weights(w, hipabi.KL_PREC_SPLIT)
+    lm.ensure_pool(2 * n)
+    rng = np.random.default_rng(3)
+    ctx = rng.integers(0, 200, (n, n_ctx))
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    st = O.zero_states(cfg, n, np.float64)
+    a, b = np.arange(n), np.arange(n, 2 * n)
+    worst = 0.0
+    for step in range(24):
+        idx = rng.integers(0, voc, n)
+        ref, st = O.step_batch(cfg, w64, idx, ctx, st)
+        probs = lm.step_slots(idx, ctx, a, b).cpu().numpy()
+        a, b = b, a
+        worst = max(worst, np.abs(probs - ref).max())
+    assert worst < 2e-5, worst
+    pool = lm.pool.cpu().numpy()
+    for k in range(2 * depth):
+        assert np.abs(pool[a, k] - st[k]).max() < 1e-4
+
+
+def test_step_batch_bf16_within_1e3():
+    from ocrd_keraslm_amd.lib import hipabi
+    depth, width, voc, n = 2, 512, 256, 64
+    cfg, w, lm = make_model(depth, width, voc)
+    lm.set_weights(w, hipabi.KL_PREC_BF16)
+    lm.ensure_pool(2 * n)
+    rng = np.random.default_rng(3)
+    ctx = rng.integers(0, 200, (n, 1))
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    st = O.zero_states(cfg, n, np.float64)
+    a, b = np.arange(n), np.arange(n, 2 * n)
+    worst = 0.0
+    for step in range(64):
+        idx = rng.integers(1, voc, n)
+        ref, st = O.step_batch(cfg, w64, idx, ctx, st)
+        probs = lm.step_slots(idx, ctx, a, b).cpu().numpy()
+        a, b = b, a
+        worst = max(worst, np.abs(probs - ref).max())
+    assert worst < 1e-3, worst
+
+
+@pytest.mark.parametrize("depth,width,voc,B,T,n_ctx", [(2, 64, 50, 1, 32, 1), (2, 128, 60, 3, 16, 1),
+                                                       (1, 128, 40, 1, 64, 1), (2, 512, 256, 2, 24, 1),
+                                                       (3, 64, 30, 2, 7, 2)])
+def test_forward_window_parity(depth, width, voc, B, T, n_ctx):
+    """F1-F6 stateful windows (rating.py:490, 516): two consecutive windows carry state."""
+    from ocrd_keraslm_amd.lib import hipabi
+    cfg, w, lm = make_model(depth, width, voc, n_ctx)
+    lm.set_weights(w, hipabi.KL_PREC_SPLIT)
+    lm.reset_states(B)
+    rng = np.random.default_rng(9)
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    st = O.zero_states(cfg, B, np.float64)
+    for win in range(2):
+        idx = rng.integers(0, voc, (B, T))
+        ctx = rng.integers(0, 200, (B, 1, n_ctx)).repeat(T, axis=1)
+        tgt = rng.integers(0, voc, (B, T))
+        tgt[:, -2:] = -1
+        ref, st, _ = O.forward_window(cfg, w64, idx, ctx, st)
+        lm.loss_acc.zero_()
+        probs = lm.forward_window(idx, ctx, tgt).cpu().numpy()
+        assert np.abs(probs - ref).max() < 2e-5
+        ce, acc, _ = O.crossentropy(ref, tgt)
+        l, a, _ = lm.read_loss()
+        assert abs(l - ce) < 1e-4 * max(1, ce)
+        assert abs(a - acc) < 1e-6
+    states = lm.states.cpu().numpy()
+    for k in range(2 * depth):
+        assert np.abs(states[:, k] - st[k]).max() < 1e-4
+
+
+@pytest.mark.parametrize("depth,width,voc,B,T,n_ctx,use_masks", [(1, 64, 40, 2, 8, 1, False), (2, 64, 50, 4, 16, 1, True),
+                                                                 (2, 128, 70, 8, 32, 1, True), (3, 64, 30, 3, 8, 2, True),
+                                                                 (2, 64, 50, 1, 5, 1, False)])
+def test_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks):
+    """B1-B7 + F7: gradients of mean CE + regularisers vs the f64 oracle.  The HIP
+    path computes in bf16 with f32 accumulation: relative error of each gradient
+    array is held to 3e-2 of its max-norm (bf16 has 8 mantissa bits)."""
+    from ocrd_keraslm_amd.lib import hipabi
+    cfg, w, lm = make_model(depth, width, voc, n_ctx, emb_std=0.3)
+    lm.set_weights(w, hipabi.KL_PREC_BF16)
+    lm.reset_states(B)
+    rng = np.random.default_rng(21)
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    idx = rng.integers(0, voc, (B, T))
+    ctx = rng.integers(0, 200, (B, 1, n_ctx)).repeat(T, axis=1)
+    tgt = rng.integers(0, voc, (B, T))
+    if T > 4:
+        tgt[0, -2:] = -1
+    st0 = [rng.standard_normal((B, width)) * 0.1 for _ in range(2 * depth)]
+    states = np.stack(st0, axis=1).astype(np.float32)   # [B][2L][W]
+    import torch
+    lm.states.copy_(torch.from_numpy(states))
+    masks = lm.draw_dropout_masks(B) if use_masks else None
+    omasks = [None] + [masks[l].astype(np.float64) for l in range(1, depth)] if use_masks else None
+    ref_p, ref_st, cache = O.forward_window(cfg, w64, idx, ctx, [s.astype(np.float64) for s in st0], omasks,
+                                            keep_cache=True)
+    ce, acc, _ = O.crossentropy(ref_p, tgt)
+    reg = O.regularisers(cfg, w64)
+    g_ref = O.backward_window(cfg, w64, idx, ctx, tgt, ref_p, cache, omasks)
+    lm.loss_acc.zero_()
+    lm.train_window(idx, ctx, tgt, masks)
+    l, a, r = lm.read_loss()
+    assert abs(l - ce) < 2e-2 * max(1.0, ce), (l, ce)
+    assert abs(r - reg) < 1e-3 * max(1.0, abs(reg)), (r, reg)
+    flat = lm.grads.cpu().numpy()
+    for name, off, rows, cols in lm.layout:
+        got = flat[off:off + rows * cols].reshape(g_ref[name].shape)
+        scale = np.abs(g_ref[name]).max() + 1e-12
+        err = np.abs(got - g_ref[name]).max() / scale
+        assert err < 3e-2, (name, err, scale)
+    st_got = lm.states.cpu().numpy()
+    for k in range(2 * depth):
+        assert np.abs(st_got[:, k] - ref_st[k]).max() < 2e-2
+
+
+def test_adam_step_matches_oracle():
+    from ocrd_keraslm_amd.lib import hipabi
+    import torch
+    cfg, w, lm = make_model(1, 64, 20)
+    lm.set_weights(w, hipabi.KL_PREC_BF16)
+    lm.ensure_training_buffers()
+    rng = np.random.default_rng(5)
+    g = (rng.standard_normal(lm.n_params) * 2).astype(np.float32)
+    opt = O.Adam(cfg)
+    wo = {k: v.copy() for k, v in w.items()}
+    for it in range(3):
+        lm.grads.copy_(torch.from_numpy(g))
+        lm.adam_step()
+        gd = {name: g[off:off + rows * cols].reshape(wo[name].shape) for name, off, rows, cols in lm.layout}
+        opt.step(wo, gd)
+    got = lm.get_weights()
+    for k in wo:
+        assert np.abs(got[k] - wo[k]).max() < 1e-6, k
