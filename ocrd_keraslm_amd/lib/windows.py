@@ -1,0 +1,136 @@
+"""Host-side data preparation of the Rater: text -> index windows.
+
+Behavioural restatement of the stateful branch of `Rater._gen_data` /
+`Rater._vectorize` / `Rater._gen_data_from_files`
+(ocrd_keraslm/lib/rating.py:977-1158), producing int32 index arrays for the HIP
+engine instead of one-hot booleans:
+
+  * windows advance by `length`; window k holds text[kT:(k+1)T] as input and the
+    same span shifted by one as target (rating.py:1050-1052);
+  * the residue after the last full window is emitted as ONE extra window holding
+    text[i:size-1] -> text[i+1:size], right-padded with index 0 for characters AND
+    contexts (rating.py:1096-1102, 1123-1143); padded target positions are all-zero
+    one-hot rows there, encoded here as -1;
+  * unmapped characters become index 0 and are reported through `on_unmapped`
+    (rating.py:1133-1135, 1149-1151);
+  * training augmentation (rating.py:1062-1077): after each full window, driven by
+    one uniform number that is re-scaled and re-used: with probability
+    `char_degradation` the window is repeated with one input column zeroed, with
+    probability `context_degradation` it is repeated with one context zeroed;
+  * the context of a file is ceil(year/10) parsed from `author_title_year.ext`
+    names, else 0 (rating.py:993-999).
+
+The stateless (non-stateful) window modes of the reference are not part of this
+round's scope.
+"""
+from __future__ import annotations
+
+import os
+import unicodedata
+from math import ceil
+
+import numpy as np
+
+CTX_VOCAB = 200
+
+
+def normalize(text):
+    return unicodedata.normalize('NFC', text)
+
+
+def read_normalize_file(file):
+    """rating.py:1320-1323"""
+    text = normalize(file.read())
+    return text, len(text)
+
+
+def context_from_filename(name):
+    """rating.py:993-999 -- `a_b_1784.txt` -> [ceil(1784/10)], anything else -> [0]."""
+    parts = os.path.basename(name).split('.')[0].split('_')
+    if len(parts) == 3:
+        return [ceil(int(parts[2]) / 10)]
+    return [0]
+
+
+def clamp_context(context):
+    """ceil(year/10) reaches 200 for years >= 1991, outside Embedding(200,10)
+    (latent bugs): clamp instead of reading out of bounds."""
+    return [min(max(int(c), 0), CTX_VOCAB - 1) for c in context]
+
+
+def encode(text, c_i, on_unmapped=None, base=0):
+    """characters -> int32 ids (0 = unmapped)"""
+    ids = np.zeros(len(text), dtype=np.int32)
+    for j, char in enumerate(text):
+        k = c_i.get(char)
+        if k is None:
+            if on_unmapped is not None:
+                on_unmapped(char, base + j)
+        else:
+            ids[j] = k
+    return ids
+
+
+def count_windows(size, length):
+    """number of batches `stateful_windows` yields (== the reference's epoch sizes
+    ceil((size-1)/length) of rating.py:487, 515 for size >= 2)."""
+    full = len(range(length, size, length))
+    last = (length + (full - 1) * length) if full else 0
+    return full + (1 if last + 1 < size else 0)
+
+
+def stateful_windows(text, context, length, c_i, train=False, rng=None, char_degradation=0.01,
+                     context_degradation=0.1, on_unmapped=None):
+    """Yield (x[T], ctx[T,C], y[T]) int32 arrays for one text, in order."""
+    size = len(text)
+    context = clamp_context(context)
+    n_ctx = len(context)
+    ids = encode(text, c_i, on_unmapped)
+    i = 0
+    for i in range(length, size, length):
+        x = ids[i - length:i].copy()
+        y = ids[i - length + 1:i + 1].copy()
+        z = np.tile(np.asarray(context, dtype=np.int32), (length, 1)) if n_ctx else np.zeros((length, 0), np.int32)
+        yield x, z, y
+        if train:
+            rand = float(rng.uniform(0, 1)) if rng is not None else float(np.random.uniform(0, 1, 1)[0])
+            rand_max = char_degradation
+            if 0 < rand < rand_max:
+                j = int((length - 1) * rand / rand_max)
+                xa = x.copy()
+                xa[j] = 0
+                yield xa, z, y
+            rand = (rand - rand_max) / (1 - rand_max)
+            rand_max = context_degradation
+            if 0 < rand < rand_max and n_ctx:
+                j = int(n_ctx * rand / rand_max)      # == int((len(x)-1)*rand/rand_max)+1 over [chars]+contexts
+                za = z.copy()
+                za[:, min(j, n_ctx - 1)] = 0
+                yield x, za, y
+    if i + 1 < size:
+        n = size - 1 - i
+        x = np.zeros(length, dtype=np.int32)
+        y = np.full(length, -1, dtype=np.int32)
+        z = np.zeros((length, n_ctx), dtype=np.int32)
+        x[:n] = ids[i:size - 1]
+        y[:n] = ids[i + 1:size]
+        if n_ctx:
+            z[:n] = np.asarray(context, dtype=np.int32)
+        yield x, z, y
+
+
+def file_windows(files, length, c_i, train=False, repeat=False, rng=None, on_new_file=None, on_unmapped=None,
+                 char_degradation=0.01, context_degradation=0.1):
+    """rating.py:977-1002: windows of a list of open text files; `on_new_file(name)`
+    is the reset hook of stateful training (callbacks.py:50-60)."""
+    while True:
+        for file in files:
+            file.seek(0)
+            if on_new_file is not None:
+                on_new_file(file.name)
+            text, _ = read_normalize_file(file)
+            yield from stateful_windows(text, context_from_filename(file.name), length, c_i, train=train, rng=rng,
+                                        char_degradation=char_degradation, context_degradation=context_degradation,
+                                        on_unmapped=on_unmapped)
+        if not repeat:
+            break
