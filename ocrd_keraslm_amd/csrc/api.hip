@@ -14,7 +14,11 @@
 //   step      L launches + logits + softmax for n hypotheses with pool slots
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <functional>
+#include <utility>
 
 #include <vector>
 
@@ -52,6 +56,9 @@ struct WindowWs {
   std::vector<void*> H;        // [(T+1)B][W]  f32 (inference) or bf16 (training)
   std::vector<float*> C;       // [(T+1)B][W]
   float* logits;               // [BT][V]
+  float* rowstat;              // [BT][2] per-row (loss, hit)
+  int *s_idx, *s_ctx, *s_tgt;  // staged inputs (fixed addresses for graph replay)
+  float *s_masks, *s_probs;
   // training only
   std::vector<bf16_t*> G, dZ, Hd;
   bf16_t *dZT, *HT, *dlogits, *dlogitsT, *OHT, *dEKT_bf, *dEK_bf;
@@ -73,6 +80,21 @@ struct kl_handle {
   size_t derived_bytes = 0;
   Derived d;
   int precision = 0;            // 0 = not prepared
+  // hipGraph cache of whole-window launch sequences (keyed by every baked-in pointer)
+  struct GraphKey {
+    int kind, B, T, flags, precision;
+    const void *states, *loss_acc, *ws, *grads;
+    bool operator==(const GraphKey& o) const {
+      return kind == o.kind && B == o.B && T == o.T && flags == o.flags && precision == o.precision &&
+             states == o.states && loss_acc == o.loss_acc && ws == o.ws && grads == o.grads;
+    }
+  };
+  std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;
+  bool graphs_enabled = true;
+  void drop_graphs() {
+    for (auto& g : graphs) hipGraphExecDestroy(g.second);
+    graphs.clear();
+  }
 };
 
 namespace {
@@ -155,6 +177,12 @@ size_t carve_window(const kl_handle* h, void* base, int B, int T, int training, 
     o.C[l] = cv.take<float>((BT + B) * W);
   }
   o.logits = cv.take<float>(BT * V);
+  o.rowstat = cv.take<float>(BT * 2);
+  o.s_idx = cv.take<int>(BT);
+  o.s_ctx = cv.take<int>(BT * (size_t)(c.n_ctx > 0 ? c.n_ctx : 1));
+  o.s_tgt = cv.take<int>(BT);
+  o.s_masks = cv.take<float>(training ? L * (size_t)B * W : 1);
+  o.s_probs = cv.take<float>(training ? 1 : BT * V);
   if (training) {
     o.G.assign(L, nullptr); o.dZ.assign(L, nullptr); o.Hd.assign(L, nullptr);
     o.dc0.assign(L, nullptr); o.dc1.assign(L, nullptr);
@@ -372,7 +400,10 @@ kl_handle* kl_create(const kl_config* cfg) {
   return h;
 }
 
-void kl_destroy(kl_handle* h) { delete h; }
+void kl_destroy(kl_handle* h) {
+  if (h) h->drop_graphs();
+  delete h;
+}
 
 size_t kl_derived_bytes(const kl_handle* h) { return h ? carve_derived(h, nullptr, nullptr) : 0; }
 
@@ -384,7 +415,10 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->derived_bytes = derived_bytes;
   carve_derived(h, derived, &h->d);
   h->precision = 0;
-  return 0;
+  h->drop_graphs();
+  const char* env = getenv("KL_GRAPH");
+  h->graphs_enabled = !(env && env[0] == '0');
+  return kl_zero_page_ready();
 }
 
 int kl_prepare(kl_handle* h, int precision, void* stream) {
@@ -399,7 +433,7 @@ size_t kl_window_workspace_bytes(const kl_handle* h, int B, int T, int training)
   return carve_window(h, nullptr, B, T, training, nullptr);
 }
 
-int kl_forward_window(kl_handle* h, int B, int T, const int32_t* idx, const int32_t* ctx, const int32_t* tgt,
+static int forward_window_body(kl_handle* h, int B, int T, const int32_t* idx, const int32_t* ctx, const int32_t* tgt,
                       float* states, float* probs, float* loss_acc, void* ws, size_t ws_bytes, void* stream) {
   if (!h || !idx || !states || !ws || B < 1 || T < 1) return KL_ERR_ARG;
   if (h->cfg.n_ctx > 0 && !ctx) return KL_ERR_ARG;
@@ -415,7 +449,7 @@ int kl_forward_window(kl_handle* h, int B, int T, const int32_t* idx, const int3
   op.WT_hi = h->d.E_hi; op.WT_lo = h->precision == 3 ? h->d.E_lo : nullptr; op.ldw = W; op.K = W;
   KL_TRY(kl_launch_thin_gemm(&op, B * T, V, w.logits, V, nullptr, h->precision, s));
   KL_TRY(kl_launch_softmax_ce(w.logits, V, B * T, V, tgt, B, T, 1.0f / ((float)B * T), nullptr, 0,
-                              tgt ? loss_acc : nullptr, 1, s));
+                              tgt ? loss_acc : nullptr, w.rowstat, 1, s));
   if (probs) {
     if (B == 1) KL_TRY(hip_ok(hipMemcpyAsync(probs, w.logits, (size_t)T * V * sizeof(float), hipMemcpyDeviceToDevice, s)));
     else KL_TRY(kl_launch_rows_tm_to_bm(w.logits, V, probs, B, T, V, s));
@@ -423,7 +457,7 @@ int kl_forward_window(kl_handle* h, int B, int T, const int32_t* idx, const int3
   return 0;
 }
 
-int kl_train_window(kl_handle* h, int B, int T, const int32_t* idx, const int32_t* ctx, const int32_t* tgt,
+static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, const int32_t* ctx, const int32_t* tgt,
                     float* states, const float* masks, float* grads, float* loss_acc, void* ws, size_t ws_bytes,
                     void* stream) {
   if (!h || !idx || !tgt || !states || !grads || !ws || B < 1 || T < 1) return KL_ERR_ARG;
@@ -447,7 +481,7 @@ int kl_train_window(kl_handle* h, int B, int T, const int32_t* idx, const int32_
   const bool top_masked = masks != nullptr && L > 1;
   const bf16_t* Htop = top_masked ? w.Hd[L - 1] : (const bf16_t*)w.H[L - 1] + BW;
   KL_TRY(kl_launch_gemm_tn(Htop, d.E_hi, w.logits, nullptr, BT, V, W, W, W, V, 0, 1, 1.f, s));
-  KL_TRY(kl_launch_softmax_ce(w.logits, V, BT, V, tgt, B, T, 1.0f / (float)BT, w.dlogits, Vp, loss_acc, 1, s));
+  KL_TRY(kl_launch_softmax_ce(w.logits, V, BT, V, tgt, B, T, 1.0f / (float)BT, w.dlogits, Vp, loss_acc, w.rowstat, 1, s));
   // B1: dH = dlogits . E ; dE += dlogits^T . Htop
   KL_TRY(kl_launch_gemm_tn(w.dlogits, d.ET, w.dH, nullptr, BT, W, Vp, Vp, Vp, W, 0, 1, 1.f, s));
   if (BTp != BT) {
@@ -621,7 +655,7 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
   op.A = pool + (size_t)2 * (L - 1) * W; op.lda = slot_ld; op.row_index = slot_out; op.a_is_f32 = 1;
   op.WT_hi = d.E_hi; op.WT_lo = split == 3 ? d.E_lo : nullptr; op.ldw = W; op.K = W;
   KL_TRY(kl_launch_thin_gemm(&op, n, V, probs, V, nullptr, split, s));
-  KL_TRY(kl_launch_softmax_ce(probs, V, n, V, nullptr, n, 1, 1.f, nullptr, 0, nullptr, 0, s));
+  KL_TRY(kl_launch_softmax_ce(probs, V, n, V, nullptr, n, 1, 1.f, nullptr, 0, nullptr, nullptr, 0, s));
   return 0;
 }
 
@@ -649,3 +683,118 @@ int kl_test_thin_gemm(const float* A, long lda, const uint16_t* WT_hi, const uin
 }
 
 }  // extern "C"
+
+// Tuning hook: launch `iters` identical forward cell steps (bf16 A, split 1) on raw
+// buffers, `fused` copies per launch.  Used by tools/probe_step.py only.
+extern "C" int kl_test_fwd_step(const uint16_t* A, long lda, const uint16_t* WT, long ldw, int K, int n_ops,
+                                int n_rows, int W, int fused, int iters, float* c_out, uint16_t* h_out,
+                                void* stream) {
+  KlFwdStep st[4];
+  if (fused < 1 || fused > 4 || n_ops < 1 || n_ops > 2) return KL_ERR_ARG;
+  for (int f = 0; f < fused; ++f) {
+    KlFwdStep& S = st[f];
+    memset(&S, 0, sizeof(S));
+    S.n_rows = n_rows; S.W = W; S.split = 1; S.n_ops = n_ops;
+    for (int p = 0; p < n_ops; ++p) {
+      KlOperand& o = S.op[p];
+      o.A = A; o.lda = lda; o.WT_hi = WT + (size_t)(f * 2 + p) * (size_t)4 * W * ldw; o.ldw = ldw;
+      o.K = K; o.a_is_f32 = 0;
+    }
+    S.c_out = c_out + (size_t)f * n_rows * W; S.c_out_ld = W;
+    S.h_out_bf16 = h_out + (size_t)f * n_rows * W; S.h_out_bf16_ld = W;
+  }
+  for (int i = 0; i < iters; ++i) {
+    int e = kl_launch_fwd_steps(st, fused, (hipStream_t)stream);
+    if (e) return e;
+  }
+  return 0;
+}
+
+
+// ---- whole-window hipGraph replay ------------------------------------------------
+// A window is 2(T+L-1) dependent step launches plus ~40 helper launches; issued
+// eagerly the host launch rate (~4.5 us per launch) bounds it.  The sequence is
+// captured once per (shape, pointer set) and replayed.  Inputs are first staged
+// into fixed workspace slots so that replays read the new batch.
+namespace {
+
+int run_graphed(kl_handle* h, const kl_handle::GraphKey& key, hipStream_t s, const std::function<int()>& body) {
+  if (!h->graphs_enabled || s == nullptr) return body();   // the legacy default stream cannot be captured
+  for (auto& g : h->graphs)
+    if (g.first == key) return hip_ok(hipGraphLaunch(g.second, s));
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    h->graphs_enabled = false;
+    return body();
+  }
+  const int e = body();
+  hipGraph_t graph = nullptr;
+  const hipError_t ce = hipStreamEndCapture(s, &graph);
+  if (e != 0 || ce != hipSuccess || graph == nullptr) {
+    if (graph) hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    h->graphs_enabled = false;
+    return e != 0 ? e : body();
+  }
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (ie != hipSuccess || exec == nullptr) {
+    (void)hipGetLastError();
+    h->graphs_enabled = false;
+    return body();
+  }
+  if (h->graphs.size() >= 16) h->drop_graphs();
+  h->graphs.emplace_back(key, exec);
+  return hip_ok(hipGraphLaunch(exec, s));
+}
+
+}  // namespace
+
+extern "C" int kl_forward_window(kl_handle* h, int B, int T, const int32_t* idx, const int32_t* ctx, const int32_t* tgt,
+                                 float* states, float* probs, float* loss_acc, void* ws, size_t ws_bytes,
+                                 void* stream) {
+  if (!h || !idx || !states || !ws || B < 1 || T < 1) return KL_ERR_ARG;
+  if (h->cfg.n_ctx > 0 && !ctx) return KL_ERR_ARG;
+  if (!h->precision) return KL_ERR_STATE;
+  hipStream_t s = (hipStream_t)stream;
+  WindowWs w;
+  if (ws_bytes < carve_window(h, ws, B, T, 0, &w)) return KL_ERR_WORKSPACE;
+  const size_t BT = (size_t)B * T;
+  KL_TRY(hip_ok(hipMemcpyAsync(w.s_idx, idx, BT * sizeof(int), hipMemcpyDeviceToDevice, s)));
+  if (h->cfg.n_ctx > 0)
+    KL_TRY(hip_ok(hipMemcpyAsync(w.s_ctx, ctx, BT * h->cfg.n_ctx * sizeof(int), hipMemcpyDeviceToDevice, s)));
+  if (tgt) KL_TRY(hip_ok(hipMemcpyAsync(w.s_tgt, tgt, BT * sizeof(int), hipMemcpyDeviceToDevice, s)));
+  kl_handle::GraphKey key{0, B, T, (tgt ? 1 : 0) | (probs ? 2 : 0), h->precision, states, loss_acc, ws, nullptr};
+  KL_TRY(run_graphed(h, key, s, [&]() {
+    return forward_window_body(h, B, T, w.s_idx, w.s_ctx, tgt ? w.s_tgt : nullptr, states, probs ? w.s_probs : nullptr,
+                               loss_acc, ws, ws_bytes, stream);
+  }));
+  if (probs)
+    KL_TRY(hip_ok(hipMemcpyAsync(probs, w.s_probs, BT * h->cfg.voc_size * sizeof(float), hipMemcpyDeviceToDevice, s)));
+  return 0;
+}
+
+extern "C" int kl_train_window(kl_handle* h, int B, int T, const int32_t* idx, const int32_t* ctx, const int32_t* tgt,
+                               float* states, const float* masks, float* grads, float* loss_acc, void* ws,
+                               size_t ws_bytes, void* stream) {
+  if (!h || !idx || !tgt || !states || !grads || !ws || B < 1 || T < 1) return KL_ERR_ARG;
+  if (h->cfg.n_ctx > 0 && !ctx) return KL_ERR_ARG;
+  if (h->precision != KL_PREC_BF16) return KL_ERR_STATE;
+  hipStream_t s = (hipStream_t)stream;
+  WindowWs w;
+  if (ws_bytes < carve_window(h, ws, B, T, 1, &w)) return KL_ERR_WORKSPACE;
+  const size_t BT = (size_t)B * T;
+  KL_TRY(hip_ok(hipMemcpyAsync(w.s_idx, idx, BT * sizeof(int), hipMemcpyDeviceToDevice, s)));
+  if (h->cfg.n_ctx > 0)
+    KL_TRY(hip_ok(hipMemcpyAsync(w.s_ctx, ctx, BT * h->cfg.n_ctx * sizeof(int), hipMemcpyDeviceToDevice, s)));
+  KL_TRY(hip_ok(hipMemcpyAsync(w.s_tgt, tgt, BT * sizeof(int), hipMemcpyDeviceToDevice, s)));
+  if (masks)
+    KL_TRY(hip_ok(hipMemcpyAsync(w.s_masks, masks, (size_t)h->cfg.depth * B * h->cfg.width * sizeof(float),
+                                 hipMemcpyDeviceToDevice, s)));
+  kl_handle::GraphKey key{1, B, T, masks ? 1 : 0, h->precision, states, loss_acc, ws, grads};
+  return run_graphed(h, key, s, [&]() {
+    return train_window_body(h, B, T, w.s_idx, w.s_ctx, w.s_tgt, states, masks ? w.s_masks : nullptr, grads, loss_acc,
+                             ws, ws_bytes, stream);
+  });
+}

@@ -90,7 +90,7 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ in, long ld_in, int
 // targets are [B][T] with -1 = all-zero one-hot row (padded tail).
 __global__ void softmax_ce_kernel(float* __restrict__ logits, long ld, int rows, int V, const int* __restrict__ tgt,
                                   int B, int T, float inv_count, bf16_t* __restrict__ dlogits, long ld_dl,
-                                  float* __restrict__ loss_acc, int time_major) {
+                                  float* __restrict__ rowstat, int time_major) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -137,14 +137,31 @@ __global__ void softmax_ce_kernel(float* __restrict__ logits, long ld, int rows,
       d[v] = f2bf(g * inv_count);
     }
   }
-  if (lane == 0 && loss_acc) {
+  if (lane == 0 && rowstat) {
+    float l = 0.f;
     if (valid) {
       const float pc = fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f);
-      atomicAdd(loss_acc + 0, -logf(pc) * inv_count);
+      l = -logf(pc) * inv_count;
     }
     const int tsafe = valid ? t : 0;
-    if (amax == tsafe) atomicAdd(loss_acc + 1, inv_count);
+    rowstat[2 * (long)row] = l;
+    rowstat[2 * (long)row + 1] = (amax == tsafe) ? inv_count : 0.f;
   }
+}
+
+// sum of the per-row (loss, hit) pairs -> loss_acc[0], loss_acc[1]; one block
+__global__ void rowstat_reduce_kernel(const float* __restrict__ rowstat, int rows, float* __restrict__ loss_acc) {
+  __shared__ float red[2][1024];
+  float a = 0.f, b = 0.f;
+  for (int r = threadIdx.x; r < rows; r += blockDim.x) { a += rowstat[2 * (long)r]; b += rowstat[2 * (long)r + 1]; }
+  red[0][threadIdx.x] = a;
+  red[1][threadIdx.x] = b;
+  __syncthreads();
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { atomicAdd(loss_acc + 0, red[0][0]); atomicAdd(loss_acc + 1, red[1][0]); }
 }
 
 // ---- clip + Adam (Keras 2.3.1 formula; lr_t carries the bias correction) ---------
@@ -192,10 +209,12 @@ __global__ void reg_table_kernel(const float* __restrict__ X, int R, int D, floa
     s1[d] = a - X[(long)(R - 1) * D + d];
     s2[d] = a - X[(long)1 * D + d];
   }
-  for (int r = tid; r < R; r += nt) {
+  for (int r = tid >> 6; r < R; r += nt >> 6) {
     float a = 0.f;
-    for (int d = 0; d < D; ++d) { const float x = X[(long)r * D + d]; a += x * x; }
-    nr[r] = a;
+    for (int d = tid & 63; d < D; d += 64) { const float x = X[(long)r * D + d]; a += x * x; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if ((tid & 63) == 0) nr[r] = a;
   }
   __syncthreads();
   const float c_low = mode == 0 ? 0.01f : 0.02f;
@@ -293,10 +312,13 @@ int kl_launch_f32_to_bf16_t(const float* in, long ld_in, int rows, int cols, bf1
 }
 
 int kl_launch_softmax_ce(float* logits, long ld, int rows, int V, const int* tgt, int B, int T, float inv_count,
-                         bf16_t* dlogits, long ld_dl, float* loss_acc, int time_major, hipStream_t stream) {
+                         bf16_t* dlogits, long ld_dl, float* loss_acc, float* rowstat, int time_major,
+                         hipStream_t stream) {
   dim3 grid((rows + 3) / 4);
+  const bool stats = tgt != nullptr && loss_acc != nullptr && rowstat != nullptr;
   hipLaunchKernelGGL(softmax_ce_kernel, grid, dim3(256), 0, stream, logits, ld, rows, V, tgt, B, T, inv_count,
-                     dlogits, ld_dl, loss_acc, time_major);
+                     dlogits, ld_dl, stats ? rowstat : nullptr, time_major);
+  if (stats) hipLaunchKernelGGL(rowstat_reduce_kernel, dim3(1), dim3(1024), 0, stream, rowstat, rows, loss_acc);
   return ok();
 }
 

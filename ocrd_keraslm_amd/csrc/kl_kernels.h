@@ -61,6 +61,7 @@ struct KlBwdStep {
   bf16_t* dz_out; long dz_ld;                   // [rows][4W]
 };
 int kl_launch_bwd_steps(const KlBwdStep* steps, int n_steps, hipStream_t stream);
+int kl_zero_page_ready();   // resolves the zero page's device address (call outside stream capture)
 
 // thin split-precision contraction C[M,N] = A[M,K] . WT[N,K]^T (+bias) for
 // small M (tables, inference logits)
@@ -76,7 +77,8 @@ int kl_launch_transpose_bf16(const bf16_t* in, long ld_in, bf16_t* out, long ld_
 int kl_launch_f32_to_bf16_t(const float* in, long ld_in, int rows, int cols, bf16_t* out_hi, bf16_t* out_lo,
                             long ld_out, int transpose, hipStream_t stream);
 int kl_launch_softmax_ce(float* logits, long ld, int rows, int V, const int* tgt, int B, int T, float inv_count,
-                         bf16_t* dlogits, long ld_dl, float* loss_acc, int time_major_to_bt, hipStream_t stream);
+                         bf16_t* dlogits, long ld_dl, float* loss_acc, float* rowstat, int time_major,
+                         hipStream_t stream);
 int kl_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                    float eps, float clip, hipStream_t stream);
 int kl_launch_onehot_t(const int* ids, int B, int T, int n_classes, int col, int n_cols, bf16_t* out, long ld,

@@ -10,6 +10,7 @@ contraction through the hand-written gfx950 kernels behind the C ABI
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 
@@ -44,6 +45,9 @@ class HipLM:
                                  % (self.depth, self.width, self.voc_size))
         self.n_params = self.lib.kl_param_count(C.byref(self.cfg))
         self.layout = self._read_layout()
+        # all launches go to one side stream: whole windows are replayed as hipGraphs,
+        # and the legacy default stream cannot be captured
+        self.stream = torch.cuda.Stream(device=self.device)
         with torch.cuda.device(self.device):
             self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
             nbytes = self.lib.kl_derived_bytes(self.handle)
@@ -82,7 +86,18 @@ class HipLM:
         return out
 
     def _stream(self):
-        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(self.stream.cuda_stream)
+
+    @contextlib.contextmanager
+    def _launch(self):
+        """Run the enclosed launches on the engine stream, ordered after what the
+        caller's current stream has enqueued and before what it enqueues next."""
+        torch = self.torch
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            yield
+        cur.wait_stream(self.stream)
 
     def get_weights(self):
         """dict name -> float32 array in Keras shapes (E, Ctx0.., K0, U0, b0, ...)."""
@@ -100,7 +115,8 @@ class HipLM:
             if a.size != rows * cols:
                 raise ValueError("weight %s has %d elements, expected %d x %d" % (name, a.size, rows, cols))
             flat[off:off + rows * cols] = a.reshape(-1)
-        self.params.copy_(self.torch.from_numpy(flat))
+        with self._launch():
+            self.params.copy_(self.torch.from_numpy(flat))
         self.prepare(precision or self.precision or hipabi.KL_PREC_SPLIT)
 
     def init_weights(self, seed=None, emb_std=0.001):
@@ -127,7 +143,7 @@ class HipLM:
         self.set_weights(w, self.precision or hipabi.KL_PREC_SPLIT)
 
     def prepare(self, precision):
-        with self.torch.cuda.device(self.device):
+        with self._launch():
             hipabi.check(self.lib.kl_prepare(self.handle, int(precision), self._stream()), "kl_prepare")
         self.precision = int(precision)
 
@@ -160,17 +176,17 @@ class HipLM:
         """idx [B,T], ctx [B,T,n_ctx], tgt [B,T] (-1 = padded) or None.
         Returns probs [B,T,V] (numpy) or None; with tgt also accumulates loss_acc."""
         torch = self.torch
-        idx_d = self._dev_i32(idx)
-        B, T = idx_d.shape
-        ctx_d = self._dev_i32(ctx) if self.n_ctx else None
-        tgt_d = self._dev_i32(tgt) if tgt is not None else None
-        if self.states is None or self.states.shape[0] != B:
-            self.reset_states(B)
         if self.precision == 0:
             raise hipabi.KlError("weights not prepared")
-        ws = self._workspace(B, T, False)
-        probs = torch.empty((B, T, self.voc_size), dtype=torch.float32, device=self.device) if want_probs else None
-        with torch.cuda.device(self.device):
+        with self._launch():
+            idx_d = self._dev_i32(idx)
+            B, T = idx_d.shape
+            ctx_d = self._dev_i32(ctx) if self.n_ctx else None
+            tgt_d = self._dev_i32(tgt) if tgt is not None else None
+            if self.states is None or self.states.shape[0] != B:
+                self.reset_states(B)
+            ws = self._workspace(B, T, False)
+            probs = torch.empty((B, T, self.voc_size), dtype=torch.float32, device=self.device) if want_probs else None
             hipabi.check(self.lib.kl_forward_window(self.handle, B, T, _ptr(idx_d), _ptr(ctx_d), _ptr(tgt_d),
                                                     _ptr(self.states), _ptr(probs), _ptr(self.loss_acc), _ptr(ws),
                                                     ws.numel(), self._stream()), "kl_forward_window")
@@ -197,18 +213,18 @@ class HipLM:
         self.ensure_training_buffers()
         if self.precision != hipabi.KL_PREC_BF16:
             self.prepare(hipabi.KL_PREC_BF16)
-        idx_d = self._dev_i32(idx)
-        B, T = idx_d.shape
-        ctx_d = self._dev_i32(ctx) if self.n_ctx else None
-        tgt_d = self._dev_i32(tgt)
-        if self.states is None or self.states.shape[0] != B:
-            self.reset_states(B)
-        masks_d = None
-        if masks is not None:
-            masks_d = masks if isinstance(masks, torch.Tensor) else torch.from_numpy(
-                np.ascontiguousarray(masks, dtype=np.float32)).to(self.device)
-        ws = self._workspace(B, T, True)
-        with torch.cuda.device(self.device):
+        with self._launch():
+            idx_d = self._dev_i32(idx)
+            B, T = idx_d.shape
+            ctx_d = self._dev_i32(ctx) if self.n_ctx else None
+            tgt_d = self._dev_i32(tgt)
+            if self.states is None or self.states.shape[0] != B:
+                self.reset_states(B)
+            masks_d = None
+            if masks is not None:
+                masks_d = masks if isinstance(masks, torch.Tensor) else torch.from_numpy(
+                    np.ascontiguousarray(masks, dtype=np.float32)).to(self.device)
+            ws = self._workspace(B, T, True)
             hipabi.check(self.lib.kl_train_window(self.handle, B, T, _ptr(idx_d), _ptr(ctx_d), _ptr(tgt_d),
                                                   _ptr(self.states), _ptr(masks_d), _ptr(self.grads),
                                                   _ptr(self.loss_acc), _ptr(ws), ws.numel(), self._stream()),
@@ -217,7 +233,7 @@ class HipLM:
     def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7, clip=1.0):
         """Keras-2.3 Adam(clipvalue=1.0) (rating.py:178)."""
         self.adam_t += 1
-        with self.torch.cuda.device(self.device):
+        with self._launch():
             hipabi.check(self.lib.kl_adam_step(self.handle, _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
                                                self.adam_t, lr, b1, b2, eps, clip, self._stream()), "kl_adam_step")
 
@@ -242,16 +258,16 @@ class HipLM:
         """One LSTM step for n hypotheses whose states live in pool slots
         (device-resident variant of rating.py:578-639).  Returns probs tensor [n,V]."""
         torch = self.torch
-        idx_d = self._dev_i32(idx).reshape(-1)
-        n = idx_d.numel()
-        ctx_d = self._dev_i32(ctx).reshape(n, -1) if self.n_ctx else None
-        si = self._dev_i32(slot_in).reshape(-1)
-        so = self._dev_i32(slot_out).reshape(-1)
-        probs = torch.empty((n, self.voc_size), dtype=torch.float32, device=self.device)
-        nws = self.lib.kl_step_workspace_bytes(self.handle, n)
-        if self._step_ws is None or self._step_ws.numel() < nws:
-            self._step_ws = torch.empty(nws, dtype=torch.uint8, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._launch():
+            idx_d = self._dev_i32(idx).reshape(-1)
+            n = idx_d.numel()
+            ctx_d = self._dev_i32(ctx).reshape(n, -1) if self.n_ctx else None
+            si = self._dev_i32(slot_in).reshape(-1)
+            so = self._dev_i32(slot_out).reshape(-1)
+            probs = torch.empty((n, self.voc_size), dtype=torch.float32, device=self.device)
+            nws = self.lib.kl_step_workspace_bytes(self.handle, n)
+            if self._step_ws is None or self._step_ws.numel() < nws:
+                self._step_ws = torch.empty(nws, dtype=torch.uint8, device=self.device)
             hipabi.check(self.lib.kl_step_batch(self.handle, n, _ptr(idx_d), _ptr(ctx_d), _ptr(self.pool), _ptr(si),
                                                 _ptr(so), _ptr(probs), _ptr(self._step_ws), self._step_ws.numel(),
                                                 self._stream()), "kl_step_batch")
@@ -261,7 +277,23 @@ class HipLM:
         torch = self.torch
         a_d, b_d = self._dev_i32(a).reshape(-1), self._dev_i32(b).reshape(-1)
         out = torch.empty(a_d.numel(), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._launch():
             hipabi.check(self.lib.kl_state_dist2(self.handle, a_d.numel(), _ptr(self.pool), _ptr(a_d), _ptr(b_d), int(k),
                                                  _ptr(out), self._stream()), "kl_state_dist2")
         return out
+
+    # ------------------------------------------------------------------ pool access (host <-> HBM)
+    def pool_zero(self, slots):
+        with self._launch():
+            self.pool[self.torch.as_tensor(list(slots), device=self.device, dtype=self.torch.long)] = 0
+
+    def pool_read(self, slots):
+        """states of the given slots as a numpy array [n][2L][W]"""
+        with self._launch():
+            out = self.pool[self.torch.as_tensor(list(slots), device=self.device, dtype=self.torch.long)]
+        return out.cpu().numpy()
+
+    def pool_write(self, slots, values):
+        with self._launch():
+            v = self.torch.from_numpy(np.ascontiguousarray(values, dtype=np.float32)).to(self.device)
+            self.pool[self.torch.as_tensor(list(slots), device=self.device, dtype=self.torch.long)] = v

@@ -1,2 +1,789 @@
+"""Rater: character-level LSTM language model for rating text -- MI355X edition.
+
+Drop-in for `ocrd_keraslm.lib.Rater` (ocrd_keraslm/lib/rating.py:12-1238): same
+attributes, same methods, same status machine and assertion conventions.  The
+seam the reference fills with a compiled Keras model (`self.model`,
+rating.py:56) is filled here by `engine.HipLM`, which runs the network on
+hand-written gfx950 kernels; everything in this file is host logic
+(vocabulary, windowing, beam bookkeeping, training loop control).
+
+Differences that are deliberate:
+  * `streams` (new, default 1): number of independent stateful streams trained
+    in lockstep per GPU.  1 reproduces the reference's batch_size=1 stateful
+    training (rating.py:90-92); larger values are the data-parallel capability
+    north_star asks for (each stream has its own carried state and reset points).
+  * beam searches keep hypothesis states in a device-resident pool; `Node.state`
+    is then a `StateRef`.  `predict()` called directly still takes and returns
+    the reference's list-of-arrays states (rating.py:622-639).
+  * context ids are clamped to the embedding range (the reference can index
+    Embedding(200,10) out of range for years >= 1991, rating.py:111, 996).
+  * the stateless, non-incremental window modes (rating.py:93-99, 352-378) are
+    not built yet: configure() says so.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import signal
+from bisect import insort_left
+from math import ceil, exp, log
+from random import shuffle
+
+import numpy as np
+
+from . import modelio, windows
+from .node import Node
+
+PREC_BF16 = 1
+PREC_SPLIT = 3
+
+
+def _np(x):
+    """engine results are torch tensors (HIP) or numpy arrays (test doubles)"""
+    if hasattr(x, "detach"):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+class StateRef(object):
+    """Handle of one hypothesis state in the engine's device pool.  Quacks like
+    the reference's state list [h1,c1,...,hL,cL] of (1,W) arrays when indexed."""
+    __slots__ = ("pool", "slot", "__weakref__")
+
+    def __init__(self, pool, slot):
+        self.pool = pool
+        self.slot = slot
+
+    def __del__(self):
+        try:
+            self.pool.release(self.slot)
+        except Exception:
+            pass
+
+    def __len__(self):
+        return 2 * self.pool.depth
+
+    def __getitem__(self, k):
+        return self.pool.fetch(self.slot)[k][None, :]
+
+    def __bool__(self):
+        return True
+
+
+class StatePool(object):
+    """Slot allocator over engine.pool ([slots][2L][W] f32 in HBM)."""
+
+    def __init__(self, engine, depth, initial=1024):
+        self.engine = engine
+        self.depth = depth
+        self.capacity = 0
+        self.free = []
+        self._grow(initial)
+        self.zero_slot = self.take()      # never released: the all-zero state of `None`
+        self.engine.pool_zero([self.zero_slot])
+
+    def _grow(self, n):
+        new = max(n, 2 * self.capacity)
+        self.engine.ensure_pool(new)
+        self.free.extend(range(new - 1, self.capacity - 1, -1))
+        self.capacity = new
+
+    def take(self):
+        if not self.free:
+            self._grow(2 * self.capacity)
+        return self.free.pop()
+
+    def release(self, slot):
+        self.free.append(slot)
+
+    def ref(self):
+        return StateRef(self, self.take())
+
+    def fetch(self, slot):
+        return self.engine.pool_read([slot])[0]
+
+
 class Rater(object):
-    pass
+    '''A character-level RNN language model for rating text (see module docstring).
+
+    Interfaces (as the reference, rating.py:25-32):
+    - `Rater.train` : file handles of character sequences
+    - `Rater.test` : file handles of character sequences
+    - `Rater.rate2` (alias `rate_once`) : character string, one by one
+    - `Rater.rate` : character string, all at once
+    - `Rater.rate_best` : lattice graph
+    - `Rater.generate` : alternative list of characters and states
+    '''
+
+    def __init__(self, logger=None, engine_factory=None):
+        # configuration variables (rating.py:39-47)
+        self.width = 0
+        self.depth = 0
+        self.length = 0
+        self.variable_length = True
+        self.first_window = 0.1
+        self.char_degradation = 0.01
+        self.context_degradation = 0.1
+        self.stateful = True
+        self.mapping = ({}, {})
+        # configuration constants (rating.py:49-51)
+        self.batch_size = 128
+        self.validation_split = 0.2
+        self.smoothing = 0.2
+        # runtime variables (rating.py:53-59)
+        self.logger = logger or logging.getLogger(__name__)
+        self.reset_cb = None
+        self.incremental = False
+        self.model = None
+        self.history = {}
+        self.status = 0
+        self.voc_size = 0
+        # MI355X additions
+        self.streams = 1
+        self.n_ctx = 1
+        self.max_epochs = 100
+        self.patience = 3
+        self.seed = None
+        self._engine_factory = engine_factory
+        self._pool = None
+        self._stop = False
+
+    # ------------------------------------------------------------------ definition
+    def configure(self):
+        '''Define the model for the given parameters (rating.py:61-179).'''
+        if self.stateful:
+            self.variable_length = False
+            self.first_window = 0
+            self.batch_size = 1
+        elif not self.incremental:
+            raise NotImplementedError("stateless non-incremental window mode is not built on the MI355X path yet "
+                                      "(use stateful=True, or incremental=True for predict/generate/rate_best)")
+        self.logger.info('using MI355X HIP implementation to compile %s %s model of depth %d width %d length %s size %d',
+                         'stateful' if self.stateful else 'stateless',
+                         'incremental' if self.incremental else 'contiguous',
+                         self.depth, self.width,
+                         'variable' if self.variable_length else str(self.length), self.voc_size)
+        previous = self.model
+        if self.voc_size > 0:
+            factory = self._engine_factory
+            if factory is None:
+                from .engine import HipLM
+                factory = HipLM
+            self.model = factory(int(self.depth), int(self.width), int(self.voc_size), int(self.n_ctx))
+            self.model.init_weights(seed=self.seed)
+        else:
+            self.model = None     # vocabulary unknown before the first training (rating.py:230)
+        del previous
+        self._pool = None
+        self.status = 1
+
+    def underspecify_contexts(self):
+        '''Default input for context variables (rating.py:181-185).'''
+        self.logger.info('using underspecification (zero) for %d context variables', self.n_ctx)
+        return [0] * self.n_ctx
+
+    # ------------------------------------------------------------------ training
+    def train(self, data, val_data=None):
+        '''Train model on text files (rating.py:248-310): stateful windows, one
+        optimizer step per batch, validation after each epoch, early stopping with
+        best-weights restore, per-epoch checkpoints, NaN abort, SIGINT graceful stop,
+        state reset at file boundaries and before validation (callbacks.py:36-69).'''
+        assert self.status > 0
+        assert self.incremental is False
+        (training_data, validation_data, _split, training_epoch_size, validation_epoch_size,
+         total_size, steps) = self._split_data(data, val_data)
+        self.logger.info('training on %d files / %d batches per epoch / %d character tokens for %d character types',
+                         len(training_data), training_epoch_size, total_size, self.voc_size)
+        self.reconfigure_for_mapping()
+        lm = self.model
+        if getattr(lm, "precision", PREC_BF16) != PREC_BF16:
+            lm.prepare(PREC_BF16)
+        sync = self._grad_sync()
+        rank, world = sync.rank, sync.world
+        B = max(1, int(self.streams))
+        n_streams = B * world
+        if len(training_data) < n_streams or len(validation_data) < 1:
+            assert n_streams == 1 or len(training_data) >= n_streams, \
+                "need at least %d training files for %d streams" % (n_streams, n_streams)
+        rng = np.random.default_rng(self.seed)
+        reset_rows = set()
+
+        def make_streams(files, train):
+            gens = []
+            for s in range(B):
+                gid = rank * B + s
+                mine = files[gid::n_streams] or files[:1]
+
+                def hook(name, s=s):
+                    if train:
+                        reset_rows.add(s)    # ResetStatesCallback.reset (callbacks.py:50-53)
+                gens.append(windows.file_windows(mine, self.length, self.mapping[0], train=train, repeat=True, rng=rng,
+                                                 on_new_file=hook, on_unmapped=self._unmapped_input,
+                                                 char_degradation=self.char_degradation,
+                                                 context_degradation=self.context_degradation))
+            return gens
+
+        def next_batch(gens):
+            xs, zs, ys = [], [], []
+            for g in gens:
+                x, z, y = next(g)
+                xs.append(x); zs.append(z); ys.append(y)
+            return np.stack(xs), np.stack(zs), np.stack(ys)
+
+        train_gens = make_streams(training_data, True)
+        val_gens = make_streams(validation_data, False)
+        steps_per_epoch = max(1, ceil(training_epoch_size / n_streams))
+        val_steps = max(1, ceil(validation_epoch_size / n_streams))
+        history = {'loss': [], 'accuracy': [], 'val_loss': [], 'val_accuracy': []}
+        best_val, best_weights, wait, stopped_epoch = None, None, 0, 0
+        self._stop = False
+        received = {'n': 0}
+
+        def stopper(sig, _frame):      # StopSignalCallback (callbacks.py:6-34)
+            if received['n']:
+                self.logger.critical('interrupting')
+                raise SystemExit(0)
+            self.logger.critical('stopping training')
+            received['n'] += 1
+            self._stop = True
+        try:
+            old_handler = signal.signal(signal.SIGINT, stopper)
+        except ValueError:             # not in the main thread
+            old_handler = None
+        nan_abort = False
+        try:
+            lm.reset_states(B)
+            for epoch in range(self.max_epochs):
+                lm.read_loss(reset=True)
+                loss_sum = acc_sum = 0.0
+                for step in range(steps_per_epoch):
+                    x, z, y = next_batch(train_gens)
+                    if reset_rows:     # on_batch_begin: reset streams that entered a new file
+                        lm.reset_states(B, rows=sorted(reset_rows))
+                        reset_rows.clear()
+                    masks = lm.draw_dropout_masks(B)
+                    lm.train_window(x, z, y, masks)
+                    sync.average(lm)
+                    lm.adam_step()
+                    ce, acc, reg = lm.read_loss(reset=True)
+                    loss = ce + reg
+                    loss_sum += loss
+                    acc_sum += acc
+                    if loss > 25:
+                        self.logger.warning('huge loss at batch %d', step)
+                    if not np.isfinite(loss):    # TerminateOnNaN
+                        self.logger.critical('NaN loss at batch %d', step)
+                        nan_abort = True
+                        break
+                    if self._stop:
+                        break
+                history['loss'].append(loss_sum / (step + 1))
+                history['accuracy'].append(acc_sum / (step + 1))
+                if nan_abort:
+                    break
+                # validation: states reset first (callbacks.py:67-69); dropout/regularisers off
+                lm.reset_states(B)
+                lm.prepare(PREC_BF16)
+                v_loss = v_acc = 0.0
+                for _ in range(val_steps):
+                    x, z, y = next_batch(val_gens)
+                    lm.forward_window(x, z, y, want_probs=False)
+                    ce, acc, _ = lm.read_loss(reset=True)
+                    v_loss += ce
+                    v_acc += acc
+                v_loss, v_acc = sync.mean_scalars(v_loss / val_steps, v_acc / val_steps)
+                history['val_loss'].append(v_loss)
+                history['val_accuracy'].append(v_acc)
+                lm.reset_states(B)
+                self.logger.info('epoch %d: loss %.4f accuracy %.4f val_loss %.4f val_accuracy %.4f', epoch + 1,
+                                 history['loss'][-1], history['accuracy'][-1], v_loss, v_acc)
+                if best_val is None or v_loss < best_val:      # EarlyStopping / ModelCheckpoint
+                    best_val, wait = v_loss, 0
+                    best_weights = lm.get_weights()
+                    if rank == 0:
+                        self._checkpoint('ckpt.%02d-%.2f.h5' % (epoch + 1, v_loss))
+                else:
+                    wait += 1
+                    if wait >= self.patience:
+                        stopped_epoch = epoch
+                        lm.set_weights(best_weights, PREC_BF16)
+                        self.logger.info('early stopping at epoch %d, best weights restored', epoch + 1)
+                        break
+                if self._stop:
+                    break
+        finally:
+            if old_handler is not None:
+                signal.signal(signal.SIGINT, old_handler)
+        self.history = history
+        if history['val_loss']:
+            self.logger.info('training finished with val_loss %f', min(history['val_loss']))
+            if (np.isnan(history['val_loss'][-1]) or stopped_epoch == 0) and best_weights is not None:
+                lm.set_weights(best_weights, PREC_BF16)     # rating.py:303-306
+            self.status = 2
+        else:
+            self.logger.critical('training failed')
+            self.status = 1
+
+    def _grad_sync(self):
+        from .distributed import GradSync
+        return GradSync()
+
+    def _checkpoint(self, filename):
+        try:
+            modelio.save_weights(filename, self.model.get_weights(), self.depth, self.n_ctx)
+        except Exception as err:     # checkpoints are best effort
+            self.logger.warning('cannot write checkpoint %s: %s', filename, err)
+
+    def print_history(self):
+        for k, v in self.history.items():
+            print(f"{k}: {v}")
+
+    def _split_data(self, data, val_data):
+        '''Read text files, split into training vs validation, count batches and update
+        the character mapping (stateful branch of rating.py:317-385).'''
+        assert self.status >= 1
+        assert self.stateful, "only the stateful mode is built"
+        shuffle(data)
+        total_size = 0
+        chars = set(self.mapping[0].keys())
+        steps = self.length
+        if val_data:
+            training_data, validation_data = data, val_data
+        else:
+            split = ceil(len(data) * self.validation_split)
+            training_data, validation_data = data[:-split], data[-split:]
+        assert training_data, "stateful mode needs at least one file for training"
+        assert validation_data, "stateful mode needs at least one file for validation"
+        for file in validation_data:
+            self.logger.info('using input %s for validation only', file.name)
+        sizes = []
+        for group in (training_data, validation_data):
+            epoch_size = 0
+            for file in group:
+                file.seek(0)
+                text, size = windows.read_normalize_file(file)
+                total_size += size
+                epoch_size += ceil((size - self.length) / steps / self.batch_size)
+                chars.update(set(text))
+            sizes.append(epoch_size)
+        chars = sorted(list(chars))
+        self.voc_size = len(chars) + 1
+        c_i = dict((c, i) for i, c in enumerate(chars, 1))
+        i_c = dict((i, c) for i, c in enumerate(chars, 1))
+        self.mapping = (c_i, i_c)
+        return training_data, validation_data, None, sizes[0], sizes[1], total_size, steps
+
+    def reconfigure_for_mapping(self):
+        '''Reconfigure the character embedding after a change of mapping, transferring
+        previous weights (rating.py:387-414).'''
+        assert self.status >= 1
+        old_voc = self.model.voc_size if self.model is not None else 0
+        if old_voc < self.voc_size:
+            if self.status >= 2 and self.model is not None:
+                self.logger.warning('transferring weights from previous model with only %d character types', old_voc)
+                old = self.model.get_weights()
+                self.configure()
+                new = self.model.get_weights()
+                for name, value in old.items():
+                    if name == 'E':
+                        new['E'][0:old_voc, :] = value
+                    else:
+                        new[name] = value
+                self.model.set_weights(new)
+            else:
+                self.configure()
+
+    def remove_from_mapping(self, char=None, idx=None):
+        '''Remove one character from mapping and shrink the embedding (rating.py:416-460).'''
+        assert self.status > 1
+        assert self.voc_size > 0
+        if not char and not idx:
+            return False
+        if char:
+            if char in self.mapping[0]:
+                idx = self.mapping[0][char]
+            else:
+                self.logger.error('unmapped character "%s" cannot be removed', char)
+                return False
+        else:
+            if idx in self.mapping[1]:
+                char = self.mapping[1][idx]
+            else:
+                self.logger.error('unmapped index "%d" cannot be removed', idx)
+                return False
+        weights = self.model.get_weights()
+        precision = getattr(self.model, "precision", PREC_SPLIT) or PREC_SPLIT
+        self.logger.warning('pruning character "%s" [%d] with norm %f', char, idx, np.linalg.norm(weights['E'][idx, :]))
+        c_i, i_c = self.mapping
+        c_i.pop(char)
+        i_c.pop(idx)
+        for i in range(idx + 1, self.voc_size):
+            other = i_c.pop(i)
+            c_i[other] -= 1
+            i_c[i - 1] = other
+        self.voc_size -= 1
+        weights['E'] = np.delete(weights['E'], idx, 0)
+        self.configure()
+        self.model.set_weights(weights, precision)
+        self.status = 2
+        return True
+
+    # ------------------------------------------------------------------ windowed inference
+    def _unmapped_input(self, char, position):
+        self.logger.error('unmapped character "%s" at input position %d', char, position)
+
+    def _ensure_precision(self):
+        lm = self.model
+        if getattr(lm, "precision", PREC_SPLIT) != PREC_SPLIT:
+            lm.prepare(PREC_SPLIT)
+
+    def test(self, test_data):
+        '''Evaluate model on text files: exp(mean cross-entropy) (rating.py:462-491).'''
+        assert self.status > 1
+        assert self.incremental is False
+        self._ensure_precision()
+        lm = self.model
+        lm.reset_states(1)
+        lm.read_loss(reset=True)
+        n = 0
+        total = 0.0
+        for x, z, y in windows.file_windows(test_data, self.length, self.mapping[0], on_unmapped=self._unmapped_input):
+            lm.forward_window(x[None], z[None], y[None], want_probs=False)
+            n += 1
+            if n % 64 == 0:
+                total += lm.read_loss(reset=True)[0]
+        total += lm.read_loss(reset=True)[0]
+        return exp(total / max(n, 1))
+
+    def rate(self, text, context=None):
+        '''Rate a string all at once (rating.py:493-529): probability of every
+        character given its predecessors; the first character gets 1.0.  The
+        implicit LSTM state is NOT reset and is advanced over the zero-padded tail
+        of the last window, exactly as the reference does.'''
+        assert self.status > 1
+        assert self.incremental is False
+        if not context:
+            context = self.underspecify_contexts()
+        self._ensure_precision()
+        text = windows.normalize(text)
+        size = len(text)
+        preds = []
+        for x, z, _y in windows.stateful_windows(text, context, self.length, self.mapping[0],
+                                                 on_unmapped=self._unmapped_input):
+            preds.append(_np(self.model.forward_window(x[None], z[None]))[0])
+        probs = [1.0]
+        if not preds:
+            return probs[:size]
+        preds = np.concatenate(preds, axis=0)[0:size]
+        for pred, next_char in zip(preds, list(text[1:])):
+            idx = self.mapping[0].get(next_char, 0)
+            probs.append(pred[idx])
+            if len(probs) >= size:
+                break
+        return probs
+
+    def rate2(self, text, context=None):
+        '''Rate a string one by one (rating.py:531-576): resets the state, feeds one
+        character per step, returns [(char, prob)] and the perplexity 2^(H/len).'''
+        assert self.status > 1
+        assert self.incremental is False
+        if not context:
+            context = self.underspecify_contexts()
+        context = windows.clamp_context(context)
+        self._ensure_precision()
+        text = windows.normalize(text)
+        lm = self.model
+        lm.reset_states(1)
+        z = np.asarray(context, dtype=np.int32).reshape(1, 1, -1)
+        entropy = 0
+        result = []
+        prev = 0
+        for i, char in enumerate(text):
+            if char not in self.mapping[0]:
+                self.logger.error('unmapped character "%s" at input position %d', char, i)
+                idx = 0
+            else:
+                idx = self.mapping[0][char]
+            if i == 0:
+                result.append((char, 1.0))
+            else:
+                pred = _np(lm.forward_window(np.array([[prev]], dtype=np.int32), z))[0, 0]
+                prob = float(pred[idx])
+                entropy -= log(max(prob, 1e-99), 2)
+                result.append((char, prob))
+            prev = idx
+        return result, pow(2.0, entropy / len(text))
+
+    rate_once = rate2   # historic name of the one-by-one rater (north_star / BASELINE.json)
+
+    # ------------------------------------------------------------------ incremental step
+    def _state_pool(self):
+        if self._pool is None:
+            self._pool = StatePool(self.model, self.depth)
+        return self._pool
+
+    def _ids(self, candidates):
+        c_i = self.mapping[0]
+        return np.fromiter((c_i.get(c, 0) for c in candidates), dtype=np.int32, count=len(candidates))
+
+    def _predict_refs(self, candidates, states, context):
+        """device-resident variant of predict(): states are StateRef (or None = zero
+        state); returns (probs [n,V] float32 array, list of new StateRef)."""
+        pool = self._state_pool()
+        n = len(candidates)
+        slot_in = np.fromiter((s.slot if s is not None else pool.zero_slot for s in states), dtype=np.int32, count=n)
+        new = [pool.ref() for _ in range(n)]
+        slot_out = np.fromiter((r.slot for r in new), dtype=np.int32, count=n)
+        ctx = np.tile(np.asarray(windows.clamp_context(context), dtype=np.int32), (n, 1))
+        probs = _np(self.model.step_slots(self._ids(candidates), ctx, slot_in, slot_out))
+        return probs, new
+
+    def predict(self, candidates, initial_states, context=None):
+        '''Predict character probabilities for n hypotheses at once, passing initial
+        and final states explicitly (rating.py:578-639).  `initial_states[i]` is None
+        (zero state), a list [h1,c1,...,hL,cL] of arrays, or a StateRef.  Returns
+        (list of n probability arrays [V], list of n state lists of (1,W) arrays).'''
+        assert self.status > 1
+        assert self.stateful is False
+        assert self.incremental is True
+        assert len(candidates) == len(initial_states), \
+            "number of inputs (%d) and number of states (%d) inconsistent" % (len(candidates), len(initial_states))
+        if not context:
+            context = self.underspecify_contexts()
+        self._ensure_precision()
+        pool = self._state_pool()
+        n = len(candidates)
+        refs, upload_slots, upload_vals = [], [], []
+        for state in initial_states:
+            if state is None or (not isinstance(state, StateRef) and not state):
+                refs.append(None)
+            elif isinstance(state, StateRef):
+                refs.append(state)
+            else:
+                ref = pool.ref()
+                upload_slots.append(ref.slot)
+                upload_vals.append(np.stack([np.asarray(s, dtype=np.float32).reshape(self.width) for s in state]))
+                refs.append(ref)
+        if upload_slots:
+            self.model.pool_write(upload_slots, np.stack(upload_vals))
+        probs, new = self._predict_refs(candidates, refs, context)
+        states = self.model.pool_read([r.slot for r in new])      # [n][2L][W]
+        preds = [probs[i, :] for i in range(n)]
+        final_states = [[states[i, k][None, :] for k in range(2 * self.depth)] for i in range(n)]
+        return preds, final_states
+
+    # ------------------------------------------------------------------ beam searches
+    def generate(self, prefix, length, context=None, variants=1):
+        '''Generate `length` characters after `prefix` by beam search over the 10 best
+        continuations with p >= 0.004 per hypothesis, 256 hypotheses wide
+        (rating.py:642-709).  Returns `variants` strings, each starting with prefix[-1].'''
+        assert self.status > 1
+        assert self.stateful is False
+        assert self.incremental is True
+        if not context:
+            context = self.underspecify_contexts()
+        self._ensure_precision()
+        state = None
+        for char in prefix[:-1]:
+            _, states = self._predict_refs([char], [state], context)
+            state = states[0]
+        next_fringe = [Node(state=state, value=prefix[-1], cost=0.0)]
+        i_c = self.mapping[1]
+        for _ in range(length):
+            fringe = next_fringe
+            preds, states = self._predict_refs([n.value for n in fringe], [n.state for n in fringe], context)
+            next_fringe = []
+            for j, n in enumerate(fringe):
+                pred = preds[j]
+                pred_best = np.argsort(pred)[-10:]
+                pred_best = pred_best[np.searchsorted(pred[pred_best], 0.004):]
+                costs = -np.log(pred[pred_best])
+                state = states[j]
+                for best, cost in zip(pred_best, costs):
+                    if best not in i_c:
+                        continue
+                    insort_left(next_fringe, Node(parent=n, state=state, value=i_c[best], cost=cost))
+            next_fringe = next_fringe[:256]
+        best = next_fringe[0:variants]
+        return [''.join([n.value for n in res.to_sequence()]) for res in best]
+
+    def rate_best(self, graph, start_node, end_node, start_traceback=None, context=None, lm_weight=0.5,
+                  beam_width=10, beam_clustering_dist=0):
+        '''Rate a lattice of string alternatives, decoding the best-scoring path
+        incrementally (rating.py:712-859).  `graph` is a networkx.DiGraph whose edges
+        carry `element` and `alternatives` (objects with `.Unicode`, `.conf`, `.index`).
+        Returns (path [(element, alternative, score)], entropy, traceback).'''
+        import networkx as nx
+
+        if not context:
+            context = self.underspecify_contexts()
+        self._ensure_precision()
+        if not start_traceback:
+            root = Node(state=None, value='\n', cost=0.0)
+            start_traceback = ([root], root)
+
+        def lattice_edges(G, start):
+            visited = [start]
+            for out in nx.topological_sort(G):
+                for in_, _ in G.in_edges([out]):
+                    if in_ in visited:
+                        yield in_, out
+                        visited.append(out)
+        graph.nodes[start_node]['traceback'], _ = start_traceback
+        out = 0
+        out_node = None
+        c_i = self.mapping[0]
+        for in_, out in lattice_edges(graph, start_node):
+            edge = graph.edges[in_, out]
+            element = edge['element']
+            textequivs = edge['alternatives']
+            in_node = graph.nodes[in_]
+            out_node = graph.nodes[out]
+            self.logger.debug("rating %d alternatives from %d to %d", len(textequivs), in_, out)
+            assert 'traceback' in in_node, \
+                "breadth-first search should have visited %d first in '%s'" % (in_, element.id)
+            beam = in_node['traceback']
+            final_beam = out_node['traceback'] if 'traceback' in out_node else []
+            next_beam = [Node(parent=hyp, state=hyp.state, value="", cost=0.0, extras=(element, textequiv))
+                         for hyp in beam for textequiv in textequivs]
+            unmapped_seen = dict()
+            max_batches = max(map(lambda x: len(x.Unicode), textequivs)) * 3
+            for _ in range(max_batches):
+                beam = []
+                while next_beam:
+                    candidate = next_beam.pop()       # worst first (rating.py:801)
+                    if candidate.value == candidate.extras[1].Unicode:
+                        if (beam_clustering_dist and
+                                self._history_clustering(candidate, final_beam, beam_clustering_dist)):
+                            continue
+                        insort_left(final_beam, candidate)
+                    else:
+                        insort_left(beam, candidate)
+                    if len(beam) >= self.batch_size:
+                        break
+                if not beam:
+                    break
+                elif not final_beam:
+                    pass
+                elif beam[0].cum_cost >= final_beam[0].cum_cost + 15:
+                    break
+                preds, states = self._predict_refs(
+                    [hyp.value[-1] if hyp.value else hyp.parent.value[-1] for hyp in beam],
+                    [hyp.state for hyp in beam], context)
+                for i, candidate in enumerate(beam):
+                    alt = candidate.extras[1]
+                    conf = alt.conf
+                    char = alt.Unicode[len(candidate.value)]
+                    if char not in c_i:
+                        if char not in unmapped_seen.setdefault(alt.index, []):
+                            self.logger.error('unmapped character "%s" at input alternative %d of element %s',
+                                              char, alt.index or i, element.id if element else "space")
+                            unmapped_seen[alt.index].append(char)
+                        idx = 0
+                    else:
+                        idx = c_i[char]
+                    cost = (-log(max(preds[i][idx], 1e-99), 2) * lm_weight +
+                            -log(max(conf, 1e-99), 2) * (1. - lm_weight))
+                    candidate.cum_cost += cost
+                    candidate.value += char
+                    candidate.state = states[i]
+                    if next_beam and candidate.cum_cost >= next_beam[0].cum_cost + 2.5:
+                        continue
+                    insort_left(next_beam, candidate)
+                next_beam = next_beam[:max_batches * self.batch_size]
+            out_node['traceback'] = final_beam[:beam_width]
+        assert out == end_node, \
+            'breadth-first search failed to reach true end node (%d instead of %d)' % (out, end_node)
+        assert out_node is not None and 'traceback' in out_node, \
+            "breadth-first search failed to reach end node with any result"
+        return self.next_path(out_node['traceback'], start_traceback)
+
+    def next_path(self, beam, traceback):
+        '''Advance from `traceback` to `beam` (rating.py:862-885): lock into the best
+        hypothesis' ancestor in the previous beam, emit its path, cut the others.'''
+        prev_beam, prev_start_node = traceback
+        best_node = beam[0]
+        best_path = best_node.to_sequence(stop_at=prev_beam)
+        start_node = best_path[-1]
+        result = []
+        for node in best_path:
+            if node.extras:
+                element, textequiv = node.extras
+                parent_cost = node.parent.cum_cost if node.parent else prev_start_node.cum_cost
+                score = pow(2.0, -(node.cum_cost - parent_cost) / len(textequiv.Unicode))
+                result.append((element, textequiv, score))
+        next_beam = []
+        for hyp in beam:
+            other_path = hyp.to_sequence(stop_at=[start_node])
+            if not other_path:
+                continue
+            hyp.cut_at(start_node)
+            insort_left(next_beam, hyp)
+        return result, start_node.cum_cost - prev_start_node.cum_cost, (next_beam, start_node)
+
+    def _state_distance_below(self, a, b, k, distance):
+        if isinstance(a, StateRef) and isinstance(b, StateRef):
+            d2 = float(_np(self.model.state_dist2([a.slot], [b.slot], k))[0])
+            return d2 < distance * distance
+        return np.linalg.norm(np.asarray(a[k]) - np.asarray(b[k])) < distance
+
+    def _history_clustering(self, candidate, beam, distance=5):
+        '''Whether `candidate` is redundant w.r.t. a hypothesis in `beam` with the same
+        text and close state vectors (entries k < depth of [h1,c1,...], as the reference
+        compares them, rating.py:887-916); removes the dominated one.'''
+        for hyp in beam:
+            if (candidate.value == hyp.value and
+                    all(self._state_distance_below(candidate.state, hyp.state, k, distance)
+                        for k in range(self.depth))):
+                if hyp.cum_cost < candidate.cum_cost:
+                    return True
+                beam.remove(hyp)
+                break
+        return False
+
+    # ------------------------------------------------------------------ model I/O
+    def save(self, filename):
+        '''Save weights and configuration (rating.py:918-945).'''
+        assert self.status > 1
+        config = {
+            'history': json.dumps(self.history, cls=modelio.NumpyEncoder),
+            'width': int(self.width), 'depth': int(self.depth), 'length': int(self.length),
+            'stateful': bool(self.stateful), 'variable_length': bool(self.variable_length),
+            'mapping': np.fromiter((ord(self.mapping[1][i]) if i in self.mapping[1] else 0
+                                    for i in range(self.voc_size)), dtype='uint32'),
+        }
+        modelio.save_model(filename, self.model.get_weights(), config, self.depth, self.n_ctx)
+
+    def load_config(self, filename):
+        '''Load parameters to prepare configuration (rating.py:947-964).'''
+        assert self.status == 0
+        config = modelio.load_config(filename)
+        history = config.get('history')
+        self.history = json.loads(history) if history else {}
+        self.width = int(config['width'])
+        self.depth = int(config['depth'])
+        self.length = int(config['length'])
+        self.stateful = bool(config['stateful'])
+        self.variable_length = bool(config['variable_length'])
+        mapping = config['mapping']
+        c_i = dict((chr(c), i) for i, c in enumerate(mapping) if c > 0)
+        i_c = dict((i, chr(c)) for i, c in enumerate(mapping) if c > 0)
+        self.mapping = (c_i, i_c)
+        self.voc_size = len(c_i) + 1
+
+    def load_weights(self, filename):
+        '''Load weights into the configured model (rating.py:966-974).'''
+        assert self.status > 0
+        weights = modelio.load_weights(filename, self.depth, self.width, self.n_ctx)
+        self.model.set_weights(weights, PREC_SPLIT if (self.incremental or True) else PREC_BF16)
+        self.status = 2
+
+    def print_charset(self):
+        '''Print the mapped characters (rating.py:1160-1167).'''
+        import unicodedata
+        for i, c in self.mapping[1].items():
+            print('%d: "%s"' % (i, c))
+            char = unicodedata.normalize('NFC', c)
+            if c != char:
+                self.logger.warning('mapped character "%s" (%d) should have been normalized to "%s", which is %s mapped',
+                                    c, i, char, 'also' if char in self.mapping[0] else 'not')
