@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Benchmark of the Rater hot path on MI355X (contract: see the task statement).
+
+  python bench.py --gpus N --steps K --warmup W
+
+N = 1: runs in-process.  N > 1: the driver launches this file under
+`python -m torch.distributed.run --nproc-per-node N ...`; every rank owns one GPU
+and B independent stateful streams; gradients are averaged with one RCCL all-reduce
+per step (weak scaling: global batch = B*N).
+
+A "step" = one training batch of BASELINE.json config 1 ("cfg2"): depth=2 width=512
+length=256, V=256, one context variable, B streams of T=256 characters:
+forward + backward + gradient all-reduce + clip/Adam, bf16 MFMA operands with f32
+accumulation and f32 master weights, dropout on.  Inputs (the 10M-character
+synthetic corpus) are resident in HBM before the timed region.
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline      the dominant kernel (backward cell-step launch) against the dense
+                bf16 MFMA peak: algorithmic FLOPs per launch / mean launch time,
+                timed with HIP events on the engine's stream in an extra traced step
+  cpu_baseline  the CPU restatement (oracle/, numpy f32) of the same training step
+                with the reference's own batching (1 stream x 256 chars, stateful),
+                timed on this box's host cores on a bounded sample
+  incremental   hypotheses*chars/s of the batched incremental step (cfg3:
+                1024 hypotheses x 512 chars), split-bf16 precision (parity mode)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+DEPTH, WIDTH, LENGTH, VOC, N_CTX = 2, 512, 256, 256, 1
+CORPUS = 10_000_000
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_fwd_per_char(depth=DEPTH, width=WIDTH, voc=VOC, n_ctx=N_CTX):
+    """F_fwd = sum_l 2 (D_l + W) 4W + 2 W V"""
+    f = 0
+    for l in range(depth):
+        d = width + 10 * n_ctx if l == 0 else width
+        f += 2 * (d + width) * 4 * width
+    return f + 2 * width * voc
+
+
+def flops_cell_per_char(depth=DEPTH, width=WIDTH, n_ctx=N_CTX):
+    """the LSTM contractions one cell-step launch stands for (no output projection)"""
+    return flops_fwd_per_char(depth, width, 0, n_ctx)
+
+
+def synthetic_corpus(n=CORPUS, voc=VOC, seed=0):
+    rng = np.random.default_rng(seed)
+    p = 1.0 / (np.arange(1, voc) + 1.0)
+    p /= p.sum()
+    ids = rng.choice(np.arange(1, voc), size=n, p=p).astype(np.int32)
+    ids[rng.random(n) < 0.01] = 0
+    return ids
+
+
+def cpu_baseline(seconds=15.0):
+    """CPU restatement (numpy oracle, f32) of the same training step with the
+    reference's batching: stateful, batch 1 x length 256 (rating.py:90-92)."""
+    from oracle import lstm_oracle as O
+    # a 1 x 256 stateful window is a chain of matrix-vector products: BLAS gains nothing
+    # beyond a few threads (128 threads measured 2.5x SLOWER than 8), so cap them
+    threads = min(16, os.cpu_count() or 1)
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=threads)
+    except Exception:
+        pass
+    cfg = O.ModelConfig(DEPTH, WIDTH, VOC, N_CTX)
+    w = O.init_weights(cfg, seed=1, dtype=np.float32)
+    opt = O.Adam(cfg, dtype=np.float32)
+    rng = np.random.default_rng(0)
+    ids = synthetic_corpus(64 * LENGTH + 1, VOC, 0)
+    states = O.zero_states(cfg, 1, np.float32)
+    ctx = np.full((1, LENGTH, 1), 17)
+    n = 0
+    t0 = time.time()
+    while True:
+        idx = ids[n * LENGTH:(n + 1) * LENGTH][None].astype(np.int64)
+        tgt = ids[n * LENGTH + 1:(n + 1) * LENGTH + 1][None].astype(np.int64)
+        masks = O.draw_dropout_masks(cfg, 1, rng)
+        _, _, states = O.train_step(cfg, w, opt, idx, ctx, tgt, states, masks)
+        n += 1
+        el = time.time() - t0
+        if el >= seconds or n >= 60:
+            break
+    return {"value": n * LENGTH / el, "unit": "chars/s", "cores": int(threads), "kind": "port",
+            "sample": "%d stateful windows of 1x%d chars (forward+backward+Adam, numpy f32 oracle, %.1f s)" % (n, LENGTH, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("KL_BENCH_STREAMS", "64")),
+                    help="stateful streams per GPU (B)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-incremental", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ocrd_keraslm_amd.lib import hipabi
+    from ocrd_keraslm_amd.lib.distributed import GradSync, init_from_env
+    from ocrd_keraslm_amd.lib.engine import HipLM
+
+    rank, world, local = init_from_env("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    device = "cuda:%d" % local
+    torch.cuda.set_device(local)
+    B, T = args.streams, LENGTH
+
+    lm = HipLM(DEPTH, WIDTH, VOC, N_CTX, device=device)
+    lm.init_weights(seed=1)                       # identical initial weights on every rank
+    lm.prepare(hipabi.KL_PREC_BF16)
+    lm.ensure_training_buffers()
+    sync = GradSync()
+
+    # synthetic corpus cut into B*world contiguous streams; this rank's share lives in HBM
+    corpus = synthetic_corpus()
+    n_streams = B * world
+    per = CORPUS // n_streams
+    mine = np.stack([corpus[(rank * B + s) * per:(rank * B + s + 1) * per] for s in range(B)])
+    streams = torch.from_numpy(mine).to(device)
+    rng = np.random.default_rng(7)
+    ctx_ids = torch.from_numpy(rng.integers(0, 200, size=n_streams)[rank * B:(rank + 1) * B].astype(np.int32)).to(device)
+    ctx = ctx_ids[:, None, None].expand(B, T, 1).contiguous()
+    n_windows = (per - 1) // T
+    gen = torch.Generator(device=device)
+    gen.manual_seed(2 + rank)
+    lm.reset_states(B)
+
+    def step(w):
+        w = w % n_windows
+        idx = streams[:, w * T:(w + 1) * T].contiguous()
+        tgt = streams[:, w * T + 1:(w + 1) * T + 1].contiguous()
+        keep = torch.rand((DEPTH, B, WIDTH), device=device, generator=gen) >= 0.1
+        masks = keep.to(torch.float32) / 0.9
+        lm.train_window(idx, ctx, tgt, masks)
+        sync.average(lm)
+        lm.adam_step()
+
+    for w in range(args.warmup):
+        step(w)
+    lm.read_loss()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ce, acc, reg = lm.read_loss()
+    chars = args.steps * B * T * world
+    value = chars / elapsed
+
+    # ---- roofline leg: one traced step, HIP events around the cell-step launches
+    import ctypes as C
+    roofline = None
+    if rank == 0:
+        hipabi.check(lm.lib.kl_trace_enable(lm.handle, 1))
+        step(args.warmup + args.steps)
+        torch.cuda.synchronize()
+        out = {}
+        for kind, name in ((0, "lstm_fwd_step_kernel"), (1, "lstm_bwd_step_kernel")):
+            n, ms = C.c_int(), C.c_float()
+            hipabi.check(lm.lib.kl_trace_read(lm.handle, kind, C.byref(n), C.byref(ms)))
+            out[name] = (n.value, ms.value)
+        hipabi.check(lm.lib.kl_trace_enable(lm.handle, 0))
+        name = max(out, key=lambda k: out[k][1] / max(out[k][0], 1))
+        n, ms = out[name]
+        n *= 8                                        # each event pair brackets 8 consecutive launches
+        per_launch_s = ms / max(n, 1) / 1e3
+        flops_launch = B * flops_cell_per_char()      # one launch = every layer's cell at one time step, B rows
+        achieved = flops_launch / per_launch_s / 1e12 if per_launch_s > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                    "launch_us": per_launch_s * 1e6, "launches_timed": n,
+                    "flops_per_launch": flops_launch,
+                    "whole_step_frac": value * 3 * flops_fwd_per_char() / world / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+
+    # ---- incremental rescoring (cfg3): 1024 hypotheses x 512 chars on this GPU
+    incremental = None
+    if rank == 0 and not args.no_incremental:
+        N, S = 1024, 512
+        lm.prepare(hipabi.KL_PREC_SPLIT)
+        lm.ensure_pool(2 * N)
+        r3 = np.random.default_rng(3)
+        ids = torch.from_numpy(r3.integers(1, VOC, size=(S, N)).astype(np.int32)).to(device)
+        cc = torch.from_numpy(r3.integers(0, 200, size=(N, 1)).astype(np.int32)).to(device)
+        a = torch.arange(N, dtype=torch.int32, device=device)
+        b = a + N
+        lm.pool.zero_()
+        warm = S // 5
+        for s in range(warm):
+            lm.step_slots(ids[s], cc, a, b)
+            a, b = b, a
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for s in range(warm, S):
+            lm.step_slots(ids[s], cc, a, b)
+            a, b = b, a
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        hv = N * (S - warm) / el
+        incremental = {"value": hv, "unit": "hypotheses*chars/s", "hypotheses": N, "chars": S, "precision": "split-bf16 (3 MFMA passes)",
+                       "us_per_step": el / (S - warm) * 1e6,
+                       "mfma_frac": hv * flops_fwd_per_char() / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        line = {
+            "metric": "chars/sec training (stacked-LSTM forward+backward+Adam)",
+            "value": value, "unit": "chars/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "cfg2: depth=2 width=512 length=256 V=256 1 context, stateful training, "
+                                   "%d streams/GPU, synthetic 10M-char corpus (SURVEY.md 8d)" % B,
+                       "streams_per_gpu": B, "global_batch": B * world, "seq_len": T,
+                       "parallelism": "dp%d" % world, "final_ce": ce / max(args.steps, 1)},
+            "roofline": roofline, "cpu_baseline": cpu, "incremental": incremental,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,6 +91,28 @@ struct kl_handle {
   };
   std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;
   bool graphs_enabled = true;
+  // optional per-launch timing of the cell-step kernels with HIP events (bench.py's
+  // roofline leg).  While tracing, windows run eagerly (events are not captured).
+  bool trace_on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev[2];   // [0] forward steps, [1] backward steps
+  size_t trace_used[2] = {0, 0};
+  bool trace_open[2] = {false, false};
+  void trace_begin(int kind, hipStream_t s) {
+    if (!trace_on) return;
+    if (trace_used[kind] == trace_ev[kind].size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { trace_on = false; return; }
+      trace_ev[kind].emplace_back(a, b);
+    }
+    (void)hipEventRecord(trace_ev[kind][trace_used[kind]].first, s);
+    trace_open[kind] = true;
+  }
+  void trace_end(int kind, hipStream_t s) {
+    if (!trace_on || !trace_open[kind]) return;
+    trace_open[kind] = false;
+    (void)hipEventRecord(trace_ev[kind][trace_used[kind]].second, s);
+    ++trace_used[kind];
+  }
   void drop_graphs() {
     for (auto& g : graphs) hipGraphExecDestroy(g.second);
     graphs.clear();
@@ -315,7 +337,13 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       }
     }
     // a launch packs at most 4 independent steps
-    for (int i = 0; i < ns; i += 4) KL_TRY(kl_launch_fwd_steps(steps + i, ns - i < 4 ? ns - i : 4, s));
+    for (int i = 0; i < ns; i += 4) {
+      // trace: one event pair brackets 8 consecutive steady-state launches (dgl = 8k .. 8k+7)
+      const bool steady = (ns == L) && dgl >= L && dgl + 8 < T;
+      if (steady && dgl % 8 == 0) h->trace_begin(0, s);
+      KL_TRY(kl_launch_fwd_steps(steps + i, ns - i < 4 ? ns - i : 4, s));
+      if (steady && dgl % 8 == 7) h->trace_end(0, s);
+    }
   }
   for (int l = 0; l < L; ++l)
     KL_TRY(kl_launch_rows_to_state(hrow(l, T), training ? 0 : 1, w.C[l] + (size_t)T * BW, B, W, L, l, states, s));
@@ -531,7 +559,12 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       S.dc_out = dc_wr; S.dc_out_ld = W;
       S.dz_out = w.dZ[l] + (size_t)t * B * 4 * W; S.dz_ld = 4 * W;
     }
-    for (int i = 0; i < ns; i += 4) KL_TRY(kl_launch_bwd_steps(steps + i, ns - i < 4 ? ns - i : 4, s));
+    for (int i = 0; i < ns; i += 4) {
+      const bool steady = (ns == L) && dgl >= L && dgl + 8 < T;
+      if (steady && dgl % 8 == 0) h->trace_begin(1, s);
+      KL_TRY(kl_launch_bwd_steps(steps + i, ns - i < 4 ? ns - i : 4, s));
+      if (steady && dgl % 8 == 7) h->trace_end(1, s);
+    }
   }
 
   // B4/B5: weight gradients, K = B*T contractions over transposed activations
@@ -719,7 +752,7 @@ extern "C" int kl_test_fwd_step(const uint16_t* A, long lda, const uint16_t* WT,
 namespace {
 
 int run_graphed(kl_handle* h, const kl_handle::GraphKey& key, hipStream_t s, const std::function<int()>& body) {
-  if (!h->graphs_enabled || s == nullptr) return body();   // the legacy default stream cannot be captured
+  if (!h->graphs_enabled || h->trace_on || s == nullptr) return body();   // (the legacy default stream cannot be captured)
   for (auto& g : h->graphs)
     if (g.first == key) return hip_ok(hipGraphLaunch(g.second, s));
   if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
@@ -797,4 +830,30 @@ extern "C" int kl_train_window(kl_handle* h, int B, int T, const int32_t* idx, c
     return train_window_body(h, B, T, w.s_idx, w.s_ctx, w.s_tgt, states, masks ? w.s_masks : nullptr, grads, loss_acc,
                              ws, ws_bytes, stream);
   });
+}
+
+
+// ---- per-launch timing of the step kernels (bench.py roofline leg) -----------------
+extern "C" int kl_trace_enable(kl_handle* h, int on) {
+  if (!h) return KL_ERR_ARG;
+  h->trace_on = on != 0;
+  h->trace_used[0] = h->trace_used[1] = 0;
+  return 0;
+}
+
+// kind 0 = forward cell-step launches, 1 = backward; call after synchronising the stream
+extern "C" int kl_trace_read(kl_handle* h, int kind, int* n_launches, float* total_ms) {
+  if (!h || kind < 0 || kind > 1 || !n_launches || !total_ms) return KL_ERR_ARG;
+  float total = 0.f;
+  int n = 0;
+  for (size_t i = 0; i < h->trace_used[kind]; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->trace_ev[kind][i].first, h->trace_ev[kind][i].second) == hipSuccess) {
+      total += ms;
+      ++n;
+    }
+  }
+  *n_launches = n;
+  *total_ms = total;
+  return 0;
 }
