@@ -59,6 +59,7 @@ struct WindowWs {
   float* rowstat;              // [BT][2] per-row (loss, hit)
   int *s_idx, *s_ctx, *s_tgt;  // staged inputs (fixed addresses for graph replay)
   float *s_masks, *s_probs;
+  unsigned *scan_cnt, *scan_status;   // persistent-scan hand-off counters [L][ceil(B/16)][T], status words [2]
   // training only
   std::vector<bf16_t*> G, dZ, Hd;
   bf16_t *dZT, *HT, *dlogits, *dlogitsT, *OHT, *dEKT_bf, *dEK_bf;
@@ -91,6 +92,7 @@ struct kl_handle {
   };
   std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;
   bool graphs_enabled = true;
+  bool scan_enabled = true;     // persistent scans (KL_SCAN=0 forces the launch-per-step path)
   // optional per-launch timing of the cell-step kernels with HIP events (bench.py's
   // roofline leg).  While tracing, windows run eagerly (events are not captured).
   bool trace_on = false;
@@ -205,6 +207,8 @@ size_t carve_window(const kl_handle* h, void* base, int B, int T, int training, 
   o.s_tgt = cv.take<int>(BT);
   o.s_masks = cv.take<float>(training ? L * (size_t)B * W : 1);
   o.s_probs = cv.take<float>(training ? 1 : BT * V);
+  o.scan_cnt = cv.take<unsigned>(L * ((size_t)(B + 15) / 16) * T);
+  o.scan_status = cv.take<unsigned>(4);
   if (training) {
     o.G.assign(L, nullptr); o.dZ.assign(L, nullptr); o.Hd.assign(L, nullptr);
     o.dc0.assign(L, nullptr); o.dc1.assign(L, nullptr);
@@ -294,7 +298,31 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
   auto hrow = [&](int l, int block) -> const void* {
     return training ? (const void*)((bf16_t*)w.H[l] + (size_t)block * BW) : (const void*)((float*)w.H[l] + (size_t)block * BW);
   };
-  for (int dgl = 0; dgl < T + L - 1; ++dgl) {
+  // persistent scan (one launch for all layers and steps) where the shape allows it
+  bool scanned = false;
+  if (training && h->scan_enabled && !h->trace_on && L <= KL_SCAN_MAXL) {
+    KlScanFwd a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.T = T; a.W = W; a.L = L;
+    for (int l = 0; l < L; ++l) {
+      a.UT[l] = d.UT_hi[l];
+      a.KT[l] = l > 0 ? d.KT_hi[l] : nullptr;
+      a.bias[l] = l > 0 ? P + h->off_b[l] : nullptr;
+      a.H[l] = (bf16_t*)w.H[l];
+      a.C[l] = w.C[l];
+      a.G[l] = w.G[l];
+      const bool masked = masks != nullptr && l > 0;
+      a.Hd[l] = masked ? w.Hd[l] : nullptr;
+      a.mask[l] = masked ? masks + (size_t)l * BW : nullptr;
+    }
+    a.P1 = w.P1;
+    a.counters = w.scan_cnt;
+    a.status = w.scan_status;
+    const int e = kl_launch_scan_fwd(a, s);
+    if (e == 0) scanned = true;
+    else if (e != KL_ERR_SHAPE) return e;
+  }
+  for (int dgl = 0; !scanned && dgl < T + L - 1; ++dgl) {
     KlFwdStep steps[4];
     int ns = 0;
     for (int l = 0; l < L; ++l) {
@@ -348,6 +376,10 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
   for (int l = 0; l < L; ++l)
     KL_TRY(kl_launch_rows_to_state(hrow(l, T), training ? 0 : 1, w.C[l] + (size_t)T * BW, B, W, L, l, states, s));
   return 0;
+}
+
+__global__ void scan_status_kernel(const unsigned* status, float* loss_acc) {
+  if (threadIdx.x == 0 && (status[0] | status[1]) != 0) loss_acc[3] += 1.f;
 }
 
 __global__ void state_dist2_kernel(const float* __restrict__ pool, long slot_stride, int W, int k,
@@ -446,6 +478,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->drop_graphs();
   const char* env = getenv("KL_GRAPH");
   h->graphs_enabled = !(env && env[0] == '0');
+  const char* env2 = getenv("KL_SCAN");
+  h->scan_enabled = !(env2 && env2[0] == '0');
   return kl_zero_page_ready();
 }
 
@@ -503,6 +537,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   const int ksplit = BT >= 4096 ? 8 : (BT >= 1024 ? 4 : 1);
 
   KL_TRY(hip_ok(hipMemsetAsync(grads, 0, h->n_params * sizeof(float), s)));
+  KL_TRY(hip_ok(hipMemsetAsync(w.scan_status, 0, 4 * sizeof(unsigned), s)));
   KL_TRY(forward_impl(h, B, T, idx, ctx, states, masks, 1, w, s));
 
   // F5/F6: logits over the (masked) top-layer outputs, softmax, CE, dlogits
@@ -521,8 +556,29 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   KL_TRY(kl_launch_transpose_bf16(Htop, W, w.HT, BTp, BT, W, s));
   KL_TRY(kl_launch_gemm_tn(w.dlogitsT, w.HT, grads + h->off_E, nullptr, V, W, BTp, BTp, BTp, W, 2, ksplit, 1.f, s));
 
-  // B3: reverse layer wavefront
-  for (int dgl = 0; dgl < T + L - 1; ++dgl) {
+  // B3: reverse recurrence -- persistent scan where the shape allows it, else the
+  // launch-per-step layer wavefront
+  bool bscanned = false;
+  if (h->scan_enabled && !h->trace_on && L <= KL_SCAN_MAXL) {
+    KlScanBwd a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.T = T; a.W = W; a.L = L;
+    for (int l = 0; l < L; ++l) {
+      a.Un[l] = d.Un[l];
+      a.Kn[l] = d.Kn[l];
+      a.G[l] = w.G[l];
+      a.C[l] = w.C[l];
+      a.dZ[l] = w.dZ[l];
+      a.mask[l] = (masks != nullptr && l > 0) ? masks + (size_t)l * BW : nullptr;
+    }
+    a.dH = w.dH;
+    a.counters = w.scan_cnt;
+    a.status = w.scan_status + 1;
+    const int e = kl_launch_scan_bwd(a, s);
+    if (e == 0) bscanned = true;
+    else if (e != KL_ERR_SHAPE) return e;
+  }
+  for (int dgl = 0; !bscanned && dgl < T + L - 1; ++dgl) {
     KlBwdStep steps[4];
     int ns = 0;
     for (int j = 0; j < L; ++j) {
@@ -611,7 +667,9 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   for (int n = 0; n < c.n_ctx; ++n) { ctabs[n] = P + h->off_Ctx[n]; gctabs[n] = grads + h->off_Ctx[n]; }
   KL_TRY(kl_launch_regulariser_grads(P + h->off_E, V, W, ctabs.data(), c.n_ctx, c.ctx_vocab, c.ctx_dim,
                                      grads + h->off_E, gctabs.data(), loss_acc, s));
-  return 0;
+  // a timed-out hand-off in a persistent scan surfaces as loss_acc[3] != 0
+  hipLaunchKernelGGL(scan_status_kernel, dim3(1), dim3(64), 0, s, w.scan_status, loss_acc);
+  return hip_ok(hipGetLastError());
 }
 
 int kl_adam_step(kl_handle* h, const float* grads, float* m, float* v, int t, float lr, float b1, float b2,

@@ -202,13 +202,19 @@ __global__ void reg_table_kernel(const float* __restrict__ X, int R, int D, floa
   float* red = nr + R;         // [blockDim] scratch
   const int tid = threadIdx.x, nt = blockDim.x;
   if (R < 2) return;
+  // column sums over rows 1..R-1: independent strided loads + LDS atomics (a per-column
+  // serial loop here was a chain of R dependent L2 round trips: ~90 us for E)
+  for (int d = tid; d < D; d += nt) mean[d] = 0.f;
+  __syncthreads();
+  for (long e = (long)D + tid; e < (long)R * D; e += nt) atomicAdd(&mean[e % D], X[e]);
+  __syncthreads();
   for (int d = tid; d < D; d += nt) {
-    float a = 0.f;
-    for (int r = 1; r < R; ++r) a += X[(long)r * D + d];
-    mean[d] = a / (float)(R - 1);
+    const float a = mean[d];
     s1[d] = a - X[(long)(R - 1) * D + d];
     s2[d] = a - X[(long)1 * D + d];
   }
+  __syncthreads();
+  for (int d = tid; d < D; d += nt) mean[d] = mean[d] / (float)(R - 1);
   for (int r = tid >> 6; r < R; r += nt >> 6) {
     float a = 0.f;
     for (int d = tid & 63; d < D; d += 64) { const float x = X[(long)r * D + d]; a += x * x; }

@@ -63,6 +63,41 @@ struct KlBwdStep {
 int kl_launch_bwd_steps(const KlBwdStep* steps, int n_steps, hipStream_t stream);
 int kl_zero_page_ready();   // resolves the zero page's device address (call outside stream capture)
 
+// ---- lstm_scan.hip ------------------------------------------------------
+// persistent scans (whole window, all layers, one launch; weights in registers)
+#define KL_SCAN_MAXL 4
+struct KlScanFwd {
+  int B, T, W, L;
+  int n_rb, n_rg;                      // filled by the launcher: row blocks of 16, row groups
+  const bf16_t* UT[KL_SCAN_MAXL];      // [4W][W] recurrent kernels, transposed
+  const bf16_t* KT[KL_SCAN_MAXL];      // [4W][W] input kernels, transposed (l >= 1)
+  const float* bias[KL_SCAN_MAXL];     // [4W] (l >= 1; layer 0's bias is folded into P1)
+  const float* P1;                     // [T*B][4W] layer-0 input contraction + bias
+  bf16_t* H[KL_SCAN_MAXL];             // [(T+1)B][W], block 0 = carried-in state
+  float* C[KL_SCAN_MAXL];              // [(T+1)B][W], block 0 = carried-in state
+  bf16_t* G[KL_SCAN_MAXL];             // [T*B][4W] gate activations (null: not kept)
+  bf16_t* Hd[KL_SCAN_MAXL];            // [T*B][W] dropout-masked outputs (null: none)
+  const float* mask[KL_SCAN_MAXL];     // [B][W] keep-masks (null: none)
+  unsigned* counters;                  // [L][n_rb][T], zeroed by the launcher
+  unsigned* status;                    // 0 = ok, 1 = a bounded spin timed out
+};
+int kl_launch_scan_fwd(KlScanFwd args, hipStream_t stream);
+
+struct KlScanBwd {
+  int B, T, W, L;
+  int n_rb, n_rg;
+  const bf16_t* Un[KL_SCAN_MAXL];      // [W][4W] recurrent kernels, natural layout
+  const bf16_t* Kn[KL_SCAN_MAXL];      // [W][4W] input kernels (rows of layer l's K; used by layer l-1)
+  const bf16_t* G[KL_SCAN_MAXL];       // [T*B][4W]
+  const float* C[KL_SCAN_MAXL];        // [(T+1)B][W]
+  bf16_t* dZ[KL_SCAN_MAXL];            // [T*B][4W]
+  const float* dH;                     // [T*B][W] gradient from the softmax (top layer)
+  const float* mask[KL_SCAN_MAXL];     // dropout mask on the OUTPUT of layer l (null: none)
+  unsigned* counters;                  // [L][n_rb][T]
+  unsigned* status;
+};
+int kl_launch_scan_bwd(KlScanBwd args, hipStream_t stream);
+
 // thin split-precision contraction C[M,N] = A[M,K] . WT[N,K]^T (+bias) for
 // small M (tables, inference logits)
 int kl_launch_thin_gemm(const KlOperand* op, int M, int N, float* C, long ldc, const float* bias, int split,

@@ -1,0 +1,495 @@
+// Persistent LSTM scans for gfx950: the whole T-step recurrence of every layer in
+// ONE launch, weights resident in registers.
+//
+// Why: a launch per time step re-streams the layer's 4W x W weight slice from
+// beyond L2 on every step and pays launch ramp + kernarg fetch each time (measured
+// 10-12 us per step at W=512).  Here every workgroup keeps its slice of the
+// recurrent (and, above layer 0, input) kernel in VGPRs for all T steps and the
+// only per-step traffic is the 16 x K state tile it contracts with.
+//
+// Decomposition: workgroup (layer l, unit group ug of 16 hidden units, row group
+// rg); rows (independent stateful streams) come in blocks of 16 = one MFMA row
+// tile.  Inside a workgroup the contraction dimension K is split over the four
+// waves (forward: each wave holds all four gate tiles for its K quarter; backward:
+// the K quarter IS one gate's column range), every wave loads exactly the fragment
+// bytes it multiplies -- straight into registers, nothing staged -- and the four
+// partial tiles meet in LDS where the gate math runs.
+//
+// Streams never interact, so synchronisation is per (layer, row block, step): the
+// W/16 workgroups that produce h_l[t] for a row block each add 1 to a counter once
+// their slice is published; consumers (same layer at t+1, layer l+1 at t) poll it.
+// There is no grid-wide barrier anywhere.
+//
+// Hand-off protocol (MI355X_MICROARCH.md, valid form "ONE lane of each storing
+// workgroup ... agent-scope atomic add"): payload stores are write-through (sc1),
+// every storing wave drains vmcnt(0), workgroup barrier, one lane adds to the
+// counter; the consumer's lane 0 polls the counter with sc1 loads, workgroup
+// barrier, then EVERY load of handed-off bytes is an sc1 buffer load.  Counters are
+// zeroed by a memset node before each launch.  All spins are bounded: on timeout
+// (or if another workgroup has raised the abort word) the kernel drains and the
+// host sees a non-zero status word instead of a hang.
+// Residency: at most 512 workgroups of 256 threads (<= 256 VGPRs, 18 KiB LDS), i.e.
+// two per CU on a full chip; a grid that oversubscribes the chip (tried: 1024)
+// times out cleanly through the bounded spins.
+#include <stdlib.h>
+#include <string.h>
+
+#include "kl_common.h"
+#include "kl_kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+// diagnostic build only (-DKL_STAMP): cycle shares of the forward scan's step phases
+#ifdef KL_STAMP
+__device__ unsigned long long kl_scan_stamps[16];
+#define SSTAMP(i)                                                                     \
+  do {                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    if (blockIdx.x == STAMP_WG && threadIdx.x == 0) {                                 \
+      const unsigned long long now_ = clock64();                                      \
+      kl_scan_stamps[i] += now_ - last_;                                              \
+      last_ = now_;                                                                   \
+    }                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+  } while (0)
+#else
+#define SSTAMP(i)
+#endif
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
+}
+__device__ __forceinline__ uint4 load16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16);
+  return uint4{v.x, v.y, v.z, v.w};
+}
+
+// v_exp_f32 / v_rcp_f32 forms (1 ulp each): the scans are latency chains, and the
+// training path computes in bf16 anyway
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.f;
+}
+
+// one lane polls; true = reached.  Raises/observes the abort word.
+__device__ __forceinline__ bool poll_counter(const unsigned* cnt, unsigned target, unsigned* status) {
+  for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
+    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+    if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return false;
+}
+
+// ---------------------------------------------------------------- forward scan
+// block = 256 threads; wave w contracts over K quarter w (KQ = W/128 k-steps of 32
+// per operand) for all 4 gates x 16 units.  MAXRB = row blocks served per step.
+template <int KSTEPS, int MAXRB>
+__global__ __launch_bounds__(256, 2) void lstm_scan_fwd_kernel(const KlScanFwd a) {
+  constexpr int KQ = KSTEPS / 4;
+  constexpr int W = KSTEPS * 32;
+  constexpr int NUG = W / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int id = blockIdx.x;
+  const int n_rg = a.n_rg, n_rb = a.n_rb, B = a.B, T = a.T;
+  const int l = id / (NUG * n_rg);
+  id -= l * NUG * n_rg;
+  const int ug = id / n_rg, rg = id % n_rg;
+  const int u0 = ug * 16;
+  const bool has_in = l > 0;
+
+  __shared__ float zt[4][4][16][17];   // [wave][gate][row][unit] partial tiles
+  __shared__ int ok_flag;
+
+  // ---- resident weights as B fragments: gate g, this wave's K quarter
+  const int kq = (lane >> 4) * 8;
+  uint4 bu[4][KQ], bk[4][KQ];
+  {
+    const bf16_t* UT = a.UT[l];
+    const bf16_t* KT = a.KT[l];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const long wrow = ((long)g * W + u0 + (lane & 15)) * W + (wave * KQ) * 32 + kq;
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) {
+        bu[g][j] = *reinterpret_cast<const uint4*>(UT + wrow + j * 32);
+        bk[g][j] = has_in ? *reinterpret_cast<const uint4*>(KT + wrow + j * 32) : uint4{0, 0, 0, 0};
+      }
+    }
+  }
+  // epilogue thread = (row er, unit eu)
+  const int er = tid >> 4, eu = tid & 15;
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (has_in) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = a.bias[l][(long)g * W + u0 + eu];
+  }
+  float* Cl = a.C[l];
+  bf16_t* Hl = a.H[l];
+  bf16_t* Gl = a.G[l];
+  bf16_t* Hdl = a.Hd[l];
+  const float* maskl = a.mask[l];
+  const float* P1 = a.P1;
+  unsigned* status = a.status;
+  float c_reg[MAXRB];
+#pragma unroll
+  for (int i = 0; i < MAXRB; ++i) {
+    const int rb = rg + i * n_rg;
+    const int row = min(rb * 16 + er, B - 1);
+    c_reg[i] = (rb < n_rb) ? Cl[(long)row * W + u0 + eu] : 0.f;
+  }
+  const long BW = (long)B * W;
+  const bf16_t* Hin = has_in ? (a.Hd[l - 1] ? a.Hd[l - 1] : a.H[l - 1] + BW) : Hl;   // input rows of step t at block t
+  const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(Hl, (long)(T + 1) * BW * 2);
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(Hin, (long)T * BW * 2);
+  unsigned* cnt_own = a.counters + (long)l * n_rb * T;
+  unsigned* cnt_in = a.counters + (long)(has_in ? l - 1 : 0) * n_rb * T;
+  bool alive = true;
+#ifdef KL_STAMP
+  const int STAMP_WG = gridDim.x - 1;     // a top-layer workgroup
+  unsigned long long last_ = clock64();
+#endif
+
+  for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int i = 0; i < MAXRB; ++i) {
+      const int rb = rg + i * n_rg;
+      if (rb >= n_rb) continue;
+      const int r0 = rb * 16;
+      const int erow = min(r0 + er, B - 1);
+      SSTAMP(0);
+      // gate inputs that do not depend on the hand-off: issue first
+      float zin[4];
+      if (!has_in) {
+        const float* p = P1 + ((long)t * B + erow) * 4 * W + u0 + eu;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) zin[g] = p[(long)g * W];
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) zin[g] = bias4[g];
+      }
+      float mk = 1.f;
+      if (maskl) mk = maskl[(long)erow * W + u0 + eu];
+      // ---- wait for h_{l-1}[t] and h_l[t-1] of this row block
+      if (tid == 0) {
+        bool ok = alive;
+        if (ok && has_in) ok = poll_counter(cnt_in + (long)rb * T + t, NUG, status);
+        if (ok && t > 0) ok = poll_counter(cnt_own + (long)rb * T + (t - 1), NUG, status);
+        ok_flag = ok ? 1 : 0;
+      }
+      SSTAMP(1);
+      __syncthreads();
+      SSTAMP(2);
+      alive = ok_flag != 0;
+      // ---- this wave's fragments of the 16 x K state tile, write-through reads
+      const int arow = min(r0 + (lane & 15), B - 1);
+      const unsigned abase = (unsigned)((((long)t * B + arow) * W + (wave * KQ) * 32 + kq) * 2);
+      uint4 ah[KQ], ax[KQ];
+      if (alive) {
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+          ax[j] = has_in ? load16_sc1(rs_in, abase + j * 64) : uint4{0, 0, 0, 0};
+          ah[j] = load16_sc1(rs_h, abase + j * 64);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) { ax[j] = uint4{0, 0, 0, 0}; ah[j] = uint4{0, 0, 0, 0}; }
+      }
+      SSTAMP(3);
+      f32x4 acc[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (has_in) {
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+          frag16 fa;
+          fa.u = ax[j];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            frag16 fb;
+            fb.u = bk[g][j];
+            acc[g] = mfma16(fa.v, fb.v, acc[g]);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) {
+        frag16 fa;
+        fa.u = ah[j];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          frag16 fb;
+          fb.u = bu[g][j];
+          acc[g] = mfma16(fa.v, fb.v, acc[g]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zt[wave][g][(lane >> 4) * 4 + r][lane & 15] = acc[g][r];
+      SSTAMP(5);
+      __syncthreads();
+      SSTAMP(6);
+      // ---- gates for (row er, unit eu)
+      float z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) z[g] = zin[g] + zt[0][g][er][eu] + zt[1][g][er][eu] + zt[2][g][er][eu] + zt[3][g][er][eu];
+      const float gi = fast_sigmoid(z[0]), gf = fast_sigmoid(z[1]), gg = fast_tanh(z[2]), go = fast_sigmoid(z[3]);
+      const float c = gf * c_reg[i] + gi * gg;
+      c_reg[i] = c;
+      const float h = go * fast_tanh(c);
+      const bool row_ok = (r0 + er) < B;
+      SSTAMP(7);
+      // publish h (and its masked copy) write-through, two units per 4-byte store
+      const unsigned hb = f2bf(h), hdb = f2bf(h * mk);
+      const unsigned hb_n = __shfl_xor(hb, 1), hdb_n = __shfl_xor(hdb, 1);
+      const long orow = (long)t * B + r0 + er;
+      if (row_ok && alive && (eu & 1) == 0) {
+        __hip_atomic_store(reinterpret_cast<unsigned*>(Hl + (orow + B) * W + u0 + eu), hb | (hb_n << 16), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        if (Hdl)
+          __hip_atomic_store(reinterpret_cast<unsigned*>(Hdl + orow * W + u0 + eu), hdb | (hdb_n << 16), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      }
+      SSTAMP(8);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      SSTAMP(9);
+      __syncthreads();   // also orders the zt reads above before the next iteration's writes
+      if (tid == 0) __hip_atomic_fetch_add(cnt_own + (long)rb * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // what only later launches read (cell state, gate activations) is stored after the
+      // publish: plain stores, off the hand-off chain
+      if (row_ok && alive) {
+        Cl[(orow + B) * W + u0 + eu] = c;
+        if (Gl) {
+          bf16_t* gp = Gl + orow * 4 * W + u0 + eu;
+          gp[0] = f2bf(gi);
+          gp[W] = f2bf(gf);
+          gp[2 * W] = f2bf(gg);
+          gp[3 * W] = f2bf(go);
+        }
+      }
+      SSTAMP(10);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward scan
+// block = 256 threads; output tile = dh of 16 rows x 16 units; wave w contracts
+// over gate w's K range (W of the 4W columns) of dZ_l[t+1] . U_l^T and, below the
+// top layer, dZ_{l+1}[t] . K_{l+1}^T; the four partial tiles meet in LDS and the
+// gate derivatives run on the reduced tile.  dc lives in registers for all T steps.
+template <int KSTEPS, int MAXRB>
+__global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a) {
+  constexpr int W = KSTEPS * 32;
+  constexpr int NUG = W / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int id = blockIdx.x;
+  const int n_rg = a.n_rg, n_rb = a.n_rb, B = a.B, T = a.T;
+  const int l = id / (NUG * n_rg);
+  id -= l * NUG * n_rg;
+  const int ug = id / n_rg, rg = id % n_rg;
+  const int u0 = ug * 16;
+  const bool has_up = l < a.L - 1;
+
+  __shared__ float zt[4][16][17];
+  __shared__ int ok_flag;
+
+  const long wrow = (long)(u0 + (lane & 15)) * 4 * W + (long)wave * W;
+  const int kq = (lane >> 4) * 8;
+  uint4 bu[KSTEPS], bk[KSTEPS];
+#pragma unroll
+  for (int j = 0; j < KSTEPS; ++j) {
+    bu[j] = *reinterpret_cast<const uint4*>(a.Un[l] + wrow + j * 32 + kq);
+    bk[j] = has_up ? *reinterpret_cast<const uint4*>(a.Kn[l + 1] + wrow + j * 32 + kq) : uint4{0, 0, 0, 0};
+  }
+  const int er = tid >> 4, eu = tid & 15;
+  float dc_reg[MAXRB];
+#pragma unroll
+  for (int i = 0; i < MAXRB; ++i) dc_reg[i] = 0.f;
+  const long BW = (long)B * W;
+  const bf16_t* Gl = a.G[l];
+  const float* Cl = a.C[l];
+  bf16_t* dZl = a.dZ[l];
+  const float* dH = a.dH;
+  const float* maskl = a.mask[l];
+  unsigned* status = a.status;
+  const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(dZl, (long)T * BW * 4 * 2);
+  const __amdgpu_buffer_rsrc_t rs_up = make_rsrc(has_up ? a.dZ[l + 1] : dZl, (long)T * BW * 4 * 2);
+  unsigned* cnt_own = a.counters + (long)l * n_rb * T;
+  unsigned* cnt_up = a.counters + (long)(has_up ? l + 1 : l) * n_rb * T;
+  bool alive = true;
+
+  for (int t = T - 1; t >= 0; --t) {
+#pragma unroll
+    for (int i = 0; i < MAXRB; ++i) {
+      const int rb = rg + i * n_rg;
+      if (rb >= n_rb) continue;
+      const int r0 = rb * 16;
+      const int erow = min(r0 + er, B - 1);
+      // epilogue operands (written by earlier launches: plain loads), issued before the wait
+      const bf16_t* gp = Gl + ((long)t * B + erow) * 4 * W + u0 + eu;
+      const bf16_t g0 = gp[0], g1 = gp[W], g2 = gp[2 * W], g3 = gp[3 * W];
+      const float c = Cl[((long)(t + 1) * B + erow) * W + u0 + eu];
+      const float cp = Cl[((long)t * B + erow) * W + u0 + eu];
+      float dh = 0.f;
+      if (!has_up) dh = dH[((long)t * B + erow) * W + u0 + eu];
+      float mk = 1.f;
+      if (maskl) mk = maskl[(long)erow * W + u0 + eu];
+      if (!has_up) dh *= mk;
+      float omask[4] = {1.f, 1.f, 1.f, 1.f};
+      if (has_up && maskl) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mr = min(r0 + (lane >> 4) * 4 + r, B - 1);
+          omask[r] = maskl[(long)mr * W + u0 + (lane & 15)];
+        }
+      }
+      if (tid == 0) {
+        bool ok = alive;
+        if (ok && has_up) ok = poll_counter(cnt_up + (long)rb * T + t, NUG, status);
+        if (ok && t < T - 1) ok = poll_counter(cnt_own + (long)rb * T + (t + 1), NUG, status);
+        ok_flag = ok ? 1 : 0;
+      }
+      __syncthreads();
+      alive = ok_flag != 0;
+      const int arow = min(r0 + (lane & 15), B - 1);
+      f32x4 acc_up = f32x4{0.f, 0.f, 0.f, 0.f}, acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (alive && has_up) {
+        uint4 av[KSTEPS];
+        const unsigned base = (unsigned)((((long)t * B + arow) * 4 * W + (long)wave * W + kq) * 2);
+#pragma unroll
+        for (int j = 0; j < KSTEPS; ++j) av[j] = load16_sc1(rs_up, base + j * 64);
+#pragma unroll
+        for (int j = 0; j < KSTEPS; ++j) {
+          frag16 fa, fb;
+          fa.u = av[j];
+          fb.u = bk[j];
+          acc_up = mfma16(fa.v, fb.v, acc_up);
+        }
+      }
+      if (alive && t < T - 1) {
+        uint4 av[KSTEPS];
+        const unsigned base = (unsigned)((((long)(t + 1) * B + arow) * 4 * W + (long)wave * W + kq) * 2);
+#pragma unroll
+        for (int j = 0; j < KSTEPS; ++j) av[j] = load16_sc1(rs_own, base + j * 64);
+#pragma unroll
+        for (int j = 0; j < KSTEPS; ++j) {
+          frag16 fa, fb;
+          fa.u = av[j];
+          fb.u = bu[j];
+          acc = mfma16(fa.v, fb.v, acc);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zt[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r] + acc_up[r] * omask[r];
+      __syncthreads();
+      dh += zt[0][er][eu] + zt[1][er][eu] + zt[2][er][eu] + zt[3][er][eu];
+      const float gi = bf2f(g0), gf = bf2f(g1), gg = bf2f(g2), go = bf2f(g3);
+      const float tc = fast_tanh(c);
+      const float dc = dh * go * (1.f - tc * tc) + dc_reg[i];
+      dc_reg[i] = dc * gf;
+      const float d_o = dh * tc, d_i = dc * gg, d_g = dc * gi, d_f = dc * cp;
+      const unsigned z0 = f2bf(d_i * gi * (1.f - gi)), z1 = f2bf(d_f * gf * (1.f - gf));
+      const unsigned z2 = f2bf(d_g * (1.f - gg * gg)), z3 = f2bf(d_o * go * (1.f - go));
+      const unsigned n0 = __shfl_xor(z0, 1), n1 = __shfl_xor(z1, 1), n2 = __shfl_xor(z2, 1), n3 = __shfl_xor(z3, 1);
+      if ((r0 + er) < B && alive && (eu & 1) == 0) {
+        unsigned* zp = reinterpret_cast<unsigned*>(dZl + ((long)t * B + r0 + er) * 4 * W + u0 + eu);
+        __hip_atomic_store(zp, z0 | (n0 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(zp + W / 2, z1 | (n1 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(zp + W, z2 | (n2 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(zp + 3 * W / 2, z3 | (n3 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(cnt_own + (long)rb * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// Upper bound of co-resident scan workgroups (KL_SCAN_WGS overrides; default 512 =
+// two per CU).
+int scan_max_wgs() {
+  static int v = 0;
+  if (!v) {
+    const char* e = getenv("KL_SCAN_WGS");
+    v = e ? atoi(e) : 512;
+    if (v < 64) v = 64;
+    if (v > 512) v = 512;
+  }
+  return v;
+}
+
+// grid plan shared by both scans; false = this shape must use the launch-per-step path
+bool plan_scan(int W, int L, int B, int T, int* n_rb, int* n_rg, int* per_wg) {
+  if (W != 512 && W != 256 && W != 128) return false;
+  if (L < 1 || L > KL_SCAN_MAXL || B < 1 || T < 1) return false;
+  const int col_tasks = L * (W / 16);
+  if (col_tasks > 256) return false;
+  *n_rb = (B + 15) / 16;
+  int g = scan_max_wgs() / col_tasks;
+  if (g > *n_rb) g = *n_rb;
+  if (g < 1) return false;
+  *n_rg = g;
+  *per_wg = (*n_rb + g - 1) / g;
+  return *per_wg <= 4;
+}
+
+}  // namespace
+
+#define KL_SCAN_CASE(KERNEL, KS, RB) hipLaunchKernelGGL((KERNEL<KS, RB>), grid, block, 0, stream, a)
+#define KL_SCAN_DISPATCH(KERNEL)                                                                      \
+  do {                                                                                                \
+    if (W == 512) {                                                                                   \
+      if (per_wg == 1) KL_SCAN_CASE(KERNEL, 16, 1);                                                   \
+      else if (per_wg == 2) KL_SCAN_CASE(KERNEL, 16, 2);                                              \
+      else KL_SCAN_CASE(KERNEL, 16, 4);                                                               \
+    } else if (W == 256) {                                                                            \
+      if (per_wg == 1) KL_SCAN_CASE(KERNEL, 8, 1);                                                    \
+      else if (per_wg == 2) KL_SCAN_CASE(KERNEL, 8, 2);                                               \
+      else KL_SCAN_CASE(KERNEL, 8, 4);                                                                \
+    } else {                                                                                          \
+      if (per_wg == 1) KL_SCAN_CASE(KERNEL, 4, 1);                                                    \
+      else if (per_wg == 2) KL_SCAN_CASE(KERNEL, 4, 2);                                               \
+      else KL_SCAN_CASE(KERNEL, 4, 4);                                                                \
+    }                                                                                                 \
+  } while (0)
+
+// Persistent forward scan; KL_ERR_SHAPE = use the launch-per-step path instead.
+int kl_launch_scan_fwd(KlScanFwd a, hipStream_t stream) {
+  const int W = a.W;
+  int per_wg = 0;
+  if (!plan_scan(W, a.L, a.B, a.T, &a.n_rb, &a.n_rg, &per_wg)) return KL_ERR_SHAPE;
+  if (hipMemsetAsync(a.counters, 0, (size_t)a.L * a.n_rb * a.T * sizeof(unsigned), stream) != hipSuccess) return KL_ERR_LAUNCH;
+  if (hipMemsetAsync(a.status, 0, sizeof(unsigned), stream) != hipSuccess) return KL_ERR_LAUNCH;
+  dim3 grid(a.L * (W / 16) * a.n_rg), block(256);
+  KL_SCAN_DISPATCH(lstm_scan_fwd_kernel);
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+int kl_launch_scan_bwd(KlScanBwd a, hipStream_t stream) {
+  const int W = a.W;
+  int per_wg = 0;
+  if (!plan_scan(W, a.L, a.B, a.T, &a.n_rb, &a.n_rg, &per_wg)) return KL_ERR_SHAPE;
+  if (hipMemsetAsync(a.counters, 0, (size_t)a.L * a.n_rb * a.T * sizeof(unsigned), stream) != hipSuccess) return KL_ERR_LAUNCH;
+  if (hipMemsetAsync(a.status, 0, sizeof(unsigned), stream) != hipSuccess) return KL_ERR_LAUNCH;
+  dim3 grid(a.L * (W / 16) * a.n_rg), block(256);
+  KL_SCAN_DISPATCH(lstm_scan_bwd_kernel);
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+#ifdef KL_STAMP
+extern "C" int kl_test_scan_stamps(unsigned long long* out, int reset) {
+  if (reset) {
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(kl_scan_stamps), z, sizeof(z)) == hipSuccess ? 0 : KL_ERR_LAUNCH;
+  }
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(kl_scan_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+#endif

@@ -242,6 +242,8 @@ class HipLM:
         v = self.loss_acc.detach().cpu().numpy().copy()
         if reset:
             self.loss_acc.zero_()
+        if v[3] != 0:
+            raise hipabi.KlError("a persistent-scan hand-off timed out on the GPU (results of this window are invalid)")
         return float(v[0]), float(v[1]), float(v[2])
 
     # ------------------------------------------------------------------ incremental

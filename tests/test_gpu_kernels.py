@@ -182,7 +182,11 @@ def test_forward_window_parity(depth, width, voc, B, T, n_ctx):
 
 @pytest.mark.parametrize("depth,width,voc,B,T,n_ctx,use_masks", [(1, 64, 40, 2, 8, 1, False), (2, 64, 50, 4, 16, 1, True),
                                                                  (2, 128, 70, 8, 32, 1, True), (3, 64, 30, 3, 8, 2, True),
-                                                                 (2, 64, 50, 1, 5, 1, False)])
+                                                                 (2, 64, 50, 1, 5, 1, False),
+                                                                 # shapes served by the persistent scans (W in 128/256/512)
+                                                                 (2, 128, 70, 40, 12, 1, True), (3, 128, 30, 20, 6, 2, True),
+                                                                 (1, 256, 40, 5, 9, 1, False), (2, 512, 64, 100, 6, 1, True),
+                                                                 (2, 512, 256, 64, 16, 1, True)])
 def test_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks):
     """B1-B7 + F7: gradients of mean CE + regularisers vs the f64 oracle.  The HIP
     path computes in bf16 with f32 accumulation: relative error of each gradient
@@ -243,3 +247,42 @@ def test_adam_step_matches_oracle():
     got = lm.get_weights()
     for k in wo:
         assert np.abs(got[k] - wo[k]).max() < 1e-6, k
+
+
+@pytest.mark.parametrize("depth,width,voc,B,T", [(2, 128, 50, 20, 12), (2, 512, 64, 40, 8)])
+def test_train_consecutive_windows_reuse_buffers(depth, width, voc, B, T):
+    """The persistent scans hand data between workgroups through buffers that are
+    re-used by every window: three consecutive windows (carried state, fresh inputs)
+    must each match the oracle -- a stale cached line from the previous window would
+    show up as a wrong loss / state / gradient here."""
+    import torch
+    from ocrd_keraslm_amd.lib import hipabi
+    cfg, w, lm = make_model(depth, width, voc, 1, emb_std=0.3)
+    lm.set_weights(w, hipabi.KL_PREC_BF16)
+    lm.reset_states(B)
+    rng = np.random.default_rng(33)
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    st = O.zero_states(cfg, B, np.float64)
+    for win in range(3):
+        idx = rng.integers(0, voc, (B, T))
+        ctx = rng.integers(0, 200, (B, 1, 1)).repeat(T, axis=1)
+        tgt = rng.integers(0, voc, (B, T))
+        masks = lm.draw_dropout_masks(B)
+        om = [None] + [masks[l].astype(np.float64) for l in range(1, depth)]
+        ref_p, st, cache = O.forward_window(cfg, w64, idx, ctx, st, om, keep_cache=True)
+        ce, _, _ = O.crossentropy(ref_p, tgt)
+        g_ref = O.backward_window(cfg, w64, idx, ctx, tgt, ref_p, cache, om)
+        lm.loss_acc.zero_()
+        lm.train_window(idx, ctx, tgt, masks)
+        l, _, _ = lm.read_loss()
+        assert abs(l - ce) < 2e-2 * max(1.0, ce), (win, l, ce)
+        got_st = lm.states.cpu().numpy()
+        for k in range(2 * depth):
+            assert np.abs(got_st[:, k] - st[k]).max() < 3e-2, (win, k)
+        flat = lm.grads.cpu().numpy()
+        for name, off, rows, cols in lm.layout:
+            got = flat[off:off + rows * cols].reshape(g_ref[name].shape)
+            scale = np.abs(g_ref[name]).max() + 1e-12
+            assert np.abs(got - g_ref[name]).max() / scale < 4e-2, (win, name)
+        # keep the oracle's carried state identical to the engine's bf16-rounded one
+        st = [got_st[:, k].astype(np.float64) for k in range(2 * depth)]

@@ -1,0 +1,86 @@
+"""BASELINE.json config 0 ("plumbing"): depth=1 width=128 length=64 stateful LSTM,
+train 1 epoch on synthetic text, save, reload, then rate_once / rate -- through
+the public Rater API only (the reference's CLI does exactly this sequence:
+scripts/run.py:48-85 train+save, :98-110 load_config/configure/load_weights/rate2).
+No bundled text exists in the reference: the text is a seeded
+order-1 Markov chain over ~40 printable characters in `author_title_year.txt` files."""
+import os
+import random
+import tempfile
+
+import numpy as np
+import pytest
+
+from ocrd_keraslm_amd.lib import Rater
+from tests.oracle_engine import OracleLM
+
+CHARS = "abcdefghijklmnopqrstuvwxyz ABCDEFG.,;!?\n-"
+
+
+def synth_files(tmp, n=3, size=1500, seed=1):
+    rng = np.random.default_rng(seed)
+    trans = rng.dirichlet(np.full(len(CHARS), 0.05), size=len(CHARS))
+    names = []
+    for i in range(n):
+        s = [int(rng.integers(len(CHARS)))]
+        for _ in range(size - 1):
+            s.append(int(rng.choice(len(CHARS), p=trans[s[-1]])))
+        name = os.path.join(tmp, "anon_text%d_%d.txt" % (i, 1784 + i))
+        with open(name, "w") as f:
+            f.write("".join(CHARS[j] for j in s))
+        names.append(name)
+    return names
+
+
+def hip_factory(*args):
+    from ocrd_keraslm_amd.lib.engine import HipLM
+    return HipLM(*args)
+
+
+@pytest.mark.parametrize("factory,width,length,size", [
+    pytest.param(OracleLM, 32, 16, 400, id="oracle-cpu"),
+    pytest.param(hip_factory, 128, 64, 1500, id="hip", marks=pytest.mark.gpu)])
+def test_train_save_load_rate(factory, width, length, size):
+    random.seed(3)
+    with tempfile.TemporaryDirectory() as tmp:
+        names = synth_files(tmp, size=size)
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            r = Rater(engine_factory=factory)
+            r.width, r.depth, r.length = width, 1, length
+            r.max_epochs = 1
+            r.seed = 5
+            r.configure()
+            assert r.status == 1
+            r.train([open(n) for n in names])
+            assert r.status == 2
+            assert set(r.history) == {"loss", "accuracy", "val_loss", "val_accuracy"}
+            assert np.isfinite(r.history["loss"][0]) and np.isfinite(r.history["val_loss"][0])
+            model_file = os.path.join(tmp, "model.npz")
+            r.save(model_file)
+            weights = r.model.get_weights()
+
+            r2 = Rater(engine_factory=factory)
+            r2.load_config(model_file)
+            assert (r2.width, r2.depth, r2.length, r2.stateful) == (width, 1, length, True)
+            assert r2.mapping == r.mapping and r2.voc_size == r.voc_size
+            r2.configure()
+            r2.load_weights(model_file)
+            assert r2.status == 2
+            for k, v in r2.model.get_weights().items():
+                assert np.array_equal(v, weights[k]), k
+
+            text = open(names[0]).read()[:150]
+            result, ppl = r2.rate_once(text, [179])
+            assert len(result) == len(text) and result[0] == (text[0], 1.0)
+            assert np.isfinite(ppl) and 1.0 < ppl < r2.voc_size
+            # windowed rating of the same string from a fresh state gives the same probabilities
+            r2.model.reset_states(1)
+            probs = r2.rate(text, [179])
+            assert np.abs(np.array(probs, dtype=np.float64) - np.array([p for _, p in result])).max() < 1e-5
+            # evaluation: perplexity of held-out files
+            p = r2.test([open(names[-1])])
+            assert np.isfinite(p) and 1.0 < p < 2 * r2.voc_size
+        finally:
+            os.chdir(cwd)
