@@ -261,9 +261,9 @@ int prepare_impl(kl_handle* h, int precision, hipStream_t s) {
     KL_TRY(kl_launch_f32_to_bf16_t(K, 4 * W, W, 4 * W, d.Kn[l], nullptr, 4 * W, 0, s));
   }
   const float* E = P + h->off_E;
-  KL_TRY(hip_ok(hipMemsetAsync(d.E_hi, 0, (size_t)Vp * W * sizeof(bf16_t), s)));
-  KL_TRY(hip_ok(hipMemsetAsync(d.E_lo, 0, (size_t)Vp * W * sizeof(bf16_t), s)));
-  KL_TRY(hip_ok(hipMemsetAsync(d.ET, 0, (size_t)W * Vp * sizeof(bf16_t), s)));
+  KL_TRY(kl_zero_async(d.E_hi, (size_t)Vp * W * sizeof(bf16_t), s));
+  KL_TRY(kl_zero_async(d.E_lo, (size_t)Vp * W * sizeof(bf16_t), s));
+  KL_TRY(kl_zero_async(d.ET, (size_t)W * Vp * sizeof(bf16_t), s));
   KL_TRY(kl_launch_f32_to_bf16_t(E, W, V, W, d.E_hi, split ? d.E_lo : nullptr, W, 0, s));
   KL_TRY(kl_launch_f32_to_bf16_t(E, W, V, W, d.ET, nullptr, Vp, 1, s));
   // layer-0 look-up tables: EK = E . K0[:W] ; CtxK_n = Ctx_n . K0[W+10n ..]
@@ -536,8 +536,8 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   Derived& d = h->d;
   const int ksplit = BT >= 4096 ? 8 : (BT >= 1024 ? 4 : 1);
 
-  KL_TRY(hip_ok(hipMemsetAsync(grads, 0, h->n_params * sizeof(float), s)));
-  KL_TRY(hip_ok(hipMemsetAsync(w.scan_status, 0, 4 * sizeof(unsigned), s)));
+  KL_TRY(kl_zero_async(grads, h->n_params * sizeof(float), s));
+  KL_TRY(kl_zero_async(w.scan_status, 4 * sizeof(unsigned), s));
   KL_TRY(forward_impl(h, B, T, idx, ctx, states, masks, 1, w, s));
 
   // F5/F6: logits over the (masked) top-layer outputs, softmax, CE, dlogits
@@ -548,9 +548,9 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   // B1: dH = dlogits . E ; dE += dlogits^T . Htop
   KL_TRY(kl_launch_gemm_tn(w.dlogits, d.ET, w.dH, nullptr, BT, W, Vp, Vp, Vp, W, 0, 1, 1.f, s));
   if (BTp != BT) {
-    KL_TRY(hip_ok(hipMemsetAsync(w.dlogitsT, 0, (size_t)Vp * BTp * sizeof(bf16_t), s)));
-    KL_TRY(hip_ok(hipMemsetAsync(w.HT, 0, (size_t)W * BTp * sizeof(bf16_t), s)));
-    KL_TRY(hip_ok(hipMemsetAsync(w.dZT, 0, (size_t)4 * W * BTp * sizeof(bf16_t), s)));
+    KL_TRY(kl_zero_async(w.dlogitsT, (size_t)Vp * BTp * sizeof(bf16_t), s));
+    KL_TRY(kl_zero_async(w.HT, (size_t)W * BTp * sizeof(bf16_t), s));
+    KL_TRY(kl_zero_async(w.dZT, (size_t)4 * W * BTp * sizeof(bf16_t), s));
   }
   KL_TRY(kl_launch_transpose_bf16(w.dlogits, Vp, w.dlogitsT, BTp, BT, Vp, s));
   KL_TRY(kl_launch_transpose_bf16(Htop, W, w.HT, BTp, BT, W, s));
@@ -638,9 +638,9 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       KL_TRY(kl_launch_gemm_tn(w.HT, w.dZT, grads + h->off_K[l], nullptr, W, 4 * W, BTp, BTp, BTp, 4 * W, 2, ksplit, 1.f, s));
     } else {
       // layer 0 through the look-up tables: dEK^T = dZ^T . OneHot ; dCtxK_n^T likewise
-      KL_TRY(hip_ok(hipMemsetAsync(w.OHT, 0, (size_t)Vp * BTp * sizeof(bf16_t), s)));
+      KL_TRY(kl_zero_async(w.OHT, (size_t)Vp * BTp * sizeof(bf16_t), s));
       KL_TRY(kl_launch_onehot_t(idx, B, T, V, 0, 1, w.OHT, BTp, s));
-      KL_TRY(hip_ok(hipMemsetAsync(w.dEKT, 0, (size_t)4 * W * Vp * sizeof(float), s)));
+      KL_TRY(kl_zero_async(w.dEKT, (size_t)4 * W * Vp * sizeof(float), s));
       KL_TRY(kl_launch_gemm_tn(w.dZT, w.OHT, w.dEKT, nullptr, 4 * W, Vp, BTp, BTp, BTp, Vp, 2, ksplit, 1.f, s));
       KL_TRY(kl_launch_f32_to_bf16_t(w.dEKT, Vp, 4 * W, Vp, w.dEKT_bf, nullptr, Vp, 0, s));
       KL_TRY(kl_launch_f32_to_bf16_t(w.dEKT, Vp, 4 * W, Vp, w.dEK_bf, nullptr, 4 * W, 1, s));
@@ -649,9 +649,9 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       // dE += dEK . K0[:W]^T     (C[V][W] = dEK[V][4W] . Kn0[W][4W]^T)
       KL_TRY(kl_launch_gemm_tn(w.dEK_bf, d.Kn[0], grads + h->off_E, nullptr, V, W, 4 * W, 4 * W, 4 * W, W, 2, 1, 1.f, s));
       for (int n = 0; n < c.n_ctx; ++n) {
-        KL_TRY(hip_ok(hipMemsetAsync(w.OHC[n], 0, (size_t)c.ctx_vocab * BTp * sizeof(bf16_t), s)));
+        KL_TRY(kl_zero_async(w.OHC[n], (size_t)c.ctx_vocab * BTp * sizeof(bf16_t), s));
         KL_TRY(kl_launch_onehot_t(ctx, B, T, c.ctx_vocab, n, c.n_ctx, w.OHC[n], BTp, s));
-        KL_TRY(hip_ok(hipMemsetAsync(w.dCtxKT[n], 0, (size_t)4 * W * c.ctx_vocab * sizeof(float), s)));
+        KL_TRY(kl_zero_async(w.dCtxKT[n], (size_t)4 * W * c.ctx_vocab * sizeof(float), s));
         KL_TRY(kl_launch_gemm_tn(w.dZT, w.OHC[n], w.dCtxKT[n], nullptr, 4 * W, c.ctx_vocab, BTp, BTp, BTp,
                                  c.ctx_vocab, 2, ksplit, 1.f, s));
         const size_t krow = (size_t)(W + n * c.ctx_dim) * 4 * W;

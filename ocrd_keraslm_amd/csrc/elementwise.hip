@@ -369,3 +369,49 @@ int kl_launch_fill_f32(float* p, size_t n, float v, hipStream_t stream) {
   hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for((long)n, 256)), dim3(256), 0, stream, p, n, v);
   return ok();
 }
+
+// ---- zero fills as kernels ---------------------------------------------------------
+// hipMemsetAsync nodes inside a replayed hipGraph were observed to lose their effect /
+// ordering after the first host synchronisation on ROCm 7.2 (gradients accumulated
+// across windows, status words kept stale values); plain kernels replay correctly.
+namespace {
+__global__ void zero_kernel(uint4* p16, size_t n16, unsigned* tail, size_t ntail) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    p16[i] = uint4{0, 0, 0, 0};
+  if (blockIdx.x == 0 && threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+// write-through zeroing for words other workgroups poll (hand-off counters)
+__global__ void zero_coherent_kernel(unsigned* p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    __hip_atomic_store(p + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+}  // namespace
+
+int kl_zero_async(void* p, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(p) & 3) || (bytes & 3)) return KL_ERR_ARG;
+  uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  size_t head = ((16 - (a & 15)) & 15);
+  if (head > bytes) head = bytes;
+  // unaligned head words + 16-byte body + tail words
+  unsigned* hp = reinterpret_cast<unsigned*>(p);
+  size_t nhead = head / 4;
+  uint4* body = reinterpret_cast<uint4*>(a + head);
+  size_t n16 = (bytes - head) / 16;
+  unsigned* tp = reinterpret_cast<unsigned*>(a + head + n16 * 16);
+  size_t ntail = (bytes - head - n16 * 16) / 4;
+  if (nhead) hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(64), 0, stream, (uint4*)nullptr, (size_t)0, hp, nhead);
+  long g = (long)((n16 + 255) / 256);
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)g), dim3(256), 0, stream, body, n16, tp, ntail);
+  return ok();
+}
+
+int kl_zero_coherent_async(unsigned* p, size_t n_words, hipStream_t stream) {
+  if (n_words == 0) return 0;
+  long g = (long)((n_words + 255) / 256);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(zero_coherent_kernel, dim3((unsigned)g), dim3(256), 0, stream, p, n_words);
+  return ok();
+}

@@ -123,6 +123,8 @@ int kl_launch_regulariser_grads(const float* E, int V, int W, const float* const
 int kl_launch_state_to_rows(const float* states, int B, int W, int L, int layer, bf16_t* h_bf16, float* h_f32,
                             float* c_f32, hipStream_t stream);
 int kl_launch_fill_f32(float* p, size_t n, float v, hipStream_t stream);
+int kl_zero_async(void* p, size_t bytes, hipStream_t stream);               // kernel-based memset(0)
+int kl_zero_coherent_async(unsigned* p, size_t n_words, hipStream_t stream);  // write-through zero of polled words
 
 // ---- tables.hip ---------------------------------------------------------
 int kl_launch_small_table(const float* A, int R, int D, const float* Kmat, long ldk, int N, float* C, long ldc,

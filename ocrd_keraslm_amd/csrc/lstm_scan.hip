@@ -41,7 +41,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-constexpr unsigned SPIN_LIMIT = 1u << 22;
+constexpr unsigned SPIN_LIMIT = 1u << 20;
 
 // diagnostic build only (-DKL_STAMP): cycle shares of the forward scan's step phases
 #ifdef KL_STAMP
@@ -466,8 +466,8 @@ int kl_launch_scan_fwd(KlScanFwd a, hipStream_t stream) {
   const int W = a.W;
   int per_wg = 0;
   if (!plan_scan(W, a.L, a.B, a.T, &a.n_rb, &a.n_rg, &per_wg)) return KL_ERR_SHAPE;
-  if (hipMemsetAsync(a.counters, 0, (size_t)a.L * a.n_rb * a.T * sizeof(unsigned), stream) != hipSuccess) return KL_ERR_LAUNCH;
-  if (hipMemsetAsync(a.status, 0, sizeof(unsigned), stream) != hipSuccess) return KL_ERR_LAUNCH;
+  if (kl_zero_coherent_async(a.counters, (size_t)a.L * a.n_rb * a.T, stream) != 0) return KL_ERR_LAUNCH;
+  if (kl_zero_coherent_async(a.status, 1, stream) != 0) return KL_ERR_LAUNCH;
   dim3 grid(a.L * (W / 16) * a.n_rg), block(256);
   KL_SCAN_DISPATCH(lstm_scan_fwd_kernel);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
@@ -477,8 +477,8 @@ int kl_launch_scan_bwd(KlScanBwd a, hipStream_t stream) {
   const int W = a.W;
   int per_wg = 0;
   if (!plan_scan(W, a.L, a.B, a.T, &a.n_rb, &a.n_rg, &per_wg)) return KL_ERR_SHAPE;
-  if (hipMemsetAsync(a.counters, 0, (size_t)a.L * a.n_rb * a.T * sizeof(unsigned), stream) != hipSuccess) return KL_ERR_LAUNCH;
-  if (hipMemsetAsync(a.status, 0, sizeof(unsigned), stream) != hipSuccess) return KL_ERR_LAUNCH;
+  if (kl_zero_coherent_async(a.counters, (size_t)a.L * a.n_rb * a.T, stream) != 0) return KL_ERR_LAUNCH;
+  if (kl_zero_coherent_async(a.status, 1, stream) != 0) return KL_ERR_LAUNCH;
   dim3 grid(a.L * (W / 16) * a.n_rg), block(256);
   KL_SCAN_DISPATCH(lstm_scan_bwd_kernel);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
