@@ -93,7 +93,7 @@ def cpu_baseline(seconds=15.0):
         _, _, states = O.train_step(cfg, w, opt, idx, ctx, tgt, states, masks)
         n += 1
         el = time.time() - t0
-        if el >= seconds or n >= 60:
+        if el >= seconds or n >= 400:
             break
     return {"value": n * LENGTH / el, "unit": "chars/s", "cores": int(threads), "kind": "port",
             "sample": "%d stateful windows of 1x%d chars (forward+backward+Adam, numpy f32 oracle, %.1f s)" % (n, LENGTH, el)}
@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("KL_BENCH_STREAMS", "64")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("KL_BENCH_STREAMS", "256")),
                     help="stateful streams per GPU (B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-incremental", action="store_true")
@@ -184,21 +184,24 @@ def main():
         step(args.warmup + args.steps)
         torch.cuda.synchronize()
         out = {}
-        for kind, name in ((0, "lstm_fwd_step_kernel"), (1, "lstm_bwd_step_kernel")):
-            n, ms = C.c_int(), C.c_float()
-            hipabi.check(lm.lib.kl_trace_read(lm.handle, kind, C.byref(n), C.byref(ms)))
-            out[name] = (n.value, ms.value)
+        for kind, step_name, scan_name in ((0, "lstm_fwd_step_kernel", "lstm_scan_fwd_kernel"),
+                                           (1, "lstm_bwd_step_kernel", "lstm_scan_bwd_kernel")):
+            n, ms, pers = C.c_int(), C.c_float(), C.c_int()
+            hipabi.check(lm.lib.kl_trace_read(lm.handle, kind, C.byref(n), C.byref(ms), C.byref(pers)))
+            out[scan_name if pers.value else step_name] = (n.value, ms.value, bool(pers.value))
         hipabi.check(lm.lib.kl_trace_enable(lm.handle, 0))
-        name = max(out, key=lambda k: out[k][1] / max(out[k][0], 1))
-        n, ms = out[name]
-        n *= 8                                        # each event pair brackets 8 consecutive launches
+        name = max(out, key=lambda k: out[k][1])          # the recurrence kernel with the larger total time
+        n, ms, pers = out[name]
         per_launch_s = ms / max(n, 1) / 1e3
-        flops_launch = B * flops_cell_per_char()      # one launch = every layer's cell at one time step, B rows
+        # algorithmic FLOPs of one launch (SURVEY.md 8d per-char figure x chars per launch): a persistent
+        # scan launch runs the cell contractions of all L layers for B*T chars, a step launch for B chars
+        flops_launch = (B * T if pers else B) * flops_cell_per_char()
         achieved = flops_launch / per_launch_s / 1e12 if per_launch_s > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                    "launch_us": per_launch_s * 1e6, "launches_timed": n,
+                    "launch_us": per_launch_s * 1e6, "launches_timed": n, "persistent": pers,
                     "flops_per_launch": flops_launch,
+                    "other_kernel": {k: {"launches": v[0], "total_ms": v[1]} for k, v in out.items() if k != name},
                     "whole_step_frac": value * 3 * flops_fwd_per_char() / world / 1e12 / MFMA_BF16_PEAK_TFLOPS}
 
     # ---- incremental rescoring (cfg3): 1024 hypotheses x 512 chars on this GPU

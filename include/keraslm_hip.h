@@ -136,13 +136,15 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
 int kl_state_dist2(const kl_handle* h, int n, const float* pool, const int32_t* a, const int32_t* b, int k,
                    float* out, void* stream);
 
-/* Per-launch timing of the cell-step kernels with HIP events on the caller's
+/* Per-launch timing of the recurrence kernels with HIP events on the caller's
  * stream (used by bench.py for the roofline figure).  While enabled, windows are
- * issued eagerly and every 8th steady-state step launch is bracketed by an event
- * pair.  kl_trace_read (after a stream synchronise) returns how many launches
- * were timed and their summed duration; kind 0 = forward steps, 1 = backward. */
+ * issued eagerly and the recurrence launches are bracketed by event pairs: each
+ * whole-window persistent scan launch, or -- on the launch-per-step path -- runs of
+ * 8 consecutive steady-state step launches.  kl_trace_read (after a stream
+ * synchronise) returns how many launches were timed, their summed duration and
+ * whether they were persistent scans; kind 0 = forward, 1 = backward recurrence. */
 int kl_trace_enable(kl_handle* h, int on);
-int kl_trace_read(kl_handle* h, int kind, int* n_launches, float* total_ms);
+int kl_trace_read(kl_handle* h, int kind, int* n_launches, float* total_ms, int* persistent);
 
 /* Test hooks: the bare contraction kernels on caller buffers. */
 int kl_test_gemm_tn(const uint16_t* A, const uint16_t* B, void* C, const float* bias, int M, int N, int K, long lda,

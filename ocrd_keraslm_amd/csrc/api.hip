@@ -99,6 +99,7 @@ struct kl_handle {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev[2];   // [0] forward steps, [1] backward steps
   size_t trace_used[2] = {0, 0};
   bool trace_open[2] = {false, false};
+  bool trace_persistent[2] = {false, false};   // the timed launches were whole-window persistent scans
   void trace_begin(int kind, hipStream_t s) {
     if (!trace_on) return;
     if (trace_used[kind] == trace_ev[kind].size()) {
@@ -300,7 +301,7 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
   };
   // persistent scan (one launch for all layers and steps) where the shape allows it
   bool scanned = false;
-  if (training && h->scan_enabled && !h->trace_on && L <= KL_SCAN_MAXL) {
+  if (training && h->scan_enabled && L <= KL_SCAN_MAXL) {
     KlScanFwd a;
     memset(&a, 0, sizeof(a));
     a.B = B; a.T = T; a.W = W; a.L = L;
@@ -318,9 +319,16 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
     a.P1 = w.P1;
     a.counters = w.scan_cnt;
     a.status = w.scan_status;
+    KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)L * ((B + 15) / 16) * T, s));
+    h->trace_begin(0, s);
     const int e = kl_launch_scan_fwd(a, s);
-    if (e == 0) scanned = true;
-    else if (e != KL_ERR_SHAPE) return e;
+    if (e == 0) {
+      scanned = true;
+      h->trace_persistent[0] = true;
+      h->trace_end(0, s);
+    } else if (e != KL_ERR_SHAPE) {
+      return e;
+    }
   }
   for (int dgl = 0; !scanned && dgl < T + L - 1; ++dgl) {
     KlFwdStep steps[4];
@@ -559,7 +567,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   // B3: reverse recurrence -- persistent scan where the shape allows it, else the
   // launch-per-step layer wavefront
   bool bscanned = false;
-  if (h->scan_enabled && !h->trace_on && L <= KL_SCAN_MAXL) {
+  if (h->scan_enabled && L <= KL_SCAN_MAXL) {
     KlScanBwd a;
     memset(&a, 0, sizeof(a));
     a.B = B; a.T = T; a.W = W; a.L = L;
@@ -574,9 +582,16 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
     a.dH = w.dH;
     a.counters = w.scan_cnt;
     a.status = w.scan_status + 1;
+    KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)L * ((B + 15) / 16) * T, s));
+    h->trace_begin(1, s);
     const int e = kl_launch_scan_bwd(a, s);
-    if (e == 0) bscanned = true;
-    else if (e != KL_ERR_SHAPE) return e;
+    if (e == 0) {
+      bscanned = true;
+      h->trace_persistent[1] = true;
+      h->trace_end(1, s);
+    } else if (e != KL_ERR_SHAPE) {
+      return e;
+    }
   }
   for (int dgl = 0; !bscanned && dgl < T + L - 1; ++dgl) {
     KlBwdStep steps[4];
@@ -896,11 +911,12 @@ extern "C" int kl_trace_enable(kl_handle* h, int on) {
   if (!h) return KL_ERR_ARG;
   h->trace_on = on != 0;
   h->trace_used[0] = h->trace_used[1] = 0;
+  h->trace_persistent[0] = h->trace_persistent[1] = false;
   return 0;
 }
 
 // kind 0 = forward cell-step launches, 1 = backward; call after synchronising the stream
-extern "C" int kl_trace_read(kl_handle* h, int kind, int* n_launches, float* total_ms) {
+extern "C" int kl_trace_read(kl_handle* h, int kind, int* n_launches, float* total_ms, int* persistent) {
   if (!h || kind < 0 || kind > 1 || !n_launches || !total_ms) return KL_ERR_ARG;
   float total = 0.f;
   int n = 0;
@@ -911,7 +927,9 @@ extern "C" int kl_trace_read(kl_handle* h, int kind, int* n_launches, float* tot
       ++n;
     }
   }
-  *n_launches = n;
+  // a pair brackets one persistent scan launch, or 8 consecutive launch-per-step launches
+  *n_launches = h->trace_persistent[kind] ? n : 8 * n;
   *total_ms = total;
+  if (persistent) *persistent = h->trace_persistent[kind] ? 1 : 0;
   return 0;
 }

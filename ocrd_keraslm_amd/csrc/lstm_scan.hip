@@ -466,8 +466,7 @@ int kl_launch_scan_fwd(KlScanFwd a, hipStream_t stream) {
   const int W = a.W;
   int per_wg = 0;
   if (!plan_scan(W, a.L, a.B, a.T, &a.n_rb, &a.n_rg, &per_wg)) return KL_ERR_SHAPE;
-  if (kl_zero_coherent_async(a.counters, (size_t)a.L * a.n_rb * a.T, stream) != 0) return KL_ERR_LAUNCH;
-  if (kl_zero_coherent_async(a.status, 1, stream) != 0) return KL_ERR_LAUNCH;
+  // (the caller has zeroed a.counters -- L*ceil(B/16)*T words -- and a.status, write-through)
   dim3 grid(a.L * (W / 16) * a.n_rg), block(256);
   KL_SCAN_DISPATCH(lstm_scan_fwd_kernel);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
@@ -477,8 +476,7 @@ int kl_launch_scan_bwd(KlScanBwd a, hipStream_t stream) {
   const int W = a.W;
   int per_wg = 0;
   if (!plan_scan(W, a.L, a.B, a.T, &a.n_rb, &a.n_rg, &per_wg)) return KL_ERR_SHAPE;
-  if (kl_zero_coherent_async(a.counters, (size_t)a.L * a.n_rb * a.T, stream) != 0) return KL_ERR_LAUNCH;
-  if (kl_zero_coherent_async(a.status, 1, stream) != 0) return KL_ERR_LAUNCH;
+  // (the caller has zeroed a.counters -- L*ceil(B/16)*T words -- and a.status, write-through)
   dim3 grid(a.L * (W / 16) * a.n_rg), block(256);
   KL_SCAN_DISPATCH(lstm_scan_bwd_kernel);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
