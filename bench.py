@@ -116,7 +116,12 @@ def main():
     from ocrd_keraslm_amd.lib.distributed import GradSync, init_from_env
     from ocrd_keraslm_amd.lib.engine import HipLM
 
-    rank, world, local = init_from_env("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    # rehearsal on a one-GPU box: KL_BENCH_SAME_GPU=1 maps every rank to cuda:0 and uses gloo
+    same_gpu = os.environ.get("KL_BENCH_SAME_GPU") == "1"
+    if same_gpu:
+        os.environ["LOCAL_RANK"] = "0"
+    backend = "gloo" if same_gpu else ("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    rank, world, local = init_from_env(backend)
     if world != args.gpus and world > 1:
         args.gpus = world
     device = "cuda:%d" % local
@@ -143,14 +148,15 @@ def main():
     gen.manual_seed(2 + rank)
     lm.reset_states(B)
 
-    def step(w):
+    def step(w, all_reduce=True):
         w = w % n_windows
         idx = streams[:, w * T:(w + 1) * T].contiguous()
         tgt = streams[:, w * T + 1:(w + 1) * T + 1].contiguous()
         keep = torch.rand((DEPTH, B, WIDTH), device=device, generator=gen) >= 0.1
         masks = keep.to(torch.float32) / 0.9
         lm.train_window(idx, ctx, tgt, masks)
-        sync.average(lm)
+        if all_reduce:
+            sync.average(lm)
         lm.adam_step()
 
     for w in range(args.warmup):
@@ -181,7 +187,7 @@ def main():
     roofline = None
     if rank == 0:
         hipabi.check(lm.lib.kl_trace_enable(lm.handle, 1))
-        step(args.warmup + args.steps)
+        step(args.warmup + args.steps, all_reduce=False)    # rank 0 only: no collective in this leg
         torch.cuda.synchronize()
         out = {}
         for kind, step_name, scan_name in ((0, "lstm_fwd_step_kernel", "lstm_scan_fwd_kernel"),
