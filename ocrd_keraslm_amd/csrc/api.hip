@@ -47,6 +47,8 @@ struct Carver {
 struct Derived {
   std::vector<bf16_t*> UT_hi, UT_lo, KT_hi, KT_lo, Un, Kn;   // per layer (KT/Kn of layer 0 = rows [0,W) of K0)
   bf16_t *E_hi = nullptr, *E_lo = nullptr, *ET = nullptr;
+  std::vector<bf16_t*> WTcat;    // [4W][3*K_l] = [hi | hi | lo] blocks, K_0 = W (U), K_l = 2W (K then U): big-n step path
+  bf16_t* Ecat = nullptr;        // [Vp][3W]
   float* EK = nullptr;
   std::vector<float*> CtxK;
 };
@@ -182,6 +184,9 @@ size_t carve_derived(const kl_handle* h, void* base, Derived* d) {
   o.E_lo = cv.take<bf16_t>(Vp * W);
   o.ET = cv.take<bf16_t>(W * Vp);
   o.EK = cv.take<float>(V * 4 * W);
+  o.WTcat.assign(c.depth, nullptr);
+  for (int l = 0; l < c.depth; ++l) o.WTcat[l] = cv.take<bf16_t>(4 * W * 3 * (l == 0 ? W : 2 * W));
+  o.Ecat = cv.take<bf16_t>(Vp * 3 * W);
   o.CtxK.assign(c.n_ctx, nullptr);
   for (int n = 0; n < c.n_ctx; ++n) o.CtxK[n] = cv.take<float>((size_t)c.ctx_vocab * 4 * W);
   return align_up(cv.off, 256);
@@ -277,6 +282,24 @@ int prepare_impl(kl_handle* h, int precision, hipStream_t s) {
     const float* Kc = P + h->off_K[0] + (size_t)(W + n * c.ctx_dim) * 4 * W;
     KL_TRY(kl_launch_small_table(P + h->off_Ctx[n], c.ctx_vocab, c.ctx_dim, Kc, 4 * W, 4 * W, d.CtxK[n], 4 * W, s));
   }
+  // concatenated [hi | hi | lo] operands of the big-n incremental step (step_big.hip)
+  for (int l = 0; l < c.depth; ++l) {
+    const int Kl = l == 0 ? W : 2 * W;
+    const long ld = 3L * Kl;
+    const float* K = P + h->off_K[l];
+    const float* U = P + h->off_U[l];
+    bf16_t* base = d.WTcat[l];
+    const int uoff = l == 0 ? 0 : W;     // U part follows the K part inside each block
+    if (l > 0) {
+      KL_TRY(kl_launch_f32_to_bf16_t(K, 4 * W, W, 4 * W, base, split ? base + 2 * Kl : nullptr, ld, 1, s));
+      if (split) KL_TRY(kl_launch_f32_to_bf16_t(K, 4 * W, W, 4 * W, base + Kl, nullptr, ld, 1, s));
+    }
+    KL_TRY(kl_launch_f32_to_bf16_t(U, 4 * W, W, 4 * W, base + uoff, split ? base + 2 * Kl + uoff : nullptr, ld, 1, s));
+    if (split) KL_TRY(kl_launch_f32_to_bf16_t(U, 4 * W, W, 4 * W, base + Kl + uoff, nullptr, ld, 1, s));
+  }
+  KL_TRY(kl_zero_async(d.Ecat, (size_t)Vp * 3 * W * sizeof(bf16_t), s));
+  KL_TRY(kl_launch_f32_to_bf16_t(E, W, V, W, d.Ecat, split ? d.Ecat + 2 * W : nullptr, 3 * W, 0, s));
+  if (split) KL_TRY(kl_launch_f32_to_bf16_t(E, W, V, W, d.Ecat + W, nullptr, 3 * W, 0, s));
   h->precision = precision;
   return 0;
 }
@@ -700,7 +723,9 @@ int kl_adam_step(kl_handle* h, const float* grads, float* m, float* v, int t, fl
 size_t kl_step_workspace_bytes(const kl_handle* h, int n) {
   if (!h || n < 1) return 0;
   Carver cv(nullptr);
-  cv.take<float>((size_t)n * 4 * h->cfg.width);   // P rows when n_ctx != 1
+  cv.take<float>((size_t)n * 4 * h->cfg.width);          // P rows when n_ctx != 1
+  cv.take<float>((size_t)n * 4 * h->cfg.width);          // z of the big-n path
+  cv.take<bf16_t>((size_t)n * 3 * 2 * h->cfg.width);     // [hi | lo | hi] activation rows
   return align_up(cv.off, 256);
 }
 
@@ -724,6 +749,41 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
     for (int k = 0; k < c.n_ctx; ++k) ctxk[k] = d.CtxK[k];
     // rows are hypotheses: treat as B = n streams, T = 1
     KL_TRY(kl_launch_p1_gather(d.EK, ctxk.data(), c.n_ctx, P + h->off_b[0], idx, ctx, n, 1, 4 * W, prow, s));
+  }
+  if (n >= KL_BIG_STEP_N && ws && ws_bytes >= kl_step_workspace_bytes(h, n)) {
+    // big-tile path: gather+split -> one bf16 GEMM over the 3x contraction -> gates
+    Carver cv(ws);
+    cv.take<float>((size_t)n * 4 * W);
+    float* z = cv.take<float>((size_t)n * 4 * W);
+    bf16_t* A3 = cv.take<bf16_t>((size_t)n * 3 * 2 * W);
+    const int nb = split == 3 ? 3 : 1;
+    for (int l = 0; l < L; ++l) {
+      const int Kl = l == 0 ? W : 2 * W;
+      if (l == 0) {
+        KL_TRY(kl_launch_split_gather(pool, slot_ld, slot_in, W, nullptr, 0, nullptr, 0, n, nb, A3, 3L * Kl, s));
+      } else {
+        KL_TRY(kl_launch_split_gather(pool + (size_t)2 * (l - 1) * W, slot_ld, slot_out, W, pool + (size_t)2 * l * W, slot_ld,
+                                      slot_in, W, n, nb, A3, 3L * Kl, s));
+      }
+      KL_TRY(kl_launch_gemm_tn(A3, d.WTcat[l], z, nullptr, n, 4 * W, nb * Kl, 3L * Kl, 3L * Kl, 4 * W, 0, 1, 1.f, s));
+      const bool tab = l == 0 && !prow;
+      KL_TRY(kl_launch_gates_rows(z, 4 * W, n, W, l == 0 ? (prow ? prow : d.EK) : nullptr, tab ? idx : nullptr,
+                                  tab ? d.CtxK[0] : nullptr, tab ? ctx : nullptr,
+                                  (l > 0 || tab) ? P + h->off_b[l] : nullptr, pool + (size_t)(2 * l + 1) * W, slot_ld, slot_in,
+                                  pool + (size_t)(2 * l + 1) * W, pool + (size_t)2 * l * W, slot_ld, slot_out, s));
+    }
+    if (V >= 1024) {   // wide vocabulary: big tiles pay off for the output projection too
+      KL_TRY(kl_launch_split_gather(pool + (size_t)2 * (L - 1) * W, slot_ld, slot_out, W, nullptr, 0, nullptr, 0, n, nb, A3, 3L * W, s));
+      KL_TRY(kl_launch_gemm_tn(A3, d.Ecat, probs, nullptr, n, V, nb * W, 3L * W, 3L * W, V, 0, 1, 1.f, s));
+    } else {           // V x W is small: the thin kernel spreads it over n/32 x V/16 workgroups
+      KlOperand op;
+      memset(&op, 0, sizeof(op));
+      op.A = pool + (size_t)2 * (L - 1) * W; op.lda = slot_ld; op.row_index = slot_out; op.a_is_f32 = 1;
+      op.WT_hi = d.E_hi; op.WT_lo = split == 3 ? d.E_lo : nullptr; op.ldw = W; op.K = W;
+      KL_TRY(kl_launch_thin_gemm(&op, n, V, probs, V, nullptr, split, s));
+    }
+    KL_TRY(kl_launch_softmax_ce(probs, V, n, V, nullptr, n, 1, 1.f, nullptr, 0, nullptr, nullptr, 0, s));
+    return 0;
   }
   for (int l = 0; l < L; ++l) {
     KlFwdStep S;

@@ -137,3 +137,11 @@ int kl_launch_rows_to_state(const void* h_rows, int h_is_f32, const float* c_row
 int kl_launch_ctx_grads(const float* Ctx, const float* K0rows, long ldk, int R, int D, const float* dT, long ldt, int N,
                         float* gK, long ldg, float* gCtx, hipStream_t stream);
 int kl_launch_rows_tm_to_bm(const float* in, long ld_in, float* out, int B, int T, int V, hipStream_t stream);
+
+// ---- step_big.hip -------------------------------------------------------
+#define KL_BIG_STEP_N 256   // from this many hypotheses on, kl_step_batch uses big-tile GEMMs
+int kl_launch_split_gather(const float* s0, long ld0, const int* i0, int w0, const float* s1, long ld1, const int* i1,
+                           int w1, int n, int nb, bf16_t* out, long ld_out, hipStream_t stream);
+int kl_launch_gates_rows(const float* z, long ldz, int n, int W, const float* T1, const int* i1, const float* T2,
+                         const int* i2, const float* bias, const float* c_prev, long c_ld, const int* slot_in,
+                         float* c_out, float* h_out, long out_ld, const int* slot_out, hipStream_t stream);

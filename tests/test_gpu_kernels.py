@@ -103,7 +103,9 @@ def make_model(depth, width, voc, n_ctx=1, seed=4, emb_std=0.5):
 
 
 @pytest.mark.parametrize("depth,width,voc,n,n_ctx", [(2, 64, 50, 5, 1), (2, 512, 256, 70, 1), (1, 128, 40, 33, 1),
-                                                     (3, 96, 30, 17, 2)])
+                                                     (3, 96, 30, 17, 2),
+                                                     # n >= 256: big-tile path (step_big.hip)
+                                                     (2, 512, 256, 300, 1), (3, 96, 30, 260, 2), (1, 128, 40, 257, 1)])
 def test_step_batch_parity(depth, width, voc, n, n_ctx):
     """S1 (rating.py:578-639): chained incremental steps through pool slots."""
     torch = _torch()
