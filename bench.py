@@ -203,8 +203,18 @@ def main():
         # scan launch runs the cell contractions of all L layers for B*T chars, a step launch for B chars
         flops_launch = (B * T if pers else B) * flops_cell_per_char()
         achieved = flops_launch / per_launch_s / 1e12 if per_launch_s > 0 else 0.0
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command
+        # (FETCH_SIZE doubled as the gfx950 guide prescribes); the summary is committed under profiles/
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_B%d.json" % B)))
+            for k, v in pmc["kernels"].items():
+                if k.startswith(name):
+                    traffic = v["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roofline = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                     "launch_us": per_launch_s * 1e6, "launches_timed": n, "persistent": pers,
                     "flops_per_launch": flops_launch,
                     "other_kernel": {k: {"launches": v[0], "total_ms": v[1]} for k, v in out.items() if k != name},
