@@ -217,3 +217,47 @@ if __name__ == "__main__":
     with open(os.path.join(HERE, "rater_seam.json"), "w") as f:
         json.dump(golden_seam(), f)
     print("golden fixtures written")
+
+
+# ---------------------------------------------------------------------------------------
+# G3: a model file written by the reference's own Rater.save (rating.py:918-945) on top of
+# a Keras-2.3-style save_weights layout produced with h5py.
+def golden_model_file(path):
+    import h5py
+
+    class SavingStub(StubModel):
+        def save_weights(self, filename):
+            cfg, w = self.cfg, self.w
+            layers = [("char_input", []), ("context1_input", []),
+                      ("char_embedding", [("embeddings:0", w["E"])]),
+                      ("context1_embedding", [("embeddings:0", w["Ctx0"])]),
+                      ("concat_hidden_input", [])]
+            for l in range(cfg.depth):
+                name = "lstm_%d" % (l + 1)
+                # TF uniquifies variable scopes on the second configure(): lstm_1/lstm_1_1/kernel:0
+                scope = name + ("_1" if l == 0 else "")
+                layers.append((name, [(scope + "/kernel:0", w["K%d" % l]), (scope + "/recurrent_kernel:0", w["U%d" % l]),
+                                      (scope + "/bias:0", w["b%d" % l])]))
+                if l > 0:
+                    layers.append(("dropout_%d" % l, []))
+            layers.append(("char_output", []))
+            with h5py.File(filename, "w") as f:
+                f.attrs["layer_names"] = np.array([n.encode("utf8") for n, _ in layers])
+                f.attrs["backend"] = b"tensorflow"
+                f.attrs["keras_version"] = b"2.3.1"
+                for name, weights in layers:
+                    g = f.create_group(name)
+                    names = [(wn if "/" in wn else name + "/" + wn) for wn, _ in weights]
+                    g.attrs["weight_names"] = np.array([n.encode("utf8") for n in names]) if names else np.zeros((0,), "S1")
+                    for n, (_, val) in zip(names, weights):
+                        g.create_dataset(n, data=np.asarray(val, dtype=np.float32))
+
+    r, cfg = make_rater(2, 32, 16, True, False)
+    r.model.__class__ = SavingStub
+    r.history = {"loss": [3.5, 3.25], "val_loss": [3.4, 3.3], "accuracy": [0.1, 0.2], "val_accuracy": [0.1, 0.15]}
+    r.save(path)
+
+
+if __name__ == "__main__":
+    golden_model_file(os.path.join(HERE, "ref_model.h5"))
+    print("reference model file written")

@@ -57,7 +57,7 @@ def test_train_save_load_rate(factory, width, length, size):
             assert r.status == 2
             assert set(r.history) == {"loss", "accuracy", "val_loss", "val_accuracy"}
             assert np.isfinite(r.history["loss"][0]) and np.isfinite(r.history["val_loss"][0])
-            model_file = os.path.join(tmp, "model.npz")
+            model_file = os.path.join(tmp, "model.h5")
             r.save(model_file)
             weights = r.model.get_weights()
 
