@@ -192,16 +192,17 @@ def main():
         out = {}
         for kind, step_name, scan_name in ((0, "lstm_fwd_step_kernel", "lstm_scan_fwd_kernel"),
                                            (1, "lstm_bwd_step_kernel", "lstm_scan_bwd_kernel")):
-            n, ms, pers = C.c_int(), C.c_float(), C.c_int()
-            hipabi.check(lm.lib.kl_trace_read(lm.handle, kind, C.byref(n), C.byref(ms), C.byref(pers)))
-            out[scan_name if pers.value else step_name] = (n.value, ms.value, bool(pers.value))
+            n, ms, pers, fl = C.c_int(), C.c_float(), C.c_int(), C.c_double()
+            hipabi.check(lm.lib.kl_trace_read(lm.handle, kind, C.byref(n), C.byref(ms), C.byref(pers), C.byref(fl)))
+            out[scan_name if pers.value else step_name] = (n.value, ms.value, bool(pers.value), fl.value)
         hipabi.check(lm.lib.kl_trace_enable(lm.handle, 0))
         name = max(out, key=lambda k: out[k][1])          # the recurrence kernel with the larger total time
-        n, ms, pers = out[name]
+        n, ms, pers, fl = out[name]
         per_launch_s = ms / max(n, 1) / 1e3
-        # algorithmic FLOPs of one launch (SURVEY.md 8d per-char figure x chars per launch): a persistent
-        # scan launch runs the cell contractions of all L layers for B*T chars, a step launch for B chars
-        flops_launch = (B * T if pers else B) * flops_cell_per_char()
+        # algorithmic FLOPs of one launch: a persistent scan launch reports the LSTM contractions it
+        # carries for its B*T chars (the library knows whether layers are fused or scanned one by one);
+        # a step launch carries every layer's cell for B chars (SURVEY.md 8d per-char figure)
+        flops_launch = fl if pers else B * flops_cell_per_char()
         achieved = flops_launch / per_launch_s / 1e12 if per_launch_s > 0 else 0.0
         # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE doubled as the gfx950 guide prescribes); the summary is committed under profiles/
@@ -217,7 +218,8 @@ def main():
                     "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                     "launch_us": per_launch_s * 1e6, "launches_timed": n, "persistent": pers,
                     "flops_per_launch": flops_launch,
-                    "other_kernel": {k: {"launches": v[0], "total_ms": v[1]} for k, v in out.items() if k != name},
+                    "other_kernel": {k: {"launches": v[0], "total_ms": v[1], "flops_per_launch": v[3]}
+                                     for k, v in out.items() if k != name},
                     "whole_step_frac": value * 3 * flops_fwd_per_char() / world / 1e12 / MFMA_BF16_PEAK_TFLOPS}
 
     # ---- incremental rescoring (cfg3): 1024 hypotheses x 512 chars on this GPU

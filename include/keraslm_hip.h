@@ -142,9 +142,11 @@ int kl_state_dist2(const kl_handle* h, int n, const float* pool, const int32_t* 
  * whole-window persistent scan launch, or -- on the launch-per-step path -- runs of
  * 8 consecutive steady-state step launches.  kl_trace_read (after a stream
  * synchronise) returns how many launches were timed, their summed duration and
- * whether they were persistent scans; kind 0 = forward, 1 = backward recurrence. */
+ * whether they were persistent scans (then also the LSTM contraction FLOPs one such
+ * launch carries); kind 0 = forward, 1 = backward recurrence. */
 int kl_trace_enable(kl_handle* h, int on);
-int kl_trace_read(kl_handle* h, int kind, int* n_launches, float* total_ms, int* persistent);
+int kl_trace_read(kl_handle* h, int kind, int* n_launches, float* total_ms, int* persistent,
+                  double* flops_per_launch);
 
 /* Test hooks: the bare contraction kernels on caller buffers. */
 int kl_test_gemm_tn(const uint16_t* A, const uint16_t* B, void* C, const float* bias, int M, int N, int K, long lda,

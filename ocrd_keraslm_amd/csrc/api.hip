@@ -95,6 +95,9 @@ struct kl_handle {
   std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;
   bool graphs_enabled = true;
   bool scan_enabled = true;     // persistent scans (KL_SCAN=0 forces the launch-per-step path)
+  bool seq_bwd = true;          // layer-sequential backward scans for many row blocks (KL_SEQ_BWD=0: always fused)
+  bool wide_bwd = true;         // ... with 64-unit workgroups (KL_WIDE_BWD=0: thin workgroups)
+  double trace_flops[2] = {0.0, 0.0};   // algorithmic FLOPs of ONE timed launch
   // optional per-launch timing of the cell-step kernels with HIP events (bench.py's
   // roofline leg).  While tracing, windows run eagerly (events are not captured).
   bool trace_on = false;
@@ -226,7 +229,7 @@ size_t carve_window(const kl_handle* h, void* base, int B, int T, int training, 
       o.dc1[l] = cv.take<float>((size_t)B * W);
     }
     o.dZT = cv.take<bf16_t>(4 * W * BTp);
-    o.HT = cv.take<bf16_t>(W * BTp);
+    o.HT = cv.take<bf16_t>((W + 1) * BTp);
     o.dlogits = cv.take<bf16_t>(BT * Vp);
     o.dlogitsT = cv.take<bf16_t>(Vp * BTp);
     o.OHT = cv.take<bf16_t>(Vp * BTp);
@@ -348,6 +351,7 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
     if (e == 0) {
       scanned = true;
       h->trace_persistent[0] = true;
+      h->trace_flops[0] = (double)B * T * (2.0 * (2.0 * L - 1.0) * W * 4.0 * W);   // U_l for all l, K_l for l >= 1
       h->trace_end(0, s);
     } else if (e != KL_ERR_SHAPE) {
       return e;
@@ -511,6 +515,10 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->graphs_enabled = !(env && env[0] == '0');
   const char* env2 = getenv("KL_SCAN");
   h->scan_enabled = !(env2 && env2[0] == '0');
+  const char* env3 = getenv("KL_SEQ_BWD");
+  h->seq_bwd = !(env3 && env3[0] == '0');
+  const char* env4 = getenv("KL_WIDE_BWD");
+  h->wide_bwd = !(env4 && env4[0] == '0');
   return kl_zero_page_ready();
 }
 
@@ -569,6 +577,8 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
 
   KL_TRY(kl_zero_async(grads, h->n_params * sizeof(float), s));
   KL_TRY(kl_zero_async(w.scan_status, 4 * sizeof(unsigned), s));
+  if (BTp != BT) KL_TRY(kl_launch_fill_bf16(w.HT + (size_t)W * BTp, BTp, 0, s));
+  KL_TRY(kl_launch_fill_bf16(w.HT + (size_t)W * BTp, BT, 0x3F80, s));   // ones row of HT (bias gradients)
   KL_TRY(forward_impl(h, B, T, idx, ctx, states, masks, 1, w, s));
 
   // F5/F6: logits over the (masked) top-layer outputs, softmax, CE, dlogits
@@ -589,8 +599,94 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
 
   // B3: reverse recurrence -- persistent scan where the shape allows it, else the
   // launch-per-step layer wavefront
+  std::vector<char> wg_done(L, 0);
+  // B4/B5: weight gradients of one layer, K = B*T contractions over transposed activations
+  auto weight_grads = [&](int l, bool dzt_ready) -> int {
+    if (!dzt_ready) KL_TRY(kl_launch_transpose_bf16(w.dZ[l], 4 * W, w.dZT, BTp, BT, 4 * W, s));
+    // dU_l = Hprev^T . dZ   (Hprev = H blocks 0..T-1)
+    KL_TRY(kl_launch_transpose_bf16((const bf16_t*)w.H[l], W, w.HT, BTp, BT, W, s));
+    // row W of HT is all ones, and b_l follows U_l in the parameter layout: the same GEMM yields db_l = sum dZ
+    KL_TRY(kl_launch_gemm_tn(w.HT, w.dZT, grads + h->off_U[l], nullptr, W + 1, 4 * W, BTp, BTp, BTp, 4 * W, 2, ksplit, 1.f, s));
+    if (l > 0) {
+      // dK_l = X^T . dZ with X = (masked) outputs of layer l-1
+      const bool masked_in = masks != nullptr && (l - 1) > 0;
+      const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
+      KL_TRY(kl_launch_transpose_bf16(X, W, w.HT, BTp, BT, W, s));
+      KL_TRY(kl_launch_gemm_tn(w.HT, w.dZT, grads + h->off_K[l], nullptr, W, 4 * W, BTp, BTp, BTp, 4 * W, 2, ksplit, 1.f, s));
+    } else {
+      // layer 0 through the look-up tables: dEK^T = dZ^T . OneHot ; dCtxK_n^T likewise
+      KL_TRY(kl_zero_async(w.OHT, (size_t)Vp * BTp * sizeof(bf16_t), s));
+      KL_TRY(kl_launch_onehot_t(idx, B, T, V, 0, 1, w.OHT, BTp, s));
+      KL_TRY(kl_zero_async(w.dEKT, (size_t)4 * W * Vp * sizeof(float), s));
+      KL_TRY(kl_launch_gemm_tn(w.dZT, w.OHT, w.dEKT, nullptr, 4 * W, Vp, BTp, BTp, BTp, Vp, 2, ksplit, 1.f, s));
+      KL_TRY(kl_launch_f32_to_bf16_t(w.dEKT, Vp, 4 * W, Vp, w.dEKT_bf, nullptr, Vp, 0, s));
+      KL_TRY(kl_launch_f32_to_bf16_t(w.dEKT, Vp, 4 * W, Vp, w.dEK_bf, nullptr, 4 * W, 1, s));
+      // dK0[:W] = E^T . dEK      (C[W][4W] = ET[W][Vp] . dEKT[4W][Vp]^T)
+      KL_TRY(kl_launch_gemm_tn(d.ET, w.dEKT_bf, grads + h->off_K[0], nullptr, W, 4 * W, Vp, Vp, Vp, 4 * W, 0, 1, 1.f, s));
+      // dE += dEK . K0[:W]^T     (C[V][W] = dEK[V][4W] . Kn0[W][4W]^T)
+      KL_TRY(kl_launch_gemm_tn(w.dEK_bf, d.Kn[0], grads + h->off_E, nullptr, V, W, 4 * W, 4 * W, 4 * W, W, 2, 1, 1.f, s));
+      for (int n = 0; n < c.n_ctx; ++n) {
+        KL_TRY(kl_zero_async(w.OHC[n], (size_t)c.ctx_vocab * BTp * sizeof(bf16_t), s));
+        KL_TRY(kl_launch_onehot_t(ctx, B, T, c.ctx_vocab, n, c.n_ctx, w.OHC[n], BTp, s));
+        KL_TRY(kl_zero_async(w.dCtxKT[n], (size_t)4 * W * c.ctx_vocab * sizeof(float), s));
+        KL_TRY(kl_launch_gemm_tn(w.dZT, w.OHC[n], w.dCtxKT[n], nullptr, 4 * W, c.ctx_vocab, BTp, BTp, BTp,
+                                 c.ctx_vocab, 2, ksplit, 1.f, s));
+        const size_t krow = (size_t)(W + n * c.ctx_dim) * 4 * W;
+        KL_TRY(kl_launch_ctx_grads(P + h->off_Ctx[n], P + h->off_K[0] + krow, 4 * W, c.ctx_vocab, c.ctx_dim,
+                                   w.dCtxKT[n], c.ctx_vocab, 4 * W, grads + h->off_K[0] + krow, 4 * W,
+                                   grads + h->off_Ctx[n], s));
+      }
+    }
+      return 0;
+  };
   bool bscanned = false;
-  if (h->scan_enabled && L <= KL_SCAN_MAXL) {
+  // Many row blocks (B >= 256 at cfg2): the fused two-layer scan is bound by every
+  // workgroup re-reading its 16 x 4W dZ tile for BOTH contractions.  Run the layers one
+  // after the other instead -- each scan then only carries the recurrent contraction and
+  // twice the row groups fit -- and take the from-above term dZ_{l+1} . K_{l+1}^T for all
+  // steps at once from the big GEMM.
+  const int n_rb_all = (B + 15) / 16, nug = W / 16;
+  const bool sequential = h->scan_enabled && h->seq_bwd && L > 1 && L <= KL_SCAN_MAXL && (W == 512 || W == 256 || W == 128) &&
+                          n_rb_all > 512 / (L * nug) && (n_rb_all + 512 / nug - 1) / (512 / nug) <= 4;
+  if (sequential) {
+    for (int l = L - 1; l >= 0; --l) {
+      if (l < L - 1)   // dX_l = dZ_{l+1} . K_{l+1}^T  -> w.dH (free once the layer above has been scanned)
+        KL_TRY(kl_launch_gemm_tn(w.dZ[l + 1], d.Kn[l + 1], w.dH, nullptr, BT, W, 4 * W, 4 * W, 4 * W, W, 0, 1, 1.f, s));
+      KlScanBwd a;
+      memset(&a, 0, sizeof(a));
+      a.B = B; a.T = T; a.W = W; a.L = 1;
+      a.Un[0] = d.Un[l];
+      a.G[0] = w.G[l];
+      a.C[0] = w.C[l];
+      a.dZ[0] = w.dZ[l];
+      a.mask[0] = (masks != nullptr && l > 0) ? masks + (size_t)l * BW : nullptr;
+      a.dH = w.dH;
+      a.counters = w.scan_cnt;
+      a.status = w.scan_status + 1;
+      KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)n_rb_all * T, s));
+      if (l == L - 1) h->trace_begin(1, s);
+      // wide (64-unit) workgroups share the dZ tile through LDS and write dZ^T themselves
+      a.dZT = (BTp == BT && (B & 7) == 0) ? w.dZT : nullptr;
+      a.ldt = BTp;
+      int e = h->wide_bwd ? kl_launch_scan_bwd_wide(a, s) : KL_ERR_SHAPE;
+      const bool wide = e == 0;
+      if (e == KL_ERR_SHAPE) {
+        a.dZT = nullptr;
+        e = kl_launch_scan_bwd(a, s);
+      }
+      if (e != 0) return e;
+      if (l == L - 1) {
+        h->trace_persistent[1] = true;
+        h->trace_flops[1] = (double)B * T * (2.0 * W * 4.0 * W);   // one layer's recurrent contraction
+        h->trace_end(1, s);
+      }
+      // dZ^T lives in ONE buffer: this layer's weight gradients before the next layer's scan
+      KL_TRY(weight_grads(l, wide && a.dZT != nullptr));
+      wg_done[l] = 1;
+    }
+    bscanned = true;
+  }
+  if (!bscanned && h->scan_enabled && L <= KL_SCAN_MAXL) {
     KlScanBwd a;
     memset(&a, 0, sizeof(a));
     a.B = B; a.T = T; a.W = W; a.L = L;
@@ -611,6 +707,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
     if (e == 0) {
       bscanned = true;
       h->trace_persistent[1] = true;
+      h->trace_flops[1] = (double)B * T * (2.0 * (2.0 * L - 1.0) * W * 4.0 * W);
       h->trace_end(1, s);
     } else if (e != KL_ERR_SHAPE) {
       return e;
@@ -661,44 +758,9 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
     }
   }
 
-  // B4/B5: weight gradients, K = B*T contractions over transposed activations
-  for (int l = L - 1; l >= 0; --l) {
-    KL_TRY(kl_launch_transpose_bf16(w.dZ[l], 4 * W, w.dZT, BTp, BT, 4 * W, s));
-    // dU_l = Hprev^T . dZ   (Hprev = H blocks 0..T-1)
-    KL_TRY(kl_launch_transpose_bf16((const bf16_t*)w.H[l], W, w.HT, BTp, BT, W, s));
-    KL_TRY(kl_launch_gemm_tn(w.HT, w.dZT, grads + h->off_U[l], nullptr, W, 4 * W, BTp, BTp, BTp, 4 * W, 2, ksplit, 1.f, s));
-    KL_TRY(kl_launch_colsum_bf16(w.dZ[l], 4 * W, BT, 4 * W, grads + h->off_b[l], s));
-    if (l > 0) {
-      // dK_l = X^T . dZ with X = (masked) outputs of layer l-1
-      const bool masked_in = masks != nullptr && (l - 1) > 0;
-      const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
-      KL_TRY(kl_launch_transpose_bf16(X, W, w.HT, BTp, BT, W, s));
-      KL_TRY(kl_launch_gemm_tn(w.HT, w.dZT, grads + h->off_K[l], nullptr, W, 4 * W, BTp, BTp, BTp, 4 * W, 2, ksplit, 1.f, s));
-    } else {
-      // layer 0 through the look-up tables: dEK^T = dZ^T . OneHot ; dCtxK_n^T likewise
-      KL_TRY(kl_zero_async(w.OHT, (size_t)Vp * BTp * sizeof(bf16_t), s));
-      KL_TRY(kl_launch_onehot_t(idx, B, T, V, 0, 1, w.OHT, BTp, s));
-      KL_TRY(kl_zero_async(w.dEKT, (size_t)4 * W * Vp * sizeof(float), s));
-      KL_TRY(kl_launch_gemm_tn(w.dZT, w.OHT, w.dEKT, nullptr, 4 * W, Vp, BTp, BTp, BTp, Vp, 2, ksplit, 1.f, s));
-      KL_TRY(kl_launch_f32_to_bf16_t(w.dEKT, Vp, 4 * W, Vp, w.dEKT_bf, nullptr, Vp, 0, s));
-      KL_TRY(kl_launch_f32_to_bf16_t(w.dEKT, Vp, 4 * W, Vp, w.dEK_bf, nullptr, 4 * W, 1, s));
-      // dK0[:W] = E^T . dEK      (C[W][4W] = ET[W][Vp] . dEKT[4W][Vp]^T)
-      KL_TRY(kl_launch_gemm_tn(d.ET, w.dEKT_bf, grads + h->off_K[0], nullptr, W, 4 * W, Vp, Vp, Vp, 4 * W, 0, 1, 1.f, s));
-      // dE += dEK . K0[:W]^T     (C[V][W] = dEK[V][4W] . Kn0[W][4W]^T)
-      KL_TRY(kl_launch_gemm_tn(w.dEK_bf, d.Kn[0], grads + h->off_E, nullptr, V, W, 4 * W, 4 * W, 4 * W, W, 2, 1, 1.f, s));
-      for (int n = 0; n < c.n_ctx; ++n) {
-        KL_TRY(kl_zero_async(w.OHC[n], (size_t)c.ctx_vocab * BTp * sizeof(bf16_t), s));
-        KL_TRY(kl_launch_onehot_t(ctx, B, T, c.ctx_vocab, n, c.n_ctx, w.OHC[n], BTp, s));
-        KL_TRY(kl_zero_async(w.dCtxKT[n], (size_t)4 * W * c.ctx_vocab * sizeof(float), s));
-        KL_TRY(kl_launch_gemm_tn(w.dZT, w.OHC[n], w.dCtxKT[n], nullptr, 4 * W, c.ctx_vocab, BTp, BTp, BTp,
-                                 c.ctx_vocab, 2, ksplit, 1.f, s));
-        const size_t krow = (size_t)(W + n * c.ctx_dim) * 4 * W;
-        KL_TRY(kl_launch_ctx_grads(P + h->off_Ctx[n], P + h->off_K[0] + krow, 4 * W, c.ctx_vocab, c.ctx_dim,
-                                   w.dCtxKT[n], c.ctx_vocab, 4 * W, grads + h->off_K[0] + krow, 4 * W,
-                                   grads + h->off_Ctx[n], s));
-      }
-    }
-  }
+  for (int l = L - 1; l >= 0; --l)
+    if (!wg_done[l]) KL_TRY(weight_grads(l, false));
+
   // F7: embedding regularisers (training phase only)
   std::vector<const float*> ctabs(c.n_ctx);
   std::vector<float*> gctabs(c.n_ctx);
@@ -976,7 +1038,8 @@ extern "C" int kl_trace_enable(kl_handle* h, int on) {
 }
 
 // kind 0 = forward cell-step launches, 1 = backward; call after synchronising the stream
-extern "C" int kl_trace_read(kl_handle* h, int kind, int* n_launches, float* total_ms, int* persistent) {
+extern "C" int kl_trace_read(kl_handle* h, int kind, int* n_launches, float* total_ms, int* persistent,
+                             double* flops_per_launch) {
   if (!h || kind < 0 || kind > 1 || !n_launches || !total_ms) return KL_ERR_ARG;
   float total = 0.f;
   int n = 0;
@@ -991,5 +1054,8 @@ extern "C" int kl_trace_read(kl_handle* h, int kind, int* n_launches, float* tot
   *n_launches = h->trace_persistent[kind] ? n : 8 * n;
   *total_ms = total;
   if (persistent) *persistent = h->trace_persistent[kind] ? 1 : 0;
+  // persistent scans report the contractions they actually carry; the step path carries
+  // every layer's cell (recurrent + input contraction above layer 0) for B rows per launch
+  if (flops_per_launch) *flops_per_launch = h->trace_persistent[kind] ? h->trace_flops[kind] : 0.0;
   return 0;
 }

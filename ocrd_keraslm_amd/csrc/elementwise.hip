@@ -415,3 +415,17 @@ int kl_zero_coherent_async(unsigned* p, size_t n_words, hipStream_t stream) {
   hipLaunchKernelGGL(zero_coherent_kernel, dim3((unsigned)g), dim3(256), 0, stream, p, n_words);
   return ok();
 }
+
+namespace {
+__global__ void fill_bf16_kernel(bf16_t* p, size_t n, bf16_t v) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+}  // namespace
+
+int kl_launch_fill_bf16(bf16_t* p, size_t n, unsigned short bits, hipStream_t stream) {
+  long g = (long)((n + 255) / 256);
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(fill_bf16_kernel, dim3((unsigned)g), dim3(256), 0, stream, p, n, (bf16_t)bits);
+  return ok();
+}

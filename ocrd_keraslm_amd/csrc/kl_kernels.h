@@ -95,8 +95,10 @@ struct KlScanBwd {
   const float* mask[KL_SCAN_MAXL];     // dropout mask on the OUTPUT of layer l (null: none)
   unsigned* counters;                  // [L][n_rb][T]
   unsigned* status;
+  bf16_t* dZT; long ldt;               // wide one-layer kernel only: also write dZ transposed [4W][ldt] (null: no)
 };
 int kl_launch_scan_bwd(KlScanBwd args, hipStream_t stream);
+int kl_launch_scan_bwd_wide(KlScanBwd args, hipStream_t stream);   // one layer per launch, 64-unit workgroups
 
 // thin split-precision contraction C[M,N] = A[M,K] . WT[N,K]^T (+bias) for
 // small M (tables, inference logits)
@@ -123,6 +125,7 @@ int kl_launch_regulariser_grads(const float* E, int V, int W, const float* const
 int kl_launch_state_to_rows(const float* states, int B, int W, int L, int layer, bf16_t* h_bf16, float* h_f32,
                             float* c_f32, hipStream_t stream);
 int kl_launch_fill_f32(float* p, size_t n, float v, hipStream_t stream);
+int kl_launch_fill_bf16(bf16_t* p, size_t n, unsigned short bits, hipStream_t stream);
 int kl_zero_async(void* p, size_t bytes, hipStream_t stream);               // kernel-based memset(0)
 int kl_zero_coherent_async(unsigned* p, size_t n_words, hipStream_t stream);  // write-through zero of polled words
 

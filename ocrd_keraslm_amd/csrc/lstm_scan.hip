@@ -45,7 +45,7 @@ constexpr unsigned SPIN_LIMIT = 1u << 20;
 
 // diagnostic build only (-DKL_STAMP): cycle shares of the forward scan's step phases
 #ifdef KL_STAMP
-__device__ unsigned long long kl_scan_stamps[16];
+__device__ unsigned long long kl_scan_stamps[32];   // [0,16) forward scan, [16,32) backward scan
 #define SSTAMP(i)                                                                     \
   do {                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                \
@@ -325,6 +325,10 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
   unsigned* cnt_own = a.counters + (long)l * n_rb * T;
   unsigned* cnt_up = a.counters + (long)(has_up ? l + 1 : l) * n_rb * T;
   bool alive = true;
+#ifdef KL_STAMP
+  const int STAMP_WG = 0;     // top layer when layers are scanned one by one (L = 1 view)
+  unsigned long long last_ = clock64();
+#endif
 
   for (int t = T - 1; t >= 0; --t) {
 #pragma unroll
@@ -333,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
       if (rb >= n_rb) continue;
       const int r0 = rb * 16;
       const int erow = min(r0 + er, B - 1);
+      SSTAMP(16);
       // epilogue operands (written by earlier launches: plain loads), issued before the wait
       const bf16_t* gp = Gl + ((long)t * B + erow) * 4 * W + u0 + eu;
       const bf16_t g0 = gp[0], g1 = gp[W], g2 = gp[2 * W], g3 = gp[3 * W];
@@ -357,7 +362,9 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
         if (ok && t < T - 1) ok = poll_counter(cnt_own + (long)rb * T + (t + 1), NUG, status);
         ok_flag = ok ? 1 : 0;
       }
+      SSTAMP(17);
       __syncthreads();
+      SSTAMP(18);
       alive = ok_flag != 0;
       const int arow = min(r0 + (lane & 15), B - 1);
       f32x4 acc_up = f32x4{0.f, 0.f, 0.f, 0.f}, acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -389,7 +396,9 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) zt[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r] + acc_up[r] * omask[r];
+      SSTAMP(19);
       __syncthreads();
+      SSTAMP(20);
       dh += zt[0][er][eu] + zt[1][er][eu] + zt[2][er][eu] + zt[3][er][eu];
       const float gi = bf2f(g0), gf = bf2f(g1), gg = bf2f(g2), go = bf2f(g3);
       const float tc = fast_tanh(c);
@@ -399,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
       const unsigned z0 = f2bf(d_i * gi * (1.f - gi)), z1 = f2bf(d_f * gf * (1.f - gf));
       const unsigned z2 = f2bf(d_g * (1.f - gg * gg)), z3 = f2bf(d_o * go * (1.f - go));
       const unsigned n0 = __shfl_xor(z0, 1), n1 = __shfl_xor(z1, 1), n2 = __shfl_xor(z2, 1), n3 = __shfl_xor(z3, 1);
+      SSTAMP(21);
       if ((r0 + er) < B && alive && (eu & 1) == 0) {
         unsigned* zp = reinterpret_cast<unsigned*>(dZl + ((long)t * B + r0 + er) * 4 * W + u0 + eu);
         __hip_atomic_store(zp, z0 | (n0 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -406,9 +416,150 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
         __hip_atomic_store(zp + W, z2 | (n2 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(zp + 3 * W / 2, z3 | (n3 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      SSTAMP(22);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      SSTAMP(23);
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(cnt_own + (long)rb * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      SSTAMP(24);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward scan, one layer, wide workgroups
+// For many row blocks the thin kernel above is bound by fabric traffic: W/16 workgroups
+// per row block each pull the same 16 x 4W dZ tile with write-through reads (stamps:
+// 46 % of a step).  Here a workgroup is 16 waves = 4 K-quarters x 4 unit groups = 64
+// hidden units, the tile is fetched ONCE per workgroup (each wave 1/16 of it) into LDS
+// and shared, so only W/64 workgroups read it.  One layer per launch (recurrent
+// contraction only; the from-above term arrives in dH from the big GEMM).  The step's
+// dZ tile is also written transposed ([4W][T*B], plain stores after the publish) for the
+// weight-gradient GEMMs, which saves the separate transpose pass.
+template <int KSTEPS, int MAXRB>
+__global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlScanBwd a) {
+  constexpr int W = KSTEPS * 32;
+  constexpr int NWG_RB = W / 64;          // producers per (row block, step)
+  constexpr int JW = KSTEPS / 4;          // k-steps of a quarter that one wave fetches
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq4 = wave & 3, ug = wave >> 2;
+  const int n_rg = a.n_rg, n_rb = a.n_rb, B = a.B, T = a.T;
+  const int cg = blockIdx.x / n_rg, rg = blockIdx.x % n_rg;
+  const int u0 = cg * 64;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* a_tile = smem;                                           // [4 quarters][KSTEPS][1 KiB]
+  float (*zt)[16][17] = reinterpret_cast<float (*)[16][17]>(smem + 4 * KSTEPS * 1024);   // [16 waves][16][17]
+  bf16_t* tr = reinterpret_cast<bf16_t*>(smem + 4 * KSTEPS * 1024 + 16 * 16 * 17 * 4);   // [4 gates][64 units][16 rows]
+  // (all LDS in the dynamic region: a static object in front would shift its 16-byte alignment)
+  int& ok_flag = *reinterpret_cast<int*>(smem + 4 * KSTEPS * 1024 + 16 * 16 * 17 * 4 + 4 * 64 * 16 * 2);
+
+  const int kq = (lane >> 4) * 8;
+  uint4 bu[KSTEPS];
+  {
+    const long wrow = (long)(u0 + ug * 16 + (lane & 15)) * 4 * W + (long)kq4 * W;
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j) bu[j] = *reinterpret_cast<const uint4*>(a.Un[0] + wrow + j * 32 + kq);
+  }
+  const int er = tid >> 6, eu = tid & 63;          // epilogue thread = (row, unit of 64)
+  float dc_reg[MAXRB];
+#pragma unroll
+  for (int i = 0; i < MAXRB; ++i) dc_reg[i] = 0.f;
+  const long BW = (long)B * W;
+  const bf16_t* Gl = a.G[0];
+  const float* Cl = a.C[0];
+  bf16_t* dZl = a.dZ[0];
+  bf16_t* dZT = a.dZT;
+  const long ldt = a.ldt;
+  const float* dH = a.dH;
+  const float* maskl = a.mask[0];
+  unsigned* status = a.status;
+  const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(dZl, (long)T * BW * 4 * 2);
+  unsigned* cnt_own = a.counters;
+  bool alive = true;
+
+  for (int t = T - 1; t >= 0; --t) {
+#pragma unroll
+    for (int i = 0; i < MAXRB; ++i) {
+      const int rb = rg + i * n_rg;
+      if (rb >= n_rb) continue;
+      const int r0 = rb * 16;
+      const int erow = min(r0 + er, B - 1);
+      const bf16_t* gp = Gl + ((long)t * B + erow) * 4 * W + u0 + eu;
+      const bf16_t g0 = gp[0], g1 = gp[W], g2 = gp[2 * W], g3 = gp[3 * W];
+      const float c = Cl[((long)(t + 1) * B + erow) * W + u0 + eu];
+      const float cp = Cl[((long)t * B + erow) * W + u0 + eu];
+      float dh = dH[((long)t * B + erow) * W + u0 + eu];
+      if (maskl) dh *= maskl[(long)erow * W + u0 + eu];
+      if (tid == 0) {
+        bool ok = alive;
+        if (ok && t < T - 1) ok = poll_counter(cnt_own + (long)rb * T + (t + 1), NWG_RB, status);
+        ok_flag = ok ? 1 : 0;
+      }
+      __syncthreads();
+      alive = ok_flag != 0;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < T - 1) {
+        // fetch 1/16 of the 16 x 4W tile of dZ[t+1]: quarter kq4, k-steps ug*JW .. +JW
+        const int arow = min(r0 + (lane & 15), B - 1);
+        const unsigned base = (unsigned)((((long)(t + 1) * B + arow) * 4 * W + (long)kq4 * W + kq) * 2);
+        uint4 av[JW];
+#pragma unroll
+        for (int j = 0; j < JW; ++j) av[j] = alive ? load16_sc1(rs_own, base + (ug * JW + j) * 64) : uint4{0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < JW; ++j)
+          *reinterpret_cast<uint4*>(a_tile + ((kq4 * KSTEPS) + ug * JW + j) * 1024 + lane * 16) = av[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KSTEPS; ++j) {
+          frag16 fa, fb;
+          fa.u = *reinterpret_cast<const uint4*>(a_tile + (kq4 * KSTEPS + j) * 1024 + lane * 16);
+          fb.u = bu[j];
+          acc = mfma16(fa.v, fb.v, acc);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zt[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+      __syncthreads();
+      const int wz = (eu >> 4) * 4;      // the four K-quarter waves of this unit group
+      dh += zt[wz][er][eu & 15] + zt[wz + 1][er][eu & 15] + zt[wz + 2][er][eu & 15] + zt[wz + 3][er][eu & 15];
+      const float gi = bf2f(g0), gf = bf2f(g1), gg = bf2f(g2), go = bf2f(g3);
+      const float tc = fast_tanh(c);
+      const float dc = dh * go * (1.f - tc * tc) + dc_reg[i];
+      dc_reg[i] = dc * gf;
+      const float d_o = dh * tc, d_i = dc * gg, d_g = dc * gi, d_f = dc * cp;
+      const unsigned z0 = f2bf(d_i * gi * (1.f - gi)), z1 = f2bf(d_f * gf * (1.f - gf));
+      const unsigned z2 = f2bf(d_g * (1.f - gg * gg)), z3 = f2bf(d_o * go * (1.f - go));
+      const unsigned n0 = __shfl_xor(z0, 1), n1 = __shfl_xor(z1, 1), n2 = __shfl_xor(z2, 1), n3 = __shfl_xor(z3, 1);
+      const bool row_ok = (r0 + er) < B;
+      if (row_ok && alive && (eu & 1) == 0) {
+        unsigned* zp = reinterpret_cast<unsigned*>(dZl + ((long)t * B + r0 + er) * 4 * W + u0 + eu);
+        __hip_atomic_store(zp, z0 | (n0 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(zp + W / 2, z1 | (n1 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(zp + W, z2 | (n2 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(zp + 3 * W / 2, z3 | (n3 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (dZT) {   // stage the tile transposed for the off-chain copy below
+        tr[(0 * 64 + eu) * 16 + er] = row_ok ? (bf16_t)z0 : (bf16_t)0;
+        tr[(1 * 64 + eu) * 16 + er] = row_ok ? (bf16_t)z1 : (bf16_t)0;
+        tr[(2 * 64 + eu) * 16 + er] = row_ok ? (bf16_t)z2 : (bf16_t)0;
+        tr[(3 * 64 + eu) * 16 + er] = row_ok ? (bf16_t)z3 : (bf16_t)0;
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(cnt_own + (long)rb * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (dZT && alive && tid < 512) {
+        // 256 columns (gate, unit) x 16 rows: two 16-byte stores per column
+        const int col = tid >> 1, half = tid & 1;
+        const int g = col >> 6, u = col & 63;
+        const long trow = (long)g * W + u0 + u;
+        const long tcol = (long)t * B + r0 + half * 8;
+        if (r0 + half * 8 + 8 <= B || (B & 7) == 0) {
+          if (r0 + half * 8 < B)
+            *reinterpret_cast<uint4*>(dZT + trow * ldt + tcol) = *reinterpret_cast<const uint4*>(tr + col * 16 + half * 8);
+        } else {
+          for (int q = 0; q < 8 && r0 + half * 8 + q < B; ++q) dZT[trow * ldt + tcol + q] = tr[col * 16 + half * 8 + q];
+        }
+      }
     }
   }
 }
@@ -485,9 +636,35 @@ int kl_launch_scan_bwd(KlScanBwd a, hipStream_t stream) {
 #ifdef KL_STAMP
 extern "C" int kl_test_scan_stamps(unsigned long long* out, int reset) {
   if (reset) {
-    unsigned long long z[16] = {0};
+    unsigned long long z[32] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(kl_scan_stamps), z, sizeof(z)) == hipSuccess ? 0 : KL_ERR_LAUNCH;
   }
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(kl_scan_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : KL_ERR_LAUNCH;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(kl_scan_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 #endif
+
+// One-layer backward scan with 64-unit workgroups (a.L must be 1).  KL_ERR_SHAPE = not applicable.
+int kl_launch_scan_bwd_wide(KlScanBwd a, hipStream_t stream) {
+  const int W = a.W;
+  if (a.L != 1 || (W != 512 && W != 256) || a.B < 1 || a.T < 1) return KL_ERR_SHAPE;
+  if (a.dZT && ((a.ldt & 7) || (a.B & 7))) return KL_ERR_SHAPE;
+  a.n_rb = (a.B + 15) / 16;
+  const int col_groups = W / 64;
+  int g = 256 / col_groups;            // one 1024-thread workgroup per CU
+  if (g > a.n_rb) g = a.n_rb;
+  a.n_rg = g;
+  const int per_wg = (a.n_rb + g - 1) / g;
+  if (per_wg > 4) return KL_ERR_SHAPE;
+  dim3 grid(col_groups * g), block(1024);
+  const size_t lds = (size_t)4 * (W / 32) * 1024 + 16 * 16 * 17 * 4 + 4 * 64 * 16 * 2 + 16;
+#define KL_WIDE_CASE(KS, RB)                                                                                         \
+  do {                                                                                                               \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_bwd_wide_kernel<KS, RB>),                     \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH; \
+    hipLaunchKernelGGL((lstm_scan_bwd_wide_kernel<KS, RB>), grid, block, lds, stream, a);                            \
+  } while (0)
+  if (W == 512) { if (per_wg == 1) KL_WIDE_CASE(16, 1); else if (per_wg == 2) KL_WIDE_CASE(16, 2); else KL_WIDE_CASE(16, 4); }
+  else { if (per_wg == 1) KL_WIDE_CASE(8, 1); else if (per_wg == 2) KL_WIDE_CASE(8, 2); else KL_WIDE_CASE(8, 4); }
+#undef KL_WIDE_CASE
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}

@@ -50,7 +50,8 @@ SIGNATURES = {
     "kl_state_dist2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                  C.c_void_p]),
     "kl_trace_enable": (C.c_int, [C.c_void_p, C.c_int]),
-    "kl_trace_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "kl_trace_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int),
+                                C.POINTER(C.c_double)]),
     "kl_test_gemm_tn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_long, C.c_long, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     "kl_test_thin_gemm": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int,

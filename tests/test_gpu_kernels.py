@@ -188,7 +188,10 @@ def test_forward_window_parity(depth, width, voc, B, T, n_ctx):
                                                                  # shapes served by the persistent scans (W in 128/256/512)
                                                                  (2, 128, 70, 40, 12, 1, True), (3, 128, 30, 20, 6, 2, True),
                                                                  (1, 256, 40, 5, 9, 1, False), (2, 512, 64, 100, 6, 1, True),
-                                                                 (2, 512, 256, 64, 16, 1, True)])
+                                                                 (2, 512, 256, 64, 16, 1, True),
+                                                                 # many row blocks: layer-sequential backward with wide workgroups
+                                                                 (2, 512, 64, 144, 6, 1, True), (2, 256, 40, 272, 4, 1, True),
+                                                                 (3, 256, 30, 176, 5, 1, True)])
 def test_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks):
     """B1-B7 + F7: gradients of mean CE + regularisers vs the f64 oracle.  The HIP
     path computes in bf16 with f32 accumulation: relative error of each gradient
@@ -251,7 +254,7 @@ def test_adam_step_matches_oracle():
         assert np.abs(got[k] - wo[k]).max() < 1e-6, k
 
 
-@pytest.mark.parametrize("depth,width,voc,B,T", [(2, 128, 50, 20, 12), (2, 512, 64, 40, 8)])
+@pytest.mark.parametrize("depth,width,voc,B,T", [(2, 128, 50, 20, 12), (2, 512, 64, 40, 8), (2, 512, 64, 144, 5)])
 def test_train_consecutive_windows_reuse_buffers(depth, width, voc, B, T):
     """The persistent scans hand data between workgroups through buffers that are
     re-used by every window: three consecutive windows (carried state, fresh inputs)

@@ -29,11 +29,17 @@ n = 5
 for _ in range(n):
     lm.train_window(idx, ctx, idx, None)
 torch.cuda.synchronize()
-st = (C.c_ulonglong * 16)()
+st = (C.c_ulonglong * 32)()
 lib.kl_test_scan_stamps(st, 0)
 v = np.array(list(st)[:11], dtype=np.float64) / (n * T)
 names = ['loop top', 'poll', 'barrier1', 'A load+LDS write', 'barrier2', 'MFMA+zt write', 'barrier3', 'gate math',
          'stores issue', 'vmcnt(0)', 'barrier4+atomic']
-print(f"B={B}: cycles per time step of the last workgroup (top layer); total {v.sum():.0f}")
+print(f"B={B}: forward scan, cycles per time step of the last workgroup (top layer); total {v.sum():.0f}")
 for nm, x in zip(names, v):
     print(f"  {nm:18s} {x:8.0f}")
+vb = np.array(list(st)[16:25], dtype=np.float64) / (n * T)
+bnames = ['loop top (plain loads)', 'poll', 'barrier1', 'sc1 loads + MFMA + zt', 'barrier2', 'gate math', 'stores issue',
+          'vmcnt(0)', 'barrier3+atomic']
+print(f"B={B}: backward scan, workgroup 0; total {vb.sum():.0f}")
+for nm, x in zip(bnames, vb):
+    print(f"  {nm:24s} {x:8.0f}")
