@@ -62,8 +62,11 @@ struct WindowWs {
   int *s_idx, *s_ctx, *s_tgt;  // staged inputs (fixed addresses for graph replay)
   float *s_masks, *s_probs;
   unsigned *scan_cnt, *scan_status;   // persistent-scan hand-off counters [L][ceil(B/16)][T], status words [2]
+  float* reg_scratch;                 // statistics of the embedding regularisers
   // training only
   std::vector<bf16_t*> G, dZ, Hd;
+  std::vector<bf16_t*> HTf, HdT;      // transposed outputs written by the wide forward scans: [W][(T+1)B], [W][BT]
+  bool ht_ready = false;              // ... valid for this window
   bf16_t *dZT, *HT, *dlogits, *dlogitsT, *OHT, *dEKT_bf, *dEK_bf;
   std::vector<bf16_t*> OHC;
   float *dH, *dEKT;
@@ -97,6 +100,7 @@ struct kl_handle {
   bool scan_enabled = true;     // persistent scans (KL_SCAN=0 forces the launch-per-step path)
   bool seq_bwd = true;          // layer-sequential backward scans for many row blocks (KL_SEQ_BWD=0: always fused)
   bool wide_bwd = true;         // ... with 64-unit workgroups (KL_WIDE_BWD=0: thin workgroups)
+  int wide_fwd_min = 256;       // layer-sequential wide forward scans from this many 64-unit workgroups (KL_WIDE_FWD_MIN; 0 = never)
   double trace_flops[2] = {0.0, 0.0};   // algorithmic FLOPs of ONE timed launch
   // optional per-launch timing of the cell-step kernels with HIP events (bench.py's
   // roofline leg).  While tracing, windows run eagerly (events are not captured).
@@ -218,6 +222,7 @@ size_t carve_window(const kl_handle* h, void* base, int B, int T, int training, 
   o.s_probs = cv.take<float>(training ? 1 : BT * V);
   o.scan_cnt = cv.take<unsigned>(L * ((size_t)(B + 15) / 16) * T);
   o.scan_status = cv.take<unsigned>(4);
+  o.reg_scratch = cv.take<float>(3 * (W > (size_t)c.ctx_dim ? W : (size_t)c.ctx_dim) + (V > (size_t)c.ctx_vocab ? V : (size_t)c.ctx_vocab) + 8);
   if (training) {
     o.G.assign(L, nullptr); o.dZ.assign(L, nullptr); o.Hd.assign(L, nullptr);
     o.dc0.assign(L, nullptr); o.dc1.assign(L, nullptr);
@@ -229,7 +234,14 @@ size_t carve_window(const kl_handle* h, void* base, int B, int T, int training, 
       o.dc1[l] = cv.take<float>((size_t)B * W);
     }
     o.dZT = cv.take<bf16_t>(4 * W * BTp);
-    o.HT = cv.take<bf16_t>((W + 1) * BTp);
+    o.HT = cv.take<bf16_t>(W * BTp);
+    o.HTf.assign(L, nullptr); o.HdT.assign(L, nullptr);
+    if ((B & 7) == 0) {
+      for (size_t l = 0; l < L; ++l) {
+        o.HTf[l] = cv.take<bf16_t>(W * (BT + B));
+        o.HdT[l] = l > 0 ? cv.take<bf16_t>(W * BT) : nullptr;
+      }
+    }
     o.dlogits = cv.take<bf16_t>(BT * Vp);
     o.dlogitsT = cv.take<bf16_t>(Vp * BTp);
     o.OHT = cv.take<bf16_t>(Vp * BTp);
@@ -318,16 +330,62 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
   const int split = training ? 1 : h->precision;
   std::vector<const float*> ctxk(c.n_ctx);
   for (int n = 0; n < c.n_ctx; ++n) ctxk[n] = d.CtxK[n];
-  KL_TRY(kl_launch_p1_gather(d.EK, ctxk.data(), c.n_ctx, P + h->off_b[0], idx, ctx, B, T, 4 * W, w.P1, s));
   for (int l = 0; l < L; ++l)
     KL_TRY(kl_launch_state_to_rows(states, B, W, L, l, training ? (bf16_t*)w.H[l] : nullptr,
                                    training ? nullptr : (float*)w.H[l], w.C[l], s));
   auto hrow = [&](int l, int block) -> const void* {
     return training ? (const void*)((bf16_t*)w.H[l] + (size_t)block * BW) : (const void*)((float*)w.H[l] + (size_t)block * BW);
   };
-  // persistent scan (one launch for all layers and steps) where the shape allows it
   bool scanned = false;
-  if (training && h->scan_enabled && L <= KL_SCAN_MAXL) {
+  // Many streams (B >= 512 at cfg2): one layer per launch with 64-unit workgroups.  The
+  // input contraction of layers >= 1 comes from one big GEMM over all steps, layer 0
+  // reads the look-up tables directly, and the scans also leave H^T for the weight gradients.
+  const int n_rb = (B + 15) / 16;
+  w.ht_ready = false;
+  if (training && h->scan_enabled && h->wide_fwd_min > 0 && (W == 512 || W == 256) && (B & 7) == 0 &&
+      n_rb * (W / 64) >= h->wide_fwd_min && n_rb <= 4 * (256 / (W / 64))) {
+    for (int l = 0; l < L; ++l) {
+      KL_TRY(kl_launch_transpose_bf16((const bf16_t*)w.H[l], W, w.HTf[l], (long)(T + 1) * B, B, W, s));
+      const bool masked = masks != nullptr && l > 0;
+      KlScanFwdWide a;
+      memset(&a, 0, sizeof(a));
+      a.B = B; a.T = T; a.W = W;
+      a.UT = d.UT_hi[l];
+      if (l > 0) {
+        const bool masked_in = masks != nullptr && (l - 1) > 0;
+        const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
+        KL_TRY(kl_launch_gemm_tn(X, d.KT_hi[l], w.P1, P + h->off_b[l], B * T, 4 * W, W, W, W, 4 * W, 0, 1, 1.f, s));
+        a.P = w.P1;
+      } else {
+        a.EK = d.EK;
+        for (int n = 0; n < c.n_ctx; ++n) a.CtxK[n] = d.CtxK[n];
+        a.n_ctx = c.n_ctx;
+        a.idx = idx; a.ctx = ctx;
+        a.bias = P + h->off_b[0];
+      }
+      a.H = (bf16_t*)w.H[l]; a.C = w.C[l]; a.G = w.G[l];
+      a.Hd = masked ? w.Hd[l] : nullptr;
+      a.mask = masked ? masks + (size_t)l * BW : nullptr;
+      a.HT = w.HTf[l]; a.ldt = (long)(T + 1) * B;
+      a.HdT = masked ? w.HdT[l] : nullptr; a.ldt_d = (long)B * T;
+      a.counters = w.scan_cnt;
+      a.status = w.scan_status;
+      KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)n_rb * T, s));
+      if (l == L - 1) h->trace_begin(0, s);
+      KL_TRY(kl_launch_scan_fwd_wide(a, s));
+      if (l == L - 1) {
+        h->trace_persistent[0] = true;
+        h->trace_flops[0] = (double)B * T * (2.0 * W * 4.0 * W);   // one layer's recurrent contraction
+        h->trace_end(0, s);
+      }
+    }
+    scanned = true;
+    w.ht_ready = true;
+  }
+  if (!scanned)
+    KL_TRY(kl_launch_p1_gather(d.EK, ctxk.data(), c.n_ctx, P + h->off_b[0], idx, ctx, B, T, 4 * W, w.P1, s));
+  // persistent scan (one launch for all layers and steps) where the shape allows it
+  if (!scanned && training && h->scan_enabled && L <= KL_SCAN_MAXL) {
     KlScanFwd a;
     memset(&a, 0, sizeof(a));
     a.B = B; a.T = T; a.W = W; a.L = L;
@@ -519,6 +577,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->seq_bwd = !(env3 && env3[0] == '0');
   const char* env4 = getenv("KL_WIDE_BWD");
   h->wide_bwd = !(env4 && env4[0] == '0');
+  const char* env5 = getenv("KL_WIDE_FWD_MIN");
+  if (env5) h->wide_fwd_min = atoi(env5);
   return kl_zero_page_ready();
 }
 
@@ -577,8 +637,6 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
 
   KL_TRY(kl_zero_async(grads, h->n_params * sizeof(float), s));
   KL_TRY(kl_zero_async(w.scan_status, 4 * sizeof(unsigned), s));
-  if (BTp != BT) KL_TRY(kl_launch_fill_bf16(w.HT + (size_t)W * BTp, BTp, 0, s));
-  KL_TRY(kl_launch_fill_bf16(w.HT + (size_t)W * BTp, BT, 0x3F80, s));   // ones row of HT (bias gradients)
   KL_TRY(forward_impl(h, B, T, idx, ctx, states, masks, 1, w, s));
 
   // F5/F6: logits over the (masked) top-layer outputs, softmax, CE, dlogits
@@ -594,25 +652,40 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
     KL_TRY(kl_zero_async(w.dZT, (size_t)4 * W * BTp * sizeof(bf16_t), s));
   }
   KL_TRY(kl_launch_transpose_bf16(w.dlogits, Vp, w.dlogitsT, BTp, BT, Vp, s));
-  KL_TRY(kl_launch_transpose_bf16(Htop, W, w.HT, BTp, BT, W, s));
-  KL_TRY(kl_launch_gemm_tn(w.dlogitsT, w.HT, grads + h->off_E, nullptr, V, W, BTp, BTp, BTp, W, 2, ksplit, 1.f, s));
+  const long ldtf = (long)(T + 1) * B;
+  if (w.ht_ready) {
+    const bf16_t* HtopT = top_masked ? w.HdT[L - 1] : w.HTf[L - 1] + B;
+    KL_TRY(kl_launch_gemm_tn(w.dlogitsT, HtopT, grads + h->off_E, nullptr, V, W, BT, BTp, top_masked ? (long)BT : ldtf, W, 2, ksplit, 1.f, s));
+  } else {
+    KL_TRY(kl_launch_transpose_bf16(Htop, W, w.HT, BTp, BT, W, s));
+    KL_TRY(kl_launch_gemm_tn(w.dlogitsT, w.HT, grads + h->off_E, nullptr, V, W, BTp, BTp, BTp, W, 2, ksplit, 1.f, s));
+  }
 
   // B3: reverse recurrence -- persistent scan where the shape allows it, else the
   // launch-per-step layer wavefront
   std::vector<char> wg_done(L, 0);
   // B4/B5: weight gradients of one layer, K = B*T contractions over transposed activations
-  auto weight_grads = [&](int l, bool dzt_ready) -> int {
+  auto weight_grads = [&](int l, bool dzt_ready, bool db_done) -> int {
     if (!dzt_ready) KL_TRY(kl_launch_transpose_bf16(w.dZ[l], 4 * W, w.dZT, BTp, BT, 4 * W, s));
     // dU_l = Hprev^T . dZ   (Hprev = H blocks 0..T-1)
-    KL_TRY(kl_launch_transpose_bf16((const bf16_t*)w.H[l], W, w.HT, BTp, BT, W, s));
-    // row W of HT is all ones, and b_l follows U_l in the parameter layout: the same GEMM yields db_l = sum dZ
-    KL_TRY(kl_launch_gemm_tn(w.HT, w.dZT, grads + h->off_U[l], nullptr, W + 1, 4 * W, BTp, BTp, BTp, 4 * W, 2, ksplit, 1.f, s));
+    if (w.ht_ready) {
+      KL_TRY(kl_launch_gemm_tn(w.HTf[l], w.dZT, grads + h->off_U[l], nullptr, W, 4 * W, BT, ldtf, BTp, 4 * W, 2, ksplit, 1.f, s));
+    } else {
+      KL_TRY(kl_launch_transpose_bf16((const bf16_t*)w.H[l], W, w.HT, BTp, BT, W, s));
+      KL_TRY(kl_launch_gemm_tn(w.HT, w.dZT, grads + h->off_U[l], nullptr, W, 4 * W, BTp, BTp, BTp, 4 * W, 2, ksplit, 1.f, s));
+    }
+    if (!db_done) KL_TRY(kl_launch_colsum_bf16(w.dZ[l], 4 * W, BT, 4 * W, grads + h->off_b[l], s));   // (the wide backward scan sums db itself)
     if (l > 0) {
       // dK_l = X^T . dZ with X = (masked) outputs of layer l-1
       const bool masked_in = masks != nullptr && (l - 1) > 0;
       const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
-      KL_TRY(kl_launch_transpose_bf16(X, W, w.HT, BTp, BT, W, s));
-      KL_TRY(kl_launch_gemm_tn(w.HT, w.dZT, grads + h->off_K[l], nullptr, W, 4 * W, BTp, BTp, BTp, 4 * W, 2, ksplit, 1.f, s));
+      if (w.ht_ready) {
+        const bf16_t* XT = masked_in ? w.HdT[l - 1] : w.HTf[l - 1] + B;
+        KL_TRY(kl_launch_gemm_tn(XT, w.dZT, grads + h->off_K[l], nullptr, W, 4 * W, BT, masked_in ? (long)BT : ldtf, BTp, 4 * W, 2, ksplit, 1.f, s));
+      } else {
+        KL_TRY(kl_launch_transpose_bf16(X, W, w.HT, BTp, BT, W, s));
+        KL_TRY(kl_launch_gemm_tn(w.HT, w.dZT, grads + h->off_K[l], nullptr, W, 4 * W, BTp, BTp, BTp, 4 * W, 2, ksplit, 1.f, s));
+      }
     } else {
       // layer 0 through the look-up tables: dEK^T = dZ^T . OneHot ; dCtxK_n^T likewise
       KL_TRY(kl_zero_async(w.OHT, (size_t)Vp * BTp * sizeof(bf16_t), s));
@@ -668,10 +741,12 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       // wide (64-unit) workgroups share the dZ tile through LDS and write dZ^T themselves
       a.dZT = (BTp == BT && (B & 7) == 0) ? w.dZT : nullptr;
       a.ldt = BTp;
+      a.db = grads + h->off_b[l];
       int e = h->wide_bwd ? kl_launch_scan_bwd_wide(a, s) : KL_ERR_SHAPE;
       const bool wide = e == 0;
       if (e == KL_ERR_SHAPE) {
         a.dZT = nullptr;
+        a.db = nullptr;
         e = kl_launch_scan_bwd(a, s);
       }
       if (e != 0) return e;
@@ -681,7 +756,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
         h->trace_end(1, s);
       }
       // dZ^T lives in ONE buffer: this layer's weight gradients before the next layer's scan
-      KL_TRY(weight_grads(l, wide && a.dZT != nullptr));
+      KL_TRY(weight_grads(l, wide && a.dZT != nullptr, wide));
       wg_done[l] = 1;
     }
     bscanned = true;
@@ -759,14 +834,14 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   }
 
   for (int l = L - 1; l >= 0; --l)
-    if (!wg_done[l]) KL_TRY(weight_grads(l, false));
+    if (!wg_done[l]) KL_TRY(weight_grads(l, false, false));
 
   // F7: embedding regularisers (training phase only)
   std::vector<const float*> ctabs(c.n_ctx);
   std::vector<float*> gctabs(c.n_ctx);
   for (int n = 0; n < c.n_ctx; ++n) { ctabs[n] = P + h->off_Ctx[n]; gctabs[n] = grads + h->off_Ctx[n]; }
   KL_TRY(kl_launch_regulariser_grads(P + h->off_E, V, W, ctabs.data(), c.n_ctx, c.ctx_vocab, c.ctx_dim,
-                                     grads + h->off_E, gctabs.data(), loss_acc, s));
+                                     grads + h->off_E, gctabs.data(), loss_acc, w.reg_scratch, s));
   // a timed-out hand-off in a persistent scan surfaces as loss_acc[3] != 0
   hipLaunchKernelGGL(scan_status_kernel, dim3(1), dim3(64), 0, s, w.scan_status, loss_acc);
   return hip_ok(hipGetLastError());

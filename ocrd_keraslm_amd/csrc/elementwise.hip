@@ -191,75 +191,87 @@ __global__ void onehot_t_kernel(const int* __restrict__ ids, int B, int T, int n
 
 // ---- embedding regularisers: gradient (+=) and value ------------------------------
 // mode 0 = chars (rating.py:222-246), mode 1 = contexts (rating.py:187-220).
-// Single block; the tables are tiny ([V,W], [200,10]).
-__global__ void reg_table_kernel(const float* __restrict__ X, int R, int D, float* __restrict__ gX, int mode,
-                                 float* __restrict__ loss_acc) {
+// Two launches per table: table statistics (one block: column means / partial column
+// sums / row norms into a scratch vector), then an elementwise multi-block pass that
+// applies the gradient and reduces the loss value.
+//   scratch = [mean D | s1 D | s2 D | nr R | N1 N2]
+__global__ void reg_stats_kernel(const float* __restrict__ X, int R, int D, float* __restrict__ scratch) {
   extern __shared__ float sm[];
-  float* mean = sm;            // [D] mean over rows 1..R-1
-  float* s1 = sm + D;          // [D] sum rows 1..R-2
-  float* s2 = sm + 2 * D;      // [D] sum rows 2..R-1
-  float* nr = sm + 3 * D;      // [R] squared norms
-  float* red = nr + R;         // [blockDim] scratch
+  float* col = sm;             // [D] sum over rows 1..R-1
+  float* red = sm + D;         // [2][blockDim]
   const int tid = threadIdx.x, nt = blockDim.x;
-  if (R < 2) return;
-  // column sums over rows 1..R-1: independent strided loads + LDS atomics (a per-column
-  // serial loop here was a chain of R dependent L2 round trips: ~90 us for E)
-  for (int d = tid; d < D; d += nt) mean[d] = 0.f;
+  float* mean = scratch;
+  float* s1 = scratch + D;
+  float* s2 = scratch + 2 * D;
+  float* nr = scratch + 3 * D;
+  for (int d = tid; d < D; d += nt) col[d] = 0.f;
   __syncthreads();
-  for (long e = (long)D + tid; e < (long)R * D; e += nt) atomicAdd(&mean[e % D], X[e]);
-  __syncthreads();
-  for (int d = tid; d < D; d += nt) {
-    const float a = mean[d];
-    s1[d] = a - X[(long)(R - 1) * D + d];
-    s2[d] = a - X[(long)1 * D + d];
-  }
-  __syncthreads();
-  for (int d = tid; d < D; d += nt) mean[d] = mean[d] / (float)(R - 1);
+  for (long e = (long)D + tid; e < (long)R * D; e += nt) atomicAdd(&col[e % D], X[e]);
+  float n1 = 0.f, n2 = 0.f;
   for (int r = tid >> 6; r < R; r += nt >> 6) {
     float a = 0.f;
     for (int d = tid & 63; d < D; d += 64) { const float x = X[(long)r * D + d]; a += x * x; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-    if ((tid & 63) == 0) nr[r] = a;
-  }
-  __syncthreads();
-  const float c_low = mode == 0 ? 0.01f : 0.02f;
-  float loss = 0.f;
-  // low-rank term on every row
-  for (long e = tid; e < (long)R * D; e += nt) {
-    const int r = (int)(e / D);
-    gX[e] += -4.f * c_low * (1.f - nr[r]) * X[e];
-  }
-  for (int r = tid; r < R; r += nt) { const float q = 1.f - nr[r]; loss += c_low * q * q; }
-  __syncthreads();
-  if (mode == 0) {
-    for (int d = tid; d < D; d += nt) {
-      const float q = X[d] - mean[d];
-      gX[d] += 2.f * q;
-      loss += q * q;
-    }
-  } else {
-    // smoothness: 0.2 * sum_d s1[d]*s2[d]; gradient 0.2*s1 on rows 2..R-1
-    for (long e = tid + 2L * D; e < (long)R * D; e += nt) gX[e] += 0.2f * s1[e % D];
-    __syncthreads();
-    for (int d = tid; d < D; d += nt) loss += 0.2f * s1[d] * s2[d];
-    // underspecification: 2 * sum_{r>=1} sum_d (C0d - n_r m_d)^2
-    float N1 = 0.f, N2 = 0.f;
-    for (int r = 1; r < R; ++r) { N1 += nr[r]; N2 += nr[r] * nr[r]; }
-    const float Rp = (float)(R - 1);
-    for (int d = tid; d < D; d += nt) {
-      const float c0 = X[d], md = mean[d];
-      gX[d] += 4.f * (Rp * c0 - N1 * md);
-      loss += 2.f * (Rp * c0 * c0 - 2.f * c0 * md * N1 + md * md * N2);
+    if ((tid & 63) == 0) {
+      nr[r] = a;
+      if (r >= 1) { n1 += a; n2 += a * a; }
     }
   }
-  red[tid] = loss;
+  __syncthreads();
+  for (int d = tid; d < D; d += nt) {
+    const float a = col[d];
+    mean[d] = a / (float)(R - 1);
+    s1[d] = a - X[(long)(R - 1) * D + d];
+    s2[d] = a - X[(long)1 * D + d];
+  }
+  red[tid] = n1;
+  red[nt + tid] = n2;
   __syncthreads();
   for (int s = nt >> 1; s > 0; s >>= 1) {
-    if (tid < s) red[tid] += red[tid + s];
+    if (tid < s) { red[tid] += red[tid + s]; red[nt + tid] += red[nt + tid + s]; }
     __syncthreads();
   }
-  if (tid == 0 && loss_acc) atomicAdd(loss_acc + 2, red[0]);
+  if (tid == 0) { scratch[3 * D + R] = red[0]; scratch[3 * D + R + 1] = red[nt]; }
+}
+
+__global__ void reg_apply_kernel(const float* __restrict__ X, int R, int D, float* __restrict__ gX, int mode,
+                                 const float* __restrict__ scratch, float* __restrict__ loss_acc) {
+  __shared__ float red[256];
+  const float* mean = scratch;
+  const float* s1 = scratch + D;
+  const float* s2 = scratch + 2 * D;
+  const float* nr = scratch + 3 * D;
+  const float N1 = scratch[3 * D + R], N2 = scratch[3 * D + R + 1];
+  const float c_low = mode == 0 ? 0.01f : 0.02f;
+  const float Rp = (float)(R - 1);
+  float loss = 0.f;
+  const long total = (long)R * D;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / D), d = (int)(e % D);
+    const float x = X[e];
+    const float q = 1.f - nr[r];
+    float g = -4.f * c_low * q * x;                      // low-rank term on every row
+    if (d == 0) loss += c_low * q * q;
+    if (mode == 0) {
+      if (r == 0) { const float u = x - mean[d]; g += 2.f * u; loss += u * u; }
+    } else {
+      if (r >= 2) g += 0.2f * s1[d];                     // smoothness (all-pairs form, rating.py:206)
+      if (r == 0) {
+        const float md = mean[d];
+        g += 4.f * (Rp * x - N1 * md);                   // underspecification at index 0
+        loss += 0.2f * s1[d] * s2[d] + 2.f * (Rp * x * x - 2.f * x * md * N1 + md * md * N2);
+      }
+    }
+    gX[e] += g;
+  }
+  red[threadIdx.x] = loss;
+  __syncthreads();
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc + 2, red[0]);
 }
 
 // ---- carried state (slot layout [B][2L][W] f32) -> bf16 h rows + f32 c rows -------
@@ -343,17 +355,22 @@ int kl_launch_onehot_t(const int* ids, int B, int T, int n_classes, int col, int
 }
 
 int kl_launch_regulariser_grads(const float* E, int V, int W, const float* const* ctx_tabs, int n_ctx, int ctx_vocab,
-                                int ctx_dim, float* gE, float* const* gCtx, float* loss_acc, hipStream_t stream) {
+                                int ctx_dim, float* gE, float* const* gCtx, float* loss_acc, float* scratch,
+                                hipStream_t stream) {
+  // scratch: 3*max(W, ctx_dim) + max(V, ctx_vocab) + 2 floats (kl_reg_scratch_floats)
   const int nt = 1024;
   if (V >= 2) {
-    size_t lds = (size_t)(3 * W + V + nt) * sizeof(float);
+    const size_t lds = (size_t)(W + 2 * nt) * sizeof(float);
     if (lds > 64 * 1024) return KL_ERR_SHAPE;
-    hipLaunchKernelGGL(reg_table_kernel, dim3(1), dim3(nt), lds, stream, E, V, W, gE, 0, loss_acc);
+    hipLaunchKernelGGL(reg_stats_kernel, dim3(1), dim3(nt), lds, stream, E, V, W, scratch);
+    hipLaunchKernelGGL(reg_apply_kernel, dim3(grid_for((long)V * W, 256)), dim3(256), 0, stream, E, V, W, gE, 0, scratch,
+                       loss_acc);
   }
   for (int n = 0; n < n_ctx; ++n) {
-    size_t lds = (size_t)(3 * ctx_dim + ctx_vocab + nt) * sizeof(float);
-    hipLaunchKernelGGL(reg_table_kernel, dim3(1), dim3(nt), lds, stream, ctx_tabs[n], ctx_vocab, ctx_dim, gCtx[n], 1,
-                       loss_acc);
+    const size_t lds = (size_t)(ctx_dim + 2 * nt) * sizeof(float);
+    hipLaunchKernelGGL(reg_stats_kernel, dim3(1), dim3(nt), lds, stream, ctx_tabs[n], ctx_vocab, ctx_dim, scratch);
+    hipLaunchKernelGGL(reg_apply_kernel, dim3(grid_for((long)ctx_vocab * ctx_dim, 256)), dim3(256), 0, stream, ctx_tabs[n],
+                       ctx_vocab, ctx_dim, gCtx[n], 1, scratch, loss_acc);
   }
   return ok();
 }

@@ -83,6 +83,24 @@ struct KlScanFwd {
 };
 int kl_launch_scan_fwd(KlScanFwd args, hipStream_t stream);
 
+// one layer per launch, 64-unit workgroups (B >= 512 streams)
+struct KlScanFwdWide {
+  int B, T, W;
+  int n_rb, n_rg;                      // filled by the launcher
+  const bf16_t* UT;                    // [4W][W]
+  const float* P;                      // [T*B][4W] input contraction + bias (layers >= 1), or null = tables:
+  const float* EK; const float* CtxK[8]; int n_ctx;   // layer 0: EK[idx] + sum_n CtxK_n[ctx_n] + bias
+  const int* idx; const int* ctx;      // [B][T], [B][T][n_ctx]
+  const float* bias;                   // [4W]
+  bf16_t* H; float* C; bf16_t* G;      // as KlScanFwd, this layer
+  bf16_t* Hd; const float* mask;       // dropout-masked copy (null: none)
+  bf16_t* HT; long ldt;                // transposed outputs [W][ldt], column (t+1)*B + row (null: none)
+  bf16_t* HdT; long ldt_d;             // transposed masked outputs [W][ldt_d], column t*B + row (null: none)
+  unsigned* counters;                  // [n_rb][T]
+  unsigned* status;
+};
+int kl_launch_scan_fwd_wide(KlScanFwdWide args, hipStream_t stream);
+
 struct KlScanBwd {
   int B, T, W, L;
   int n_rb, n_rg;
@@ -96,6 +114,7 @@ struct KlScanBwd {
   unsigned* counters;                  // [L][n_rb][T]
   unsigned* status;
   bf16_t* dZT; long ldt;               // wide one-layer kernel only: also write dZ transposed [4W][ldt] (null: no)
+  float* db;                           // wide one-layer kernel only: += column sums of dZ (bias gradient; null: no)
 };
 int kl_launch_scan_bwd(KlScanBwd args, hipStream_t stream);
 int kl_launch_scan_bwd_wide(KlScanBwd args, hipStream_t stream);   // one layer per launch, 64-unit workgroups
@@ -121,7 +140,8 @@ int kl_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float
 int kl_launch_onehot_t(const int* ids, int B, int T, int n_classes, int col, int n_cols, bf16_t* out, long ld,
                        hipStream_t stream);
 int kl_launch_regulariser_grads(const float* E, int V, int W, const float* const* ctx_tabs, int n_ctx, int ctx_vocab,
-                                int ctx_dim, float* gE, float* const* gCtx, float* loss_acc, hipStream_t stream);
+                                int ctx_dim, float* gE, float* const* gCtx, float* loss_acc, float* scratch,
+                                hipStream_t stream);
 int kl_launch_state_to_rows(const float* states, int B, int W, int L, int layer, bf16_t* h_bf16, float* h_f32,
                             float* c_f32, hipStream_t stream);
 int kl_launch_fill_f32(float* p, size_t n, float v, hipStream_t stream);

@@ -67,6 +67,9 @@ __device__ __forceinline__ uint4 load16_sc1(__amdgpu_buffer_rsrc_t r, unsigned b
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16);
   return uint4{v.x, v.y, v.z, v.w};
 }
+__device__ __forceinline__ void store16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, uint4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, r, (int)byte_off, 0, 16);
+}
 
 // v_exp_f32 / v_rcp_f32 forms (1 ulp each): the scans are latency chains, and the
 // training path computes in bf16 anyway
@@ -451,7 +454,8 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
   float (*zt)[16][17] = reinterpret_cast<float (*)[16][17]>(smem + 4 * KSTEPS * 1024);   // [16 waves][16][17]
   bf16_t* tr = reinterpret_cast<bf16_t*>(smem + 4 * KSTEPS * 1024 + 16 * 16 * 17 * 4);   // [4 gates][64 units][16 rows]
   // (all LDS in the dynamic region: a static object in front would shift its 16-byte alignment)
-  int& ok_flag = *reinterpret_cast<int*>(smem + 4 * KSTEPS * 1024 + 16 * 16 * 17 * 4 + 4 * 64 * 16 * 2);
+  bf16_t* pub = tr + 4 * 64 * 16;                                         // [4 gates][16 rows][64 units]
+  int& ok_flag = *reinterpret_cast<int*>(smem + 4 * KSTEPS * 1024 + 16 * 16 * 17 * 4 + 2 * 4 * 64 * 16 * 2);
 
   const int kq = (lane >> 4) * 8;
   uint4 bu[KSTEPS];
@@ -464,6 +468,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
   float dc_reg[MAXRB];
 #pragma unroll
   for (int i = 0; i < MAXRB; ++i) dc_reg[i] = 0.f;
+  float dbacc[4] = {0.f, 0.f, 0.f, 0.f};   // bias gradient: this thread's (unit, gate) summed over its rows and steps
   const long BW = (long)B * W;
   const bf16_t* Gl = a.G[0];
   const float* Cl = a.C[0];
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
       if (maskl) dh *= maskl[(long)erow * W + u0 + eu];
       if (tid == 0) {
         bool ok = alive;
-        if (ok && t < T - 1) ok = poll_counter(cnt_own + (long)rb * T + (t + 1), NWG_RB, status);
+        if (ok && t < T - 1) ok = poll_counter(cnt_own + (long)rb * T + (t + 1), 8 * NWG_RB, status);
         ok_flag = ok ? 1 : 0;
       }
       __syncthreads();
@@ -529,27 +534,36 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
       const float d_o = dh * tc, d_i = dc * gg, d_g = dc * gi, d_f = dc * cp;
       const unsigned z0 = f2bf(d_i * gi * (1.f - gi)), z1 = f2bf(d_f * gf * (1.f - gf));
       const unsigned z2 = f2bf(d_g * (1.f - gg * gg)), z3 = f2bf(d_o * go * (1.f - go));
-      const unsigned n0 = __shfl_xor(z0, 1), n1 = __shfl_xor(z1, 1), n2 = __shfl_xor(z2, 1), n3 = __shfl_xor(z3, 1);
       const bool row_ok = (r0 + er) < B;
-      if (row_ok && alive && (eu & 1) == 0) {
-        unsigned* zp = reinterpret_cast<unsigned*>(dZl + ((long)t * B + r0 + er) * 4 * W + u0 + eu);
-        __hip_atomic_store(zp, z0 | (n0 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(zp + W / 2, z1 | (n1 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(zp + W, z2 | (n2 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(zp + 3 * W / 2, z3 | (n3 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (row_ok && alive) {
+        dbacc[0] += bf2f((bf16_t)z0); dbacc[1] += bf2f((bf16_t)z1); dbacc[2] += bf2f((bf16_t)z2); dbacc[3] += bf2f((bf16_t)z3);
       }
+      pub[(0 * 16 + er) * 64 + eu] = (bf16_t)z0;
+      pub[(1 * 16 + er) * 64 + eu] = (bf16_t)z1;
+      pub[(2 * 16 + er) * 64 + eu] = (bf16_t)z2;
+      pub[(3 * 16 + er) * 64 + eu] = (bf16_t)z3;
       if (dZT) {   // stage the tile transposed for the off-chain copy below
         tr[(0 * 64 + eu) * 16 + er] = row_ok ? (bf16_t)z0 : (bf16_t)0;
         tr[(1 * 64 + eu) * 16 + er] = row_ok ? (bf16_t)z1 : (bf16_t)0;
         tr[(2 * 64 + eu) * 16 + er] = row_ok ? (bf16_t)z2 : (bf16_t)0;
         tr[(3 * 64 + eu) * 16 + er] = row_ok ? (bf16_t)z3 : (bf16_t)0;
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(cnt_own + (long)rb * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (dZT && alive && tid < 512) {
+      // publish dZ[t]: eight waves, one 16-byte write-through store per lane; each storing
+      // wave drains its own stores and then counts itself in (8 arrivals per workgroup)
+      if (tid < 512) {
+        const int g = tid >> 7, prow = (tid >> 3) & 15, seg = tid & 7;
+        if (alive && r0 + prow < B) {
+          const uint4 v = *reinterpret_cast<const uint4*>(pub + (g * 16 + prow) * 64 + seg * 8);
+          store16_sc1(rs_own, (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2), v);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(cnt_own + (long)rb * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (dZT && alive && tid >= 512) {
         // 256 columns (gate, unit) x 16 rows: two 16-byte stores per column
-        const int col = tid >> 1, half = tid & 1;
+        // (the waves that do not publish)
+        const int col = (tid - 512) >> 1, half = tid & 1;
         const int g = col >> 6, u = col & 63;
         const long trow = (long)g * W + u0 + u;
         const long tcol = (long)t * B + r0 + half * 8;
@@ -558,6 +572,191 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
             *reinterpret_cast<uint4*>(dZT + trow * ldt + tcol) = *reinterpret_cast<const uint4*>(tr + col * 16 + half * 8);
         } else {
           for (int q = 0; q < 8 && r0 + half * 8 + q < B; ++q) dZT[trow * ldt + tcol + q] = tr[col * 16 + half * 8 + q];
+        }
+      }
+    }
+  }
+  // db[g*W + u] += sum over this workgroup's rows and all steps (16 partials per column meet in LDS)
+  if (a.db) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(a_tile);     // [4 gates][16 rows][64 units]
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[(g * 16 + er) * 64 + eu] = dbacc[g];
+    __syncthreads();
+    if (tid < 256) {
+      const int g = tid >> 6, u = tid & 63;
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += red[(g * 16 + r) * 64 + u];
+      atomicAdd(a.db + (long)g * W + u0 + u, sum);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- forward scan, one layer, wide workgroups
+// Counterpart of lstm_scan_bwd_wide_kernel for B >= 512 streams: 16 waves = 4 K-quarters x
+// 4 unit groups = 64 hidden units per workgroup, the 16 x W state tile is fetched once
+// per workgroup (one fragment per wave) and shared through LDS.  Only the recurrent
+// contraction is carried; the input side arrives either as the precomputed P rows of the
+// big GEMM (layers >= 1) or -- layer 0 -- straight from the look-up tables
+// EK[idx] + sum_n CtxK_n[ctx_n] + b (no P1 buffer at all).  The outputs are also written
+// transposed ([W][(T+1)B]) for the weight-gradient GEMMs.
+template <int KSTEPS, int MAXRB>
+__global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlScanFwdWide a) {
+  constexpr int W = KSTEPS * 32;
+  constexpr int KQ = KSTEPS / 4;
+  constexpr int NWG_RB = W / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq4 = wave & 3, ug = wave >> 2;
+  const int n_rg = a.n_rg, n_rb = a.n_rb, B = a.B, T = a.T;
+  const int cg = blockIdx.x / n_rg, rg = blockIdx.x % n_rg;
+  const int u0 = cg * 64;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* a_tile = smem;                                                       // [KSTEPS][1 KiB]
+  float (*zt)[4][16][17] = reinterpret_cast<float (*)[4][16][17]>(smem + KSTEPS * 1024);   // [16 waves][4 gates][16][17]
+  bf16_t* tr = reinterpret_cast<bf16_t*>(smem + KSTEPS * 1024 + 16 * 4 * 16 * 17 * 4);   // [2][64 units][16 rows]
+  bf16_t* pub = tr + 2 * 64 * 16;                                                       // [16 rows][64 units]
+  int& ok_flag = *reinterpret_cast<int*>(smem + KSTEPS * 1024 + 16 * 4 * 16 * 17 * 4 + 2 * 64 * 16 * 2 + 16 * 64 * 2);
+
+  const int kq = (lane >> 4) * 8;
+  uint4 bu[4][KQ];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const long wrow = ((long)g * W + u0 + ug * 16 + (lane & 15)) * W + (kq4 * KQ) * 32 + kq;
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) bu[g][j] = *reinterpret_cast<const uint4*>(a.UT + wrow + j * 32);
+  }
+  const int er = tid >> 6, eu = tid & 63;
+  float* Cl = a.C;
+  bf16_t* Hl = a.H;
+  bf16_t* Gl = a.G;
+  bf16_t* Hdl = a.Hd;
+  bf16_t* HT = a.HT;
+  bf16_t* HdT = a.HdT;
+  const long ldt = a.ldt;
+  const float* maskl = a.mask;
+  const float* P = a.P;
+  unsigned* status = a.status;
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (!P) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = a.bias[(long)g * W + u0 + eu];
+  }
+  float c_reg[MAXRB];
+#pragma unroll
+  for (int i = 0; i < MAXRB; ++i) {
+    const int rb = rg + i * n_rg;
+    const int row = min(rb * 16 + er, B - 1);
+    c_reg[i] = (rb < n_rb) ? Cl[(long)row * W + u0 + eu] : 0.f;
+  }
+  const long BW = (long)B * W;
+  const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(Hl, (long)(T + 1) * BW * 2);
+  unsigned* cnt_own = a.counters;
+  bool alive = true;
+
+  for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int i = 0; i < MAXRB; ++i) {
+      const int rb = rg + i * n_rg;
+      if (rb >= n_rb) continue;
+      const int r0 = rb * 16;
+      const int erow = min(r0 + er, B - 1);
+      float zin[4];
+      if (P) {
+        const float* p = P + ((long)t * B + erow) * 4 * W + u0 + eu;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) zin[g] = p[(long)g * W];
+      } else {
+        const long src = (long)erow * T + t;
+        const float* e = a.EK + (long)a.idx[src] * 4 * W + u0 + eu;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) zin[g] = bias4[g] + e[(long)g * W];
+        for (int n = 0; n < a.n_ctx; ++n) {
+          const float* q = a.CtxK[n] + (long)a.ctx[src * a.n_ctx + n] * 4 * W + u0 + eu;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) zin[g] += q[(long)g * W];
+        }
+      }
+      float mk = 1.f;
+      if (maskl) mk = maskl[(long)erow * W + u0 + eu];
+      if (tid == 0) {
+        bool ok = alive;
+        if (ok && t > 0) ok = poll_counter(cnt_own + (long)rb * T + (t - 1), 2 * NWG_RB, status);
+        ok_flag = ok ? 1 : 0;
+      }
+      __syncthreads();
+      alive = ok_flag != 0;
+      if (wave < KSTEPS) {   // one fragment of the 16 x W tile of h[t-1] per wave
+        const int arow = min(r0 + (lane & 15), B - 1);
+        const uint4 v = alive ? load16_sc1(rs_h, (unsigned)((((long)t * B + arow) * W + wave * 32 + kq) * 2)) : uint4{0, 0, 0, 0};
+        *reinterpret_cast<uint4*>(a_tile + wave * 1024 + lane * 16) = v;
+      }
+      __syncthreads();
+      f32x4 acc[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) {
+        frag16 fa;
+        fa.u = *reinterpret_cast<const uint4*>(a_tile + (kq4 * KQ + j) * 1024 + lane * 16);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          frag16 fb;
+          fb.u = bu[g][j];
+          acc[g] = mfma16(fa.v, fb.v, acc[g]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zt[wave][g][(lane >> 4) * 4 + r][lane & 15] = acc[g][r];
+      __syncthreads();
+      const int wz = (eu >> 4) * 4, ue = eu & 15;
+      float z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) z[g] = zin[g] + zt[wz][g][er][ue] + zt[wz + 1][g][er][ue] + zt[wz + 2][g][er][ue] + zt[wz + 3][g][er][ue];
+      const float gi = fast_sigmoid(z[0]), gf = fast_sigmoid(z[1]), gg = fast_tanh(z[2]), go = fast_sigmoid(z[3]);
+      const float c = gf * c_reg[i] + gi * gg;
+      c_reg[i] = c;
+      const float h = go * fast_tanh(c);
+      const bool row_ok = (r0 + er) < B;
+      const unsigned hb = f2bf(h), hdb = f2bf(h * mk);
+      const long orow = (long)t * B + r0 + er;
+      pub[er * 64 + eu] = (bf16_t)hb;
+      tr[eu * 16 + er] = row_ok ? (bf16_t)hb : (bf16_t)0;
+      tr[(64 + eu) * 16 + er] = row_ok ? (bf16_t)hdb : (bf16_t)0;
+      __syncthreads();
+      // publish h[t]: two waves, one 16-byte write-through store per lane; each storing wave
+      // drains its own stores and then counts itself in (2 arrivals per workgroup)
+      if (tid < 128) {
+        const int prow = tid >> 3, seg = tid & 7;
+        if (alive && r0 + prow < B) {
+          const uint4 v = *reinterpret_cast<const uint4*>(pub + prow * 64 + seg * 8);
+          store16_sc1(rs_h, (unsigned)((((long)(t + 1) * B + r0 + prow) * W + u0 + seg * 8) * 2), v);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(cnt_own + (long)rb * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // off the hand-off chain: what only later launches read
+      if (row_ok && alive) {
+        Cl[(orow + B) * W + u0 + eu] = c;
+        if (Hdl) Hdl[orow * W + u0 + eu] = (bf16_t)hdb;
+        if (Gl) {
+          bf16_t* gp = Gl + orow * 4 * W + u0 + eu;
+          gp[0] = f2bf(gi);
+          gp[W] = f2bf(gf);
+          gp[2 * W] = f2bf(gg);
+          gp[3 * W] = f2bf(go);
+        }
+      }
+      if (alive && tid < 256) {   // transposed copies: 64 units x 16 rows, two 16-byte stores per unit (x2 buffers)
+        const int which = tid >> 7, unit = (tid >> 1) & 63, half = tid & 1;
+        bf16_t* dst = which ? HdT : HT;
+        if (dst && r0 + half * 8 < B) {
+          const long tcol = (which ? (long)t * B : (long)(t + 1) * B) + r0 + half * 8;
+          *reinterpret_cast<uint4*>(dst + (long)(u0 + unit) * (which ? a.ldt_d : ldt) + tcol) =
+              *reinterpret_cast<const uint4*>(tr + (which * 64 + unit) * 16 + half * 8);
         }
       }
     }
@@ -589,7 +788,7 @@ bool plan_scan(int W, int L, int B, int T, int* n_rb, int* n_rg, int* per_wg) {
   if (g < 1) return false;
   *n_rg = g;
   *per_wg = (*n_rb + g - 1) / g;
-  return *per_wg <= 4;
+  return *per_wg <= (W == 512 ? 8 : 4);
 }
 
 }  // namespace
@@ -600,7 +799,8 @@ bool plan_scan(int W, int L, int B, int T, int* n_rb, int* n_rg, int* per_wg) {
     if (W == 512) {                                                                                   \
       if (per_wg == 1) KL_SCAN_CASE(KERNEL, 16, 1);                                                   \
       else if (per_wg == 2) KL_SCAN_CASE(KERNEL, 16, 2);                                              \
-      else KL_SCAN_CASE(KERNEL, 16, 4);                                                               \
+      else if (per_wg <= 4) KL_SCAN_CASE(KERNEL, 16, 4);                                              \
+      else KL_SCAN_CASE(KERNEL, 16, 8);                                                               \
     } else if (W == 256) {                                                                            \
       if (per_wg == 1) KL_SCAN_CASE(KERNEL, 8, 1);                                                    \
       else if (per_wg == 2) KL_SCAN_CASE(KERNEL, 8, 2);                                               \
@@ -656,12 +856,41 @@ int kl_launch_scan_bwd_wide(KlScanBwd a, hipStream_t stream) {
   const int per_wg = (a.n_rb + g - 1) / g;
   if (per_wg > 4) return KL_ERR_SHAPE;
   dim3 grid(col_groups * g), block(1024);
-  const size_t lds = (size_t)4 * (W / 32) * 1024 + 16 * 16 * 17 * 4 + 4 * 64 * 16 * 2 + 16;
+  const size_t lds = (size_t)4 * (W / 32) * 1024 + 16 * 16 * 17 * 4 + 2 * 4 * 64 * 16 * 2 + 16;
+  if ((long)a.T * a.B * 4 * W * 2 > 0x7fffffffL) return KL_ERR_SHAPE;   // 32-bit buffer offsets
 #define KL_WIDE_CASE(KS, RB)                                                                                         \
   do {                                                                                                               \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_bwd_wide_kernel<KS, RB>),                     \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH; \
     hipLaunchKernelGGL((lstm_scan_bwd_wide_kernel<KS, RB>), grid, block, lds, stream, a);                            \
+  } while (0)
+  if (W == 512) { if (per_wg == 1) KL_WIDE_CASE(16, 1); else if (per_wg == 2) KL_WIDE_CASE(16, 2); else KL_WIDE_CASE(16, 4); }
+  else { if (per_wg == 1) KL_WIDE_CASE(8, 1); else if (per_wg == 2) KL_WIDE_CASE(8, 2); else KL_WIDE_CASE(8, 4); }
+#undef KL_WIDE_CASE
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+// One-layer forward scan with 64-unit workgroups.  KL_ERR_SHAPE = not applicable.
+int kl_launch_scan_fwd_wide(KlScanFwdWide a, hipStream_t stream) {
+  const int W = a.W;
+  if ((W != 512 && W != 256) || a.B < 1 || a.T < 1 || (a.B & 7)) return KL_ERR_SHAPE;
+  if ((a.HT && (a.ldt & 7)) || (a.HdT && (a.ldt_d & 7))) return KL_ERR_SHAPE;
+  if (!a.P && (!a.EK || !a.idx || !a.bias || a.n_ctx > 8)) return KL_ERR_ARG;
+  a.n_rb = (a.B + 15) / 16;
+  const int col_groups = W / 64;
+  int g = 256 / col_groups;
+  if (g > a.n_rb) g = a.n_rb;
+  a.n_rg = g;
+  const int per_wg = (a.n_rb + g - 1) / g;
+  if (per_wg > 4) return KL_ERR_SHAPE;
+  dim3 grid(col_groups * g), block(1024);
+  const size_t lds = (size_t)(W / 32) * 1024 + 16 * 4 * 16 * 17 * 4 + 2 * 64 * 16 * 2 + 16 * 64 * 2 + 16;
+  if ((long)(a.T + 1) * a.B * W * 2 > 0x7fffffffL) return KL_ERR_SHAPE;   // 32-bit buffer offsets
+#define KL_WIDE_CASE(KS, RB)                                                                                         \
+  do {                                                                                                               \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_fwd_wide_kernel<KS, RB>),                     \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH; \
+    hipLaunchKernelGGL((lstm_scan_fwd_wide_kernel<KS, RB>), grid, block, lds, stream, a);                            \
   } while (0)
   if (W == 512) { if (per_wg == 1) KL_WIDE_CASE(16, 1); else if (per_wg == 2) KL_WIDE_CASE(16, 2); else KL_WIDE_CASE(16, 4); }
   else { if (per_wg == 1) KL_WIDE_CASE(8, 1); else if (per_wg == 2) KL_WIDE_CASE(8, 2); else KL_WIDE_CASE(8, 4); }

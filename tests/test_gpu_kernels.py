@@ -193,6 +193,22 @@ def test_forward_window_parity(depth, width, voc, B, T, n_ctx):
                                                                  (2, 512, 64, 144, 6, 1, True), (2, 256, 40, 272, 4, 1, True),
                                                                  (3, 256, 30, 176, 5, 1, True)])
 def test_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks):
+    check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks)
+
+
+@pytest.mark.parametrize("depth,width,voc,B,T,n_ctx,use_masks", [(2, 512, 64, 144, 6, 1, True), (2, 512, 64, 40, 7, 2, True),
+                                                                 (3, 256, 30, 176, 5, 1, True), (1, 256, 40, 8, 9, 1, False),
+                                                                 (2, 256, 40, 272, 4, 1, False),
+                                                                 # the shape class that takes this path by default
+                                                                 (2, 512, 64, 512, 4, 1, True)])
+def test_train_window_wide_forward(monkeypatch, depth, width, voc, B, T, n_ctx, use_masks):
+    """Layer-sequential forward with 64-unit workgroups (table look-ups fused into the
+    layer-0 scan, transposed outputs written by the scans): forced on for small shapes."""
+    monkeypatch.setenv("KL_WIDE_FWD_MIN", "1")
+    check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks)
+
+
+def check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks):
     """B1-B7 + F7: gradients of mean CE + regularisers vs the f64 oracle.  The HIP
     path computes in bf16 with f32 accumulation: relative error of each gradient
     array is held to 3e-2 of its max-norm (bf16 has 8 mantissa bits)."""

@@ -21,6 +21,8 @@ for _ in range(n): step()
 torch.cuda.synchronize()
 dt=(time.time()-t)/n
 print(f"train B={B} T={T}: {dt*1e3:.2f} ms/step, {B*T/dt/1e6:.2f} Mchars/s, loss", lm.read_loss())
+import os
+if os.environ.get('KL_PROBE_TRAIN_ONLY'): sys.exit(0)
 # forward only (inference split)
 lm.prepare(hipabi.KL_PREC_SPLIT)
 for Bf in (1, B):
