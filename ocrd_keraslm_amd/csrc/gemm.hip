@@ -14,6 +14,8 @@
 // most CUs idle (M = 1024 hypotheses x N = 2048: 128 vs 256 workgroups).
 // Split-K over gridDim.z with f32 atomics for the K = B*T weight-gradient
 // shapes (M,N small, K huge).
+#include <stdlib.h>
+
 #include "kl_common.h"
 #include "kl_kernels.h"
 
@@ -154,6 +156,209 @@ void launch_bm(int out_mode, dim3 grid, hipStream_t stream, const bf16_t* A, con
   }
 }
 
+
+// ---------------------------------------------------------------- long-K variant
+// For the K = B*T contractions (weight gradients: M, N <= 2048, K ~ 1e5) one workgroup
+// per CU stays in its main loop for thousands of k-steps, so the loop itself is what
+// counts: 256 x 128 x 64 tile, 512 threads = 8 waves as 4 (M) x 2 (N), each 64 x 64;
+// both operand tiles arrive by LDS-DMA (buffer_load ... lds, 1 KiB = 8 rows per wave
+// instruction; no staging registers, no ds_write pass) into a 3-deep ring (144 KiB), two
+// tiles in flight across ONE raw barrier per k-step and a counted vmcnt.  The LDS image
+// is the same XOR-swizzled [rows][64] layout as above; an LDS-DMA writes lane-linear, so
+// the swizzle is applied to each lane's SOURCE chunk instead.
+// Ordering (MI355X_MICROARCH.md, LDS-DMA): a stage is read only after its issuing waves'
+// counted vmcnt AND a barrier the reader has passed; it is restaged only after a barrier
+// that every reader reaches with its ds_reads retired (they feed MFMAs issued before it).
+constexpr int LBM = 256, LBN = 128, LTHREADS = 512, LSTAGES = 3;
+constexpr int LSTAGE_BYTES = (LBM + LBN) * 128;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from rsrc[voff + soff] to LDS [lds_addr, +1 KiB).
+// Inline asm on purpose: behind the builtin hipcc drains vmcnt(0) in front of the next
+// ds_read (it cannot tell the ring's stages apart), which would serialise the pipeline;
+// the waits are counted by hand below.  M0 is compiler-reserved: saved and restored.
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(lds_addr), "s"(soff)
+      : "memory");
+}
+
+template <int OUT, bool ILV>
+__global__ __launch_bounds__(LTHREADS, 1) void gemm_tn_long_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv,
+    const float* __restrict__ bias, int M, int N, int K, long lda, long ldb, long ldc,
+    int k_per_split, float alpha) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * LBM;
+  const int n0 = blockIdx.x * LBN;
+  const int kbeg = blockIdx.z * k_per_split;
+  const int kend = min(K, kbeg + k_per_split);
+  const int nkt = (kend - kbeg) / BK;     // host guarantees whole k-tiles
+
+  // buffer resources based at this workgroup's first rows; rows past the matrix read as zero
+  auto clamp31 = [](long v) { return (int)(v > 0x7fffffffL ? 0x7fffffffL : (v < 0 ? 0 : v)); };
+  const __amdgpu_buffer_rsrc_t rsA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A + (long)m0 * lda), 0, clamp31(((long)(M - m0 - 1) * lda + K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B + (long)n0 * ldb), 0, clamp31(((long)(N - n0 - 1) * ldb + K) * 2), 0x00020000);
+  // per-lane source offsets of this wave's pieces: A rows wave*32 + j*8 + (lane>>3), B rows wave*16 + j*8 + (lane>>3)
+  unsigned voA[4], voB[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = wave * 32 + j * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    voA[j] = (unsigned)((long)row * lda * 2 + c * 16);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = wave * 16 + j * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    voB[j] = (unsigned)((long)row * ldb * 2 + c * 16);
+  }
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
+  // half 0 = A pieces 0..2, half 1 = A piece 3 + both B pieces (issued between the two MFMA groups of a k-step)
+  auto issue_half = [&](int kt, int stage, int half) {
+    const int soff = (kbeg + kt * BK) * 2;
+    const unsigned sa = lds0 + stage * LSTAGE_BYTES + wave * 32 * 128;
+    const unsigned sb = lds0 + stage * LSTAGE_BYTES + LBM * 128 + wave * 16 * 128;
+    if (half == 0) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) glds16(rsA, voA[j], soff, sa + j * 1024);
+    } else {
+      glds16(rsA, voA[3], soff, sa + 3 * 1024);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) glds16(rsB, voB[j], soff, sb + j * 1024);
+    }
+  };
+  auto issue = [&](int kt, int stage) {
+    issue_half(kt, stage, 0);
+    issue_half(kt, stage, 1);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nkt > 0) issue(0, 0);
+  if (nkt > 1) issue(1, 1);
+  const int fr = lane & 15, fq = lane >> 4;
+  int stage = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool more = kt + 2 < nkt;
+    const int nstage = stage >= 1 ? stage - 1 : LSTAGES - 1;   // (kt+2) % 3 == (stage+2) % 3
+    if (!ILV && more) issue(kt + 2, nstage);
+    const unsigned char* a_base = smem + stage * LSTAGE_BYTES;
+    const unsigned char* b_base = a_base + LBM * 128;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      frag16 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        fa[i].u = *reinterpret_cast<const uint4*>(a_base + lds_off(wm * 64 + i * 16 + fr, s * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        fb[j].u = *reinterpret_cast<const uint4*>(b_base + lds_off(wn * 64 + j * 16 + fr, s * 4 + fq));
+      if (ILV && more) issue_half(kt + 2, nstage, s);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fa[i].v, fb[j].v, acc[i][j]);
+    }
+    stage = stage + 1 < LSTAGES ? stage + 1 : 0;
+  }
+
+  if (OUT == 0 && (ldc & 3) == 0 && (n0 + LBN <= N) && ((size_t)Cv & 15) == 0) {
+    // f32 stores in whole rows: the accumulator layout (4 rows x 1 column per lane) would
+    // write 64-byte row segments; turn the tile through LDS (the ring is free now) so that
+    // 32 lanes write one 512-byte row
+    constexpr int LDP = LBN + 4;                       // padded row, floats
+    float* ct = reinterpret_cast<float*>(smem);
+    __builtin_amdgcn_s_barrier();                      // every wave is done reading the last stage
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ct[(wm * 64 + i * 16 + fq * 4 + r) * LDP + wn * 64 + j * 16 + fr] = acc[i][j][r] * alpha;
+    __syncthreads();
+    const int c4 = (tid & 31) * 4;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) bv = f32x4{bias[n0 + c4], bias[n0 + c4 + 1], bias[n0 + c4 + 2], bias[n0 + c4 + 3]};
+    float* Cf = reinterpret_cast<float*>(Cv);
+#pragma unroll 4
+    for (int p = 0; p < LBM / 16; ++p) {
+      const int row = p * 16 + (tid >> 5);
+      if (m0 + row < M) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ct + row * LDP + c4);
+        *reinterpret_cast<f32x4*>(Cf + (long)(m0 + row) * ldc + n0 + c4) = v + bv;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wn * 64 + j * 16 + fr;
+      if (col >= N) continue;
+      const float bv = (bias != nullptr && blockIdx.z == 0) ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 64 + i * 16 + fq * 4 + r;
+        if (row >= M) continue;
+        const float v = acc[i][j][r] * alpha + bv;
+        if (OUT == 0) {
+          reinterpret_cast<float*>(Cv)[(long)row * ldc + col] = v;
+        } else if (OUT == 1) {
+          reinterpret_cast<bf16_t*>(Cv)[(long)row * ldc + col] = f2bf(v);
+        } else {
+          atomicAdd(reinterpret_cast<float*>(Cv) + (long)row * ldc + col, v);
+        }
+      }
+    }
+  }
+}
+
+int launch_long(int out_mode, dim3 grid, hipStream_t stream, const bf16_t* A, const bf16_t* B, void* C, const float* bias,
+                int M, int N, int K, long lda, long ldb, long ldc, int k_per_split, float alpha) {
+  const size_t lds = (size_t)LSTAGES * LSTAGE_BYTES;
+  static const bool ilv = !(getenv("KL_GEMM_ILV") && getenv("KL_GEMM_ILV")[0] == '0');
+#define KL_LONG_CASE(O)                                                                                                  \
+  do {                                                                                                                   \
+    static bool attr_set = false;                                                                                        \
+    if (!attr_set) {                                                                                                     \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<O, true>),                              \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH; \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<O, false>),                             \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH; \
+      attr_set = true;                                                                                                   \
+    }                                                                                                                    \
+    if (ilv) hipLaunchKernelGGL((gemm_tn_long_kernel<O, true>), grid, dim3(LTHREADS), lds, stream, A, B, C, bias, M, N,  \
+                                K, lda, ldb, ldc, k_per_split, alpha);                                                   \
+    else hipLaunchKernelGGL((gemm_tn_long_kernel<O, false>), grid, dim3(LTHREADS), lds, stream, A, B, C, bias, M, N,     \
+                            K, lda, ldb, ldc, k_per_split, alpha);                                                       \
+  } while (0)
+  if (out_mode == 0) KL_LONG_CASE(0);
+  else if (out_mode == 1) KL_LONG_CASE(1);
+  else KL_LONG_CASE(2);
+#undef KL_LONG_CASE
+  return 0;
+}
+
 }  // namespace
 
 // out_mode: 0 f32 store, 1 bf16 store, 2 f32 atomic accumulate (split-K allowed)
@@ -163,6 +368,29 @@ int kl_launch_gemm_tn(const bf16_t* A, const bf16_t* B, void* C, const float* bi
   if ((K & 7) || (lda & 7) || (ldb & 7)) return KL_ERR_SHAPE;
   if (splits < 1) splits = 1;
   if (out_mode != 2) splits = 1;
+  // long-K shapes (weight gradients): one 256 x 128 tile per CU, K split to fill the chip
+  static const int long_mode = getenv("KL_GEMM_LONG") ? atoi(getenv("KL_GEMM_LONG")) : 2;   // 0 off, 1 split-K shapes only, 2 all
+  const bool long_ok = (K % BK) == 0 && lda < (1L << 22) && ldb < (1L << 22);
+  if (long_mode >= 1 && long_ok && out_mode == 2 && K >= 8192) {
+    const int tiles = ((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN);
+    int sp = (256 + tiles - 1) / tiles;          // ~ one workgroup per CU
+    const int nk = K / BK;
+    if (sp > nk / 16) sp = nk / 16;              // at least 16 k-steps per workgroup
+    if (sp < 1) sp = 1;
+    const int kps = ((nk + sp - 1) / sp) * BK;
+    sp = (K + kps - 1) / kps;
+    dim3 grid((N + LBN - 1) / LBN, (M + LBM - 1) / LBM, sp);
+    const int e = launch_long(out_mode, grid, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, kps, alpha);
+    if (e != 0) return e;
+    return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+  }
+  // many-row shapes (activations x weights): the same ring, one tile per workgroup, no split
+  if (long_mode >= 2 && long_ok && splits == 1 && K >= 256 && (long)((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) >= 256) {
+    dim3 grid((N + LBN - 1) / LBN, (M + LBM - 1) / LBM, 1);
+    const int e = launch_long(out_mode, grid, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, K, alpha);
+    if (e != 0) return e;
+    return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+  }
   int k_per_split = (K + splits - 1) / splits;
   k_per_split = ((k_per_split + BK - 1) / BK) * BK;
   splits = (K + k_per_split - 1) / k_per_split;

@@ -481,6 +481,10 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
   const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(dZl, (long)T * BW * 4 * 2);
   unsigned* cnt_own = a.counters;
   bool alive = true;
+#ifdef KL_STAMP
+  const int STAMP_WG = 0;
+  unsigned long long last_ = clock64();
+#endif
 
   for (int t = T - 1; t >= 0; --t) {
 #pragma unroll
@@ -495,12 +499,15 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
       const float cp = Cl[((long)t * B + erow) * W + u0 + eu];
       float dh = dH[((long)t * B + erow) * W + u0 + eu];
       if (maskl) dh *= maskl[(long)erow * W + u0 + eu];
+      SSTAMP(16);
       if (tid == 0) {
         bool ok = alive;
         if (ok && t < T - 1) ok = poll_counter(cnt_own + (long)rb * T + (t + 1), 8 * NWG_RB, status);
         ok_flag = ok ? 1 : 0;
       }
+      SSTAMP(17);
       __syncthreads();
+      SSTAMP(18);
       alive = ok_flag != 0;
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       if (t < T - 1) {
@@ -513,7 +520,9 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
 #pragma unroll
         for (int j = 0; j < JW; ++j)
           *reinterpret_cast<uint4*>(a_tile + ((kq4 * KSTEPS) + ug * JW + j) * 1024 + lane * 16) = av[j];
+        SSTAMP(19);
         __syncthreads();
+        SSTAMP(20);
 #pragma unroll
         for (int j = 0; j < KSTEPS; ++j) {
           frag16 fa, fb;
@@ -524,7 +533,9 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) zt[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+      SSTAMP(21);
       __syncthreads();
+      SSTAMP(22);
       const int wz = (eu >> 4) * 4;      // the four K-quarter waves of this unit group
       dh += zt[wz][er][eu & 15] + zt[wz + 1][er][eu & 15] + zt[wz + 2][er][eu & 15] + zt[wz + 3][er][eu & 15];
       const float gi = bf2f(g0), gf = bf2f(g1), gg = bf2f(g2), go = bf2f(g3);
@@ -548,7 +559,9 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
         tr[(2 * 64 + eu) * 16 + er] = row_ok ? (bf16_t)z2 : (bf16_t)0;
         tr[(3 * 64 + eu) * 16 + er] = row_ok ? (bf16_t)z3 : (bf16_t)0;
       }
+      SSTAMP(23);
       __syncthreads();
+      SSTAMP(24);
       // publish dZ[t]: eight waves, one 16-byte write-through store per lane; each storing
       // wave drains its own stores and then counts itself in (8 arrivals per workgroup)
       if (tid < 512) {
@@ -558,8 +571,10 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
           store16_sc1(rs_own, (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2), v);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SSTAMP(25);
         if (lane == 0) __hip_atomic_fetch_add(cnt_own + (long)rb * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      SSTAMP(26);
       if (dZT && alive && tid >= 512) {
         // 256 columns (gate, unit) x 16 rows: two 16-byte stores per column
         // (the waves that do not publish)
@@ -654,6 +669,10 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
   const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(Hl, (long)(T + 1) * BW * 2);
   unsigned* cnt_own = a.counters;
   bool alive = true;
+#ifdef KL_STAMP
+  const int STAMP_WG = 0;
+  unsigned long long last_ = clock64();
+#endif
 
   for (int t = 0; t < T; ++t) {
 #pragma unroll
@@ -680,19 +699,24 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
       }
       float mk = 1.f;
       if (maskl) mk = maskl[(long)erow * W + u0 + eu];
+      SSTAMP(0);
       if (tid == 0) {
         bool ok = alive;
         if (ok && t > 0) ok = poll_counter(cnt_own + (long)rb * T + (t - 1), 2 * NWG_RB, status);
         ok_flag = ok ? 1 : 0;
       }
+      SSTAMP(1);
       __syncthreads();
+      SSTAMP(2);
       alive = ok_flag != 0;
       if (wave < KSTEPS) {   // one fragment of the 16 x W tile of h[t-1] per wave
         const int arow = min(r0 + (lane & 15), B - 1);
         const uint4 v = alive ? load16_sc1(rs_h, (unsigned)((((long)t * B + arow) * W + wave * 32 + kq) * 2)) : uint4{0, 0, 0, 0};
         *reinterpret_cast<uint4*>(a_tile + wave * 1024 + lane * 16) = v;
       }
+      SSTAMP(3);
       __syncthreads();
+      SSTAMP(4);
       f32x4 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -711,7 +735,9 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int r = 0; r < 4; ++r) zt[wave][g][(lane >> 4) * 4 + r][lane & 15] = acc[g][r];
+      SSTAMP(5);
       __syncthreads();
+      SSTAMP(6);
       const int wz = (eu >> 4) * 4, ue = eu & 15;
       float z[4];
 #pragma unroll
@@ -726,7 +752,9 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
       pub[er * 64 + eu] = (bf16_t)hb;
       tr[eu * 16 + er] = row_ok ? (bf16_t)hb : (bf16_t)0;
       tr[(64 + eu) * 16 + er] = row_ok ? (bf16_t)hdb : (bf16_t)0;
+      SSTAMP(7);
       __syncthreads();
+      SSTAMP(8);
       // publish h[t]: two waves, one 16-byte write-through store per lane; each storing wave
       // drains its own stores and then counts itself in (2 arrivals per workgroup)
       if (tid < 128) {
@@ -736,8 +764,10 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
           store16_sc1(rs_h, (unsigned)((((long)(t + 1) * B + r0 + prow) * W + u0 + seg * 8) * 2), v);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SSTAMP(9);
         if (lane == 0) __hip_atomic_fetch_add(cnt_own + (long)rb * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      SSTAMP(10);
       // off the hand-off chain: what only later launches read
       if (row_ok && alive) {
         Cl[(orow + B) * W + u0 + eu] = c;

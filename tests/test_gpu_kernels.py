@@ -43,7 +43,11 @@ def ptr(t):
 
 @pytest.mark.parametrize("M,N,K,out_mode,splits", [
     (128, 128, 64, 0, 1), (200, 136, 72, 0, 1), (64, 2048, 512, 1, 1), (1, 16, 8, 0, 1),
-    (512, 2048, 4096, 2, 8), (130, 70, 200, 2, 3), (4096, 256, 512, 0, 1)])
+    (512, 2048, 4096, 2, 8), (130, 70, 200, 2, 3), (4096, 256, 512, 0, 1),
+    # long-K kernel (256 x 128 tiles fed by LDS-DMA): whole tiles, ragged tiles, odd k-step counts
+    (512, 256, 16384, 2, 8), (300, 200, 8192, 2, 4), (256, 128, 8256, 2, 1), (100, 520, 12352, 2, 2),
+    # ... with plain stores: many-row shapes (row-contiguous f32 epilogue through LDS; ragged last row tile)
+    (65536, 128, 256, 0, 1), (33000, 256, 320, 0, 1), (32768, 384, 256, 1, 1)])
 def test_gemm_tn(M, N, K, out_mode, splits):
     torch = _torch()
     from ocrd_keraslm_amd.lib import hipabi
