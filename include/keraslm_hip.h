@@ -147,6 +147,8 @@ int kl_state_dist2(const kl_handle* h, int n, const float* pool, const int32_t* 
 int kl_trace_enable(kl_handle* h, int on);
 int kl_trace_read(kl_handle* h, int kind, int* n_launches, float* total_ms, int* persistent,
                   double* flops_per_launch);
+/* name of the kernel whose launches kind 0 (forward) / 1 (backward) timed, as rocprofv3 lists it */
+const char* kl_trace_kernel_name(kl_handle* h, int kind);
 
 /* Test hooks: the bare contraction kernels on caller buffers. */
 int kl_test_gemm_tn(const uint16_t* A, const uint16_t* B, void* C, const float* bias, int M, int N, int K, long lda,

@@ -109,6 +109,7 @@ struct kl_handle {
   size_t trace_used[2] = {0, 0};
   bool trace_open[2] = {false, false};
   bool trace_persistent[2] = {false, false};   // the timed launches were whole-window persistent scans
+  const char* trace_name[2] = {"lstm_fwd_step_kernel", "lstm_bwd_step_kernel"};   // kernel the timed launches ran
   void trace_begin(int kind, hipStream_t s) {
     if (!trace_on) return;
     if (trace_used[kind] == trace_ev[kind].size()) {
@@ -375,6 +376,7 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       KL_TRY(kl_launch_scan_fwd_wide(a, s));
       if (l == L - 1) {
         h->trace_persistent[0] = true;
+        h->trace_name[0] = "lstm_scan_fwd_wide_kernel";
         h->trace_flops[0] = (double)B * T * (2.0 * W * 4.0 * W);   // one layer's recurrent contraction
         h->trace_end(0, s);
       }
@@ -409,6 +411,7 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
     if (e == 0) {
       scanned = true;
       h->trace_persistent[0] = true;
+      h->trace_name[0] = "lstm_scan_fwd_kernel";
       h->trace_flops[0] = (double)B * T * (2.0 * (2.0 * L - 1.0) * W * 4.0 * W);   // U_l for all l, K_l for l >= 1
       h->trace_end(0, s);
     } else if (e != KL_ERR_SHAPE) {
@@ -752,6 +755,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       if (e != 0) return e;
       if (l == L - 1) {
         h->trace_persistent[1] = true;
+        h->trace_name[1] = wide ? "lstm_scan_bwd_wide_kernel" : "lstm_scan_bwd_kernel";
         h->trace_flops[1] = (double)B * T * (2.0 * W * 4.0 * W);   // one layer's recurrent contraction
         h->trace_end(1, s);
       }
@@ -782,6 +786,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
     if (e == 0) {
       bscanned = true;
       h->trace_persistent[1] = true;
+      h->trace_name[1] = "lstm_scan_bwd_kernel";
       h->trace_flops[1] = (double)B * T * (2.0 * (2.0 * L - 1.0) * W * 4.0 * W);
       h->trace_end(1, s);
     } else if (e != KL_ERR_SHAPE) {
@@ -1109,10 +1114,17 @@ extern "C" int kl_trace_enable(kl_handle* h, int on) {
   h->trace_on = on != 0;
   h->trace_used[0] = h->trace_used[1] = 0;
   h->trace_persistent[0] = h->trace_persistent[1] = false;
+  h->trace_name[0] = "lstm_fwd_step_kernel";
+  h->trace_name[1] = "lstm_bwd_step_kernel";
   return 0;
 }
 
 // kind 0 = forward cell-step launches, 1 = backward; call after synchronising the stream
+extern "C" const char* kl_trace_kernel_name(kl_handle* h, int kind) {
+  if (!h || kind < 0 || kind > 1) return "";
+  return h->trace_name[kind];
+}
+
 extern "C" int kl_trace_read(kl_handle* h, int kind, int* n_launches, float* total_ms, int* persistent,
                              double* flops_per_launch) {
   if (!h || kind < 0 || kind > 1 || !n_launches || !total_ms) return KL_ERR_ARG;

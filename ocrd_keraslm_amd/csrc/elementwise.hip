@@ -206,7 +206,23 @@ __global__ void reg_stats_kernel(const float* __restrict__ X, int R, int D, floa
   float* nr = scratch + 3 * D;
   for (int d = tid; d < D; d += nt) col[d] = 0.f;
   __syncthreads();
-  for (long e = (long)D + tid; e < (long)R * D; e += nt) atomicAdd(&col[e % D], X[e]);
+  if (D <= nt) {
+    // thread = (row group, column): strided rows summed in registers, one LDS add per thread
+    const int ng = nt / D, g = tid / D, d = tid % D;
+    if (g < ng) {
+      float a = 0.f;
+#pragma unroll 8
+      for (int r = 1 + g; r < R; r += ng) a += X[(long)r * D + d];
+      atomicAdd(&col[d], a);
+    }
+  } else {
+    for (int d = tid; d < D; d += nt) {
+      float a = 0.f;
+#pragma unroll 8
+      for (int r = 1; r < R; ++r) a += X[(long)r * D + d];
+      col[d] = a;
+    }
+  }
   float n1 = 0.f, n2 = 0.f;
   for (int r = tid >> 6; r < R; r += nt >> 6) {
     float a = 0.f;
