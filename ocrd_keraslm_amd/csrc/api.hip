@@ -65,6 +65,7 @@ struct WindowWs {
   float* reg_scratch;                 // statistics of the embedding regularisers
   // training only
   std::vector<bf16_t*> G, dZ, Hd;
+  std::vector<bf16_t*> Xhi, Xlo;      // inference: state planes exchanged by the split-precision scan [(T+1)B][W]
   std::vector<bf16_t*> HTf, HdT;      // transposed outputs written by the wide forward scans: [W][(T+1)B], [W][BT]
   bool ht_ready = false;              // ... valid for this window
   bf16_t *dZT, *HT, *dlogits, *dlogitsT, *OHT, *dEKT_bf, *dEK_bf;
@@ -213,6 +214,13 @@ size_t carve_window(const kl_handle* h, void* base, int B, int T, int training, 
   for (size_t l = 0; l < L; ++l) {
     o.H[l] = training ? (void*)cv.take<bf16_t>((BT + B) * W) : (void*)cv.take<float>((BT + B) * W);
     o.C[l] = cv.take<float>((BT + B) * W);
+  }
+  o.Xhi.assign(L, nullptr); o.Xlo.assign(L, nullptr);
+  if (!training) {
+    for (size_t l = 0; l < L; ++l) {
+      o.Xhi[l] = cv.take<bf16_t>((BT + B) * W);
+      o.Xlo[l] = cv.take<bf16_t>((BT + B) * W);
+    }
   }
   o.logits = cv.take<float>(BT * V);
   o.rowstat = cv.take<float>(BT * 2);
@@ -386,6 +394,30 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
   }
   if (!scanned)
     KL_TRY(kl_launch_p1_gather(d.EK, ctxk.data(), c.n_ctx, P + h->off_b[0], idx, ctx, B, T, 4 * W, w.P1, s));
+  // rating windows in split precision: one persistent launch for all layers and steps
+  if (!scanned && !training && split == KL_PREC_SPLIT && h->scan_enabled && L <= KL_SCAN_MAXL) {
+    KlScanFwdSplit a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.T = T; a.W = W; a.L = L;
+    for (int l = 0; l < L; ++l) {
+      a.UT_hi[l] = d.UT_hi[l]; a.UT_lo[l] = d.UT_lo[l];
+      a.KT_hi[l] = l > 0 ? d.KT_hi[l] : nullptr; a.KT_lo[l] = l > 0 ? d.KT_lo[l] : nullptr;
+      a.bias[l] = l > 0 ? P + h->off_b[l] : nullptr;
+      a.Xhi[l] = w.Xhi[l]; a.Xlo[l] = w.Xlo[l];
+      a.Hf[l] = (float*)w.H[l];
+      a.C[l] = w.C[l];
+    }
+    a.P1 = w.P1;
+    a.counters = w.scan_cnt;
+    a.status = w.scan_status;
+    // the carried-in state as (hi, lo) planes; hand-off counters zeroed write-through
+    for (int l = 0; l < L; ++l)
+      KL_TRY(kl_launch_f32_to_bf16_t((const float*)w.H[l], W, B, W, w.Xhi[l], w.Xlo[l], W, 0, s));
+    KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)L * ((B + 15) / 16) * T, s));
+    const int e = kl_launch_scan_fwd_split(a, s);
+    if (e == 0) scanned = true;
+    else if (e != KL_ERR_SHAPE) return e;
+  }
   // persistent scan (one launch for all layers and steps) where the shape allows it
   if (!scanned && training && h->scan_enabled && L <= KL_SCAN_MAXL) {
     KlScanFwd a;
@@ -606,6 +638,7 @@ static int forward_window_body(kl_handle* h, int B, int T, const int32_t* idx, c
   WindowWs w;
   if (ws_bytes < carve_window(h, ws, B, T, 0, &w)) return KL_ERR_WORKSPACE;
   const int W = h->cfg.width, V = h->cfg.voc_size, L = h->cfg.depth;
+  KL_TRY(kl_zero_async(w.scan_status, 4 * sizeof(unsigned), s));
   KL_TRY(forward_impl(h, B, T, idx, ctx, states, nullptr, 0, w, s));
   KlOperand op;
   memset(&op, 0, sizeof(op));
@@ -618,7 +651,9 @@ static int forward_window_body(kl_handle* h, int B, int T, const int32_t* idx, c
     if (B == 1) KL_TRY(hip_ok(hipMemcpyAsync(probs, w.logits, (size_t)T * V * sizeof(float), hipMemcpyDeviceToDevice, s)));
     else KL_TRY(kl_launch_rows_tm_to_bm(w.logits, V, probs, B, T, V, s));
   }
-  return 0;
+  // a timed-out hand-off in the persistent scan surfaces as loss_acc[3] != 0
+  if (loss_acc) hipLaunchKernelGGL(scan_status_kernel, dim3(1), dim3(64), 0, s, w.scan_status, loss_acc);
+  return hip_ok(hipGetLastError());
 }
 
 static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, const int32_t* ctx, const int32_t* tgt,

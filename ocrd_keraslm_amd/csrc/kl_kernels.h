@@ -83,6 +83,22 @@ struct KlScanFwd {
 };
 int kl_launch_scan_fwd(KlScanFwd args, hipStream_t stream);
 
+// split-precision (bf16 hi + lo) inference scan, all layers fused
+struct KlScanFwdSplit {
+  int B, T, W, L;
+  int n_rb, n_rg;                      // filled by the launcher
+  const bf16_t* UT_hi[KL_SCAN_MAXL]; const bf16_t* UT_lo[KL_SCAN_MAXL];   // [4W][W]
+  const bf16_t* KT_hi[KL_SCAN_MAXL]; const bf16_t* KT_lo[KL_SCAN_MAXL];   // [4W][W] (l >= 1)
+  const float* bias[KL_SCAN_MAXL];     // [4W] (l >= 1)
+  const float* P1;                     // [T*B][4W] layer-0 input contraction + bias
+  bf16_t* Xhi[KL_SCAN_MAXL]; bf16_t* Xlo[KL_SCAN_MAXL];   // [(T+1)B][W] exchanged state planes, block 0 = carried in
+  float* Hf[KL_SCAN_MAXL];             // [(T+1)B][W] f32 outputs (blocks 1..T written)
+  float* C[KL_SCAN_MAXL];              // [(T+1)B][W]: block 0 read, block T written
+  unsigned* counters;                  // [L][n_rb][T]
+  unsigned* status;
+};
+int kl_launch_scan_fwd_split(KlScanFwdSplit args, hipStream_t stream);
+
 // one layer per launch, 64-unit workgroups (B >= 512 streams)
 struct KlScanFwdWide {
   int B, T, W;

@@ -283,6 +283,182 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_fwd_kernel(const KlScanFwd a
   }
 }
 
+// ---------------------------------------------------------------- forward scan, split precision (rating)
+// The inference twin of lstm_scan_fwd_kernel for rate / rate2 / test windows: every
+// operand is a bf16 (hi, lo) pair and every contraction three MFMAs (hi.hi + lo.hi +
+// hi.lo), i.e. ~f32 accuracy with f32 accumulation.  The state tile is exchanged as two
+// bf16 planes (Xhi, Xlo); the f32 outputs the logits need are stored off the hand-off
+// chain.  Weights take 4 x the registers of the training kernel (U, K) x (hi, lo):
+// one 256-thread workgroup per CU.
+template <int KSTEPS, int MAXRB>
+__global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_kernel(const KlScanFwdSplit a) {
+  constexpr int KQ = KSTEPS / 4;
+  constexpr int W = KSTEPS * 32;
+  constexpr int NUG = W / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int id = blockIdx.x;
+  const int n_rg = a.n_rg, n_rb = a.n_rb, B = a.B, T = a.T;
+  const int l = id / (NUG * n_rg);
+  id -= l * NUG * n_rg;
+  const int ug = id / n_rg, rg = id % n_rg;
+  const int u0 = ug * 16;
+  const bool has_in = l > 0;
+
+  __shared__ float zt[4][4][16][17];
+  __shared__ int ok_flag;
+
+  const int kq = (lane >> 4) * 8;
+  uint4 bu[2][4][KQ], bk[2][4][KQ];     // [hi/lo][gate][k-step]
+  {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const long wrow = ((long)g * W + u0 + (lane & 15)) * W + (wave * KQ) * 32 + kq;
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) {
+        bu[0][g][j] = *reinterpret_cast<const uint4*>(a.UT_hi[l] + wrow + j * 32);
+        bu[1][g][j] = *reinterpret_cast<const uint4*>(a.UT_lo[l] + wrow + j * 32);
+        bk[0][g][j] = has_in ? *reinterpret_cast<const uint4*>(a.KT_hi[l] + wrow + j * 32) : uint4{0, 0, 0, 0};
+        bk[1][g][j] = has_in ? *reinterpret_cast<const uint4*>(a.KT_lo[l] + wrow + j * 32) : uint4{0, 0, 0, 0};
+      }
+    }
+  }
+  const int er = tid >> 4, eu = tid & 15;
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (has_in) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = a.bias[l][(long)g * W + u0 + eu];
+  }
+  float* Cl = a.C[l];
+  float* Hf = a.Hf[l];
+  bf16_t* Xhi = a.Xhi[l];
+  bf16_t* Xlo = a.Xlo[l];
+  const float* P1 = a.P1;
+  unsigned* status = a.status;
+  float c_reg[MAXRB];
+#pragma unroll
+  for (int i = 0; i < MAXRB; ++i) {
+    const int rb = rg + i * n_rg;
+    const int row = min(rb * 16 + er, B - 1);
+    c_reg[i] = (rb < n_rb) ? Cl[(long)row * W + u0 + eu] : 0.f;
+  }
+  const long BW = (long)B * W;
+  const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc(Xhi, (long)(T + 1) * BW * 2);
+  const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(Xlo, (long)(T + 1) * BW * 2);
+  // input rows of step t = outputs of the layer below at block t + 1
+  const __amdgpu_buffer_rsrc_t rs_ihi = make_rsrc(has_in ? a.Xhi[l - 1] + BW : Xhi, (long)T * BW * 2);
+  const __amdgpu_buffer_rsrc_t rs_ilo = make_rsrc(has_in ? a.Xlo[l - 1] + BW : Xlo, (long)T * BW * 2);
+  unsigned* cnt_own = a.counters + (long)l * n_rb * T;
+  unsigned* cnt_in = a.counters + (long)(has_in ? l - 1 : 0) * n_rb * T;
+  bool alive = true;
+
+  for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int i = 0; i < MAXRB; ++i) {
+      const int rb = rg + i * n_rg;
+      if (rb >= n_rb) continue;
+      const int r0 = rb * 16;
+      const int erow = min(r0 + er, B - 1);
+      float zin[4];
+      if (!has_in) {
+        const float* p = P1 + ((long)t * B + erow) * 4 * W + u0 + eu;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) zin[g] = p[(long)g * W];
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) zin[g] = bias4[g];
+      }
+      if (tid == 0) {
+        bool ok = alive;
+        if (ok && has_in) ok = poll_counter(cnt_in + (long)rb * T + t, NUG, status);
+        if (ok && t > 0) ok = poll_counter(cnt_own + (long)rb * T + (t - 1), NUG, status);
+        ok_flag = ok ? 1 : 0;
+      }
+      __syncthreads();
+      alive = ok_flag != 0;
+      const int arow = min(r0 + (lane & 15), B - 1);
+      const unsigned abase = (unsigned)((((long)t * B + arow) * W + (wave * KQ) * 32 + kq) * 2);
+      f32x4 acc[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (alive) {
+        uint4 ahi[KQ], alo[KQ];
+        if (has_in) {
+#pragma unroll
+          for (int j = 0; j < KQ; ++j) {
+            ahi[j] = load16_sc1(rs_ihi, abase + j * 64);
+            alo[j] = load16_sc1(rs_ilo, abase + j * 64);
+          }
+#pragma unroll
+          for (int j = 0; j < KQ; ++j) {
+            frag16 fh, fl;
+            fh.u = ahi[j];
+            fl.u = alo[j];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              frag16 wh, wl;
+              wh.u = bk[0][g][j];
+              wl.u = bk[1][g][j];
+              acc[g] = mfma16(fl.v, wh.v, acc[g]);
+              acc[g] = mfma16(fh.v, wl.v, acc[g]);
+              acc[g] = mfma16(fh.v, wh.v, acc[g]);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+          ahi[j] = load16_sc1(rs_hi, abase + j * 64);
+          alo[j] = load16_sc1(rs_lo, abase + j * 64);
+        }
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+          frag16 fh, fl;
+          fh.u = ahi[j];
+          fl.u = alo[j];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            frag16 wh, wl;
+            wh.u = bu[0][g][j];
+            wl.u = bu[1][g][j];
+            acc[g] = mfma16(fl.v, wh.v, acc[g]);
+            acc[g] = mfma16(fh.v, wl.v, acc[g]);
+            acc[g] = mfma16(fh.v, wh.v, acc[g]);
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zt[wave][g][(lane >> 4) * 4 + r][lane & 15] = acc[g][r];
+      __syncthreads();
+      float z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) z[g] = zin[g] + zt[0][g][er][eu] + zt[1][g][er][eu] + zt[2][g][er][eu] + zt[3][g][er][eu];
+      const float gi = sigmoidf_(z[0]), gf = sigmoidf_(z[1]), gg = tanhf_(z[2]), go = sigmoidf_(z[3]);
+      const float c = gf * c_reg[i] + gi * gg;
+      c_reg[i] = c;
+      const float h = go * tanhf_(c);
+      const bool row_ok = (r0 + er) < B;
+      const unsigned hh = f2bf(h);
+      const unsigned hl = f2bf(h - bf2f((bf16_t)hh));
+      const unsigned hh_n = __shfl_xor(hh, 1), hl_n = __shfl_xor(hl, 1);
+      const long orow = (long)t * B + r0 + er;
+      if (row_ok && alive && (eu & 1) == 0) {
+        __hip_atomic_store(reinterpret_cast<unsigned*>(Xhi + (orow + B) * W + u0 + eu), hh | (hh_n << 16), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned*>(Xlo + (orow + B) * W + u0 + eu), hl | (hl_n << 16), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(cnt_own + (long)rb * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (row_ok && alive) {
+        Hf[(orow + B) * W + u0 + eu] = h;
+        if (t == T - 1) Cl[(orow + B) * W + u0 + eu] = c;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- backward scan
 // block = 256 threads; output tile = dh of 16 rows x 16 units; wave w contracts
 // over gate w's K range (W of the 4W columns) of dZ_l[t+1] . U_l^T and, below the
@@ -925,5 +1101,24 @@ int kl_launch_scan_fwd_wide(KlScanFwdWide a, hipStream_t stream) {
   if (W == 512) { if (per_wg == 1) KL_WIDE_CASE(16, 1); else if (per_wg == 2) KL_WIDE_CASE(16, 2); else KL_WIDE_CASE(16, 4); }
   else { if (per_wg == 1) KL_WIDE_CASE(8, 1); else if (per_wg == 2) KL_WIDE_CASE(8, 2); else KL_WIDE_CASE(8, 4); }
 #undef KL_WIDE_CASE
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+// Split-precision inference scan (all layers fused).  KL_ERR_SHAPE = not applicable.
+int kl_launch_scan_fwd_split(KlScanFwdSplit a, hipStream_t stream) {
+  const int W = a.W;
+  if (W != 512 && W != 256 && W != 128) return KL_ERR_SHAPE;
+  if (a.L < 1 || a.L > KL_SCAN_MAXL || a.B < 1 || a.T < 1) return KL_ERR_SHAPE;
+  const int col_tasks = a.L * (W / 16);
+  if (col_tasks > 256) return KL_ERR_SHAPE;
+  if ((long)(a.T + 1) * a.B * W * 2 > 0x7fffffffL) return KL_ERR_SHAPE;
+  a.n_rb = (a.B + 15) / 16;
+  int g = 256 / col_tasks;               // one workgroup per CU (the weights fill the register file)
+  if (g > a.n_rb) g = a.n_rb;
+  a.n_rg = g;
+  const int per_wg = (a.n_rb + g - 1) / g;
+  if (per_wg > 4) return KL_ERR_SHAPE;
+  dim3 grid(col_tasks * g), block(256);
+  KL_SCAN_DISPATCH(lstm_scan_fwd_split_kernel);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }

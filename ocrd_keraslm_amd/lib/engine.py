@@ -190,6 +190,9 @@ class HipLM:
             hipabi.check(self.lib.kl_forward_window(self.handle, B, T, _ptr(idx_d), _ptr(ctx_d), _ptr(tgt_d),
                                                     _ptr(self.states), _ptr(probs), _ptr(self.loss_acc), _ptr(ws),
                                                     ws.numel(), self._stream()), "kl_forward_window")
+            if want_probs and float(self.loss_acc[3].item()) != 0.0:
+                # (the caller reads the probabilities next, so this sync is not an extra one)
+                raise hipabi.KlError("persistent scan hand-off timed out (kl_forward_window)")
         return probs
 
     def draw_dropout_masks(self, B):

@@ -158,7 +158,10 @@ def test_step_batch_bf16_within_1e3():
 
 @pytest.mark.parametrize("depth,width,voc,B,T,n_ctx", [(2, 64, 50, 1, 32, 1), (2, 128, 60, 3, 16, 1),
                                                        (1, 128, 40, 1, 64, 1), (2, 512, 256, 2, 24, 1),
-                                                       (3, 64, 30, 2, 7, 2)])
+                                                       (3, 64, 30, 2, 7, 2),
+                                                       # persistent split-precision scan: row blocks > workgroups, 3 layers,
+                                                       # the cfg2 rating window
+                                                       (3, 256, 30, 40, 9, 2), (2, 512, 64, 200, 5, 1), (2, 512, 256, 1, 256, 1)])
 def test_forward_window_parity(depth, width, voc, B, T, n_ctx):
     """F1-F6 stateful windows (rating.py:490, 516): two consecutive windows carry state."""
     from ocrd_keraslm_amd.lib import hipabi
