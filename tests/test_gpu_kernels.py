@@ -109,7 +109,9 @@ def make_model(depth, width, voc, n_ctx=1, seed=4, emb_std=0.5):
 @pytest.mark.parametrize("depth,width,voc,n,n_ctx", [(2, 64, 50, 5, 1), (2, 512, 256, 70, 1), (1, 128, 40, 33, 1),
                                                      (3, 96, 30, 17, 2),
                                                      # n >= 256: big-tile path (step_big.hip)
-                                                     (2, 512, 256, 300, 1), (3, 96, 30, 260, 2), (1, 128, 40, 257, 1)])
+                                                     (2, 512, 256, 300, 1), (3, 96, 30, 260, 2), (1, 128, 40, 257, 1),
+                                                     # cfg5 topology (small and big-n paths)
+                                                     (4, 1024, 64, 20, 2), (4, 1024, 64, 272, 2)])
 def test_step_batch_parity(depth, width, voc, n, n_ctx):
     """S1 (rating.py:578-639): chained incremental steps through pool slots."""
     torch = _torch()
@@ -161,7 +163,9 @@ def test_step_batch_bf16_within_1e3():
                                                        (3, 64, 30, 2, 7, 2),
                                                        # persistent split-precision scan: row blocks > workgroups, 3 layers,
                                                        # the cfg2 rating window
-                                                       (3, 256, 30, 40, 9, 2), (2, 512, 64, 200, 5, 1), (2, 512, 256, 1, 256, 1)])
+                                                       (3, 256, 30, 40, 9, 2), (2, 512, 64, 200, 5, 1), (2, 512, 256, 1, 256, 1),
+                                                       # cfg5 topology
+                                                       (4, 1024, 64, 2, 6, 2)])
 def test_forward_window_parity(depth, width, voc, B, T, n_ctx):
     """F1-F6 stateful windows (rating.py:490, 516): two consecutive windows carry state."""
     from ocrd_keraslm_amd.lib import hipabi
@@ -198,7 +202,9 @@ def test_forward_window_parity(depth, width, voc, B, T, n_ctx):
                                                                  (2, 512, 256, 64, 16, 1, True),
                                                                  # many row blocks: layer-sequential backward with wide workgroups
                                                                  (2, 512, 64, 144, 6, 1, True), (2, 256, 40, 272, 4, 1, True),
-                                                                 (3, 256, 30, 176, 5, 1, True)])
+                                                                 (3, 256, 30, 176, 5, 1, True),
+                                                                 # cfg5 topology: depth 4, width 1024, two context variables
+                                                                 (4, 1024, 64, 4, 4, 2, True)])
 def test_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks):
     check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks)
 
