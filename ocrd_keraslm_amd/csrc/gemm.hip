@@ -187,17 +187,29 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
       : "memory");
 }
 
-template <int OUT, bool ILV>
-__global__ __launch_bounds__(LTHREADS, 1) void gemm_tn_long_kernel(
+// WM x WN waves, each 64 rows x (128 / WN) columns: (4, 2) = the 256 x 128 tile for big grids,
+// (1, 4) = a 64 x 128 tile (4 waves, 72 KiB) for M ~ 1e3 shapes (the incremental step's GEMMs),
+// where 256-row tiles would leave 3/4 of the CUs idle.  Either way a wave issues 6 LDS-DMA
+// pieces per k-step (the counted vmcnt below).
+template <int OUT, bool ILV, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, int M, int N, int K, long lda, long ldb, long ldc,
     int k_per_split, float alpha) {
+  constexpr int NW = WM * WN;
+  constexpr int TBM = 64 * WM;                 // tile rows
+  constexpr int WCOLS = LBN / WN;              // columns per wave
+  constexpr int NT = WCOLS / 16;               // column fragments per wave
+  constexpr int PA = TBM / 8 / NW;             // A pieces (8 rows each) per wave and k-step
+  constexpr int PB = LBN / 8 / NW;             // B pieces
+  static_assert(PA + PB == 6, "the counted vmcnt assumes 6 pieces per wave");
+  constexpr int STAGE_BYTES = (TBM + LBN) * 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * LBM;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * TBM;
   const int n0 = blockIdx.x * LBN;
   const int kbeg = blockIdx.z * k_per_split;
   const int kend = min(K, kbeg + k_per_split);
@@ -209,33 +221,24 @@ __global__ __launch_bounds__(LTHREADS, 1) void gemm_tn_long_kernel(
       __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A + (long)m0 * lda), 0, clamp31(((long)(M - m0 - 1) * lda + K) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B + (long)n0 * ldb), 0, clamp31(((long)(N - n0 - 1) * ldb + K) * 2), 0x00020000);
-  // per-lane source offsets of this wave's pieces: A rows wave*32 + j*8 + (lane>>3), B rows wave*16 + j*8 + (lane>>3)
-  unsigned voA[4], voB[2];
+  // per-lane source offsets of this wave's pieces (rows wave*8*P + j*8 + (lane>>3)), swizzled chunk
+  unsigned vo[6];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = wave * 32 + j * 8 + (lane >> 3);
+  for (int j = 0; j < 6; ++j) {
+    const int row = j < PA ? wave * 8 * PA + j * 8 + (lane >> 3) : wave * 8 * PB + (j - PA) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
-    voA[j] = (unsigned)((long)row * lda * 2 + c * 16);
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = wave * 16 + j * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    voB[j] = (unsigned)((long)row * ldb * 2 + c * 16);
+    vo[j] = (unsigned)((long)row * (j < PA ? lda : ldb) * 2 + c * 16);
   }
   const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
-  // half 0 = A pieces 0..2, half 1 = A piece 3 + both B pieces (issued between the two MFMA groups of a k-step)
+  // pieces 0..2 and 3..5 are issued between the two MFMA groups of a k-step
   auto issue_half = [&](int kt, int stage, int half) {
     const int soff = (kbeg + kt * BK) * 2;
-    const unsigned sa = lds0 + stage * LSTAGE_BYTES + wave * 32 * 128;
-    const unsigned sb = lds0 + stage * LSTAGE_BYTES + LBM * 128 + wave * 16 * 128;
-    if (half == 0) {
+    const unsigned sa = lds0 + stage * STAGE_BYTES + wave * 8 * PA * 128;
+    const unsigned sb = lds0 + stage * STAGE_BYTES + TBM * 128 + wave * 8 * PB * 128;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) glds16(rsA, voA[j], soff, sa + j * 1024);
-    } else {
-      glds16(rsA, voA[3], soff, sa + 3 * 1024);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) glds16(rsB, voB[j], soff, sb + j * 1024);
+    for (int j = half * 3; j < half * 3 + 3; ++j) {
+      if (j < PA) glds16(rsA, vo[j], soff, sa + j * 1024);
+      else glds16(rsB, vo[j], soff, sb + (j - PA) * 1024);
     }
   };
   auto issue = [&](int kt, int stage) {
@@ -243,11 +246,11 @@ __global__ __launch_bounds__(LTHREADS, 1) void gemm_tn_long_kernel(
     issue_half(kt, stage, 1);
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][NT];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (nkt > 0) issue(0, 0);
   if (nkt > 1) issue(1, 1);
@@ -260,22 +263,22 @@ __global__ __launch_bounds__(LTHREADS, 1) void gemm_tn_long_kernel(
     const bool more = kt + 2 < nkt;
     const int nstage = stage >= 1 ? stage - 1 : LSTAGES - 1;   // (kt+2) % 3 == (stage+2) % 3
     if (!ILV && more) issue(kt + 2, nstage);
-    const unsigned char* a_base = smem + stage * LSTAGE_BYTES;
-    const unsigned char* b_base = a_base + LBM * 128;
+    const unsigned char* a_base = smem + stage * STAGE_BYTES;
+    const unsigned char* b_base = a_base + TBM * 128;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      frag16 fa[4], fb[4];
+      frag16 fa[4], fb[NT];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         fa[i].u = *reinterpret_cast<const uint4*>(a_base + lds_off(wm * 64 + i * 16 + fr, s * 4 + fq));
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        fb[j].u = *reinterpret_cast<const uint4*>(b_base + lds_off(wn * 64 + j * 16 + fr, s * 4 + fq));
+      for (int j = 0; j < NT; ++j)
+        fb[j].u = *reinterpret_cast<const uint4*>(b_base + lds_off(wn * WCOLS + j * 16 + fr, s * 4 + fq));
       if (ILV && more) issue_half(kt + 2, nstage, s);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fa[i].v, fb[j].v, acc[i][j]);
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fa[i].v, fb[j].v, acc[i][j]);
     }
     stage = stage + 1 < LSTAGES ? stage + 1 : 0;
   }
@@ -290,18 +293,19 @@ __global__ __launch_bounds__(LTHREADS, 1) void gemm_tn_long_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          ct[(wm * 64 + i * 16 + fq * 4 + r) * LDP + wn * 64 + j * 16 + fr] = acc[i][j][r] * alpha;
+          ct[(wm * 64 + i * 16 + fq * 4 + r) * LDP + wn * WCOLS + j * 16 + fr] = acc[i][j][r] * alpha;
     __syncthreads();
     const int c4 = (tid & 31) * 4;
     f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
     if (bias != nullptr) bv = f32x4{bias[n0 + c4], bias[n0 + c4 + 1], bias[n0 + c4 + 2], bias[n0 + c4 + 3]};
     float* Cf = reinterpret_cast<float*>(Cv);
+    constexpr int RPP = 64 * NW / 32;                  // rows per pass
 #pragma unroll 4
-    for (int p = 0; p < LBM / 16; ++p) {
-      const int row = p * 16 + (tid >> 5);
+    for (int p = 0; p < TBM / RPP; ++p) {
+      const int row = p * RPP + (tid >> 5);
       if (m0 + row < M) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(ct + row * LDP + c4);
         *reinterpret_cast<f32x4*>(Cf + (long)(m0 + row) * ldc + n0 + c4) = v + bv;
@@ -312,8 +316,8 @@ __global__ __launch_bounds__(LTHREADS, 1) void gemm_tn_long_kernel(
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wn * 64 + j * 16 + fr;
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + wn * WCOLS + j * 16 + fr;
       if (col >= N) continue;
       const float bv = (bias != nullptr && blockIdx.z == 0) ? bias[col] : 0.f;
 #pragma unroll
@@ -333,30 +337,36 @@ __global__ __launch_bounds__(LTHREADS, 1) void gemm_tn_long_kernel(
   }
 }
 
-int launch_long(int out_mode, dim3 grid, hipStream_t stream, const bf16_t* A, const bf16_t* B, void* C, const float* bias,
-                int M, int N, int K, long lda, long ldb, long ldc, int k_per_split, float alpha) {
-  const size_t lds = (size_t)LSTAGES * LSTAGE_BYTES;
+template <int WM, int WN>
+int launch_long_t(int out_mode, dim3 grid, hipStream_t stream, const bf16_t* A, const bf16_t* B, void* C, const float* bias,
+                  int M, int N, int K, long lda, long ldb, long ldc, int k_per_split, float alpha) {
+  const size_t lds = (size_t)LSTAGES * (64 * WM + LBN) * 128;
   static const bool ilv = !(getenv("KL_GEMM_ILV") && getenv("KL_GEMM_ILV")[0] == '0');
 #define KL_LONG_CASE(O)                                                                                                  \
   do {                                                                                                                   \
     static bool attr_set = false;                                                                                        \
     if (!attr_set) {                                                                                                     \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<O, true>),                              \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<O, true, WM, WN>),                      \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH; \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<O, false>),                             \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<O, false, WM, WN>),                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH; \
       attr_set = true;                                                                                                   \
     }                                                                                                                    \
-    if (ilv) hipLaunchKernelGGL((gemm_tn_long_kernel<O, true>), grid, dim3(LTHREADS), lds, stream, A, B, C, bias, M, N,  \
-                                K, lda, ldb, ldc, k_per_split, alpha);                                                   \
-    else hipLaunchKernelGGL((gemm_tn_long_kernel<O, false>), grid, dim3(LTHREADS), lds, stream, A, B, C, bias, M, N,     \
-                            K, lda, ldb, ldc, k_per_split, alpha);                                                       \
+    if (ilv) hipLaunchKernelGGL((gemm_tn_long_kernel<O, true, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, A, B, C,  \
+                                bias, M, N, K, lda, ldb, ldc, k_per_split, alpha);                                       \
+    else hipLaunchKernelGGL((gemm_tn_long_kernel<O, false, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, A, B, C,     \
+                            bias, M, N, K, lda, ldb, ldc, k_per_split, alpha);                                           \
   } while (0)
   if (out_mode == 0) KL_LONG_CASE(0);
   else if (out_mode == 1) KL_LONG_CASE(1);
   else KL_LONG_CASE(2);
 #undef KL_LONG_CASE
   return 0;
+}
+
+int launch_long(int out_mode, dim3 grid, hipStream_t stream, const bf16_t* A, const bf16_t* B, void* C, const float* bias,
+                int M, int N, int K, long lda, long ldb, long ldc, int k_per_split, float alpha) {
+  return launch_long_t<4, 2>(out_mode, grid, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, k_per_split, alpha);
 }
 
 }  // namespace
@@ -388,6 +398,14 @@ int kl_launch_gemm_tn(const bf16_t* A, const bf16_t* B, void* C, const float* bi
   if (long_mode >= 2 && long_ok && splits == 1 && K >= 256 && (long)((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) >= 256) {
     dim3 grid((N + LBN - 1) / LBN, (M + LBM - 1) / LBM, 1);
     const int e = launch_long(out_mode, grid, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, K, alpha);
+    if (e != 0) return e;
+    return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+  }
+  // M ~ 1e3 rows (the incremental step's GEMMs): 64 x 128 tiles of the same ring
+  if (long_mode >= 2 && long_ok && splits == 1 && K >= 512 && M >= 256 &&
+      (long)((M + 63) / 64) * ((N + LBN - 1) / LBN) >= 64) {
+    dim3 grid((N + LBN - 1) / LBN, (M + 63) / 64, 1);
+    const int e = launch_long_t<1, 4>(out_mode, grid, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, K, alpha);
     if (e != 0) return e;
     return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
   }

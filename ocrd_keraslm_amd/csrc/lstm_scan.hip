@@ -67,6 +67,12 @@ __device__ __forceinline__ uint4 load16_sc1(__amdgpu_buffer_rsrc_t r, unsigned b
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16);
   return uint4{v.x, v.y, v.z, v.w};
 }
+// wave-uniform 4-byte load through the scalar cache (data written by an earlier launch only)
+__device__ __forceinline__ int sload_i32(const int* p) {
+  int v;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
 __device__ __forceinline__ void store16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, uint4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, r, (int)byte_off, 0, 16);
 }
@@ -605,6 +611,10 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
   }
 }
 
+// dynamic LDS of the wide kernels up to (excluding) the per-row-block state slots [MAXRB][1024] f32
+#define KL_BWD_WIDE_LDS(KS) (4 * (KS) * 1024 + 16 * 16 * 17 * 4 + 2 * 4 * 64 * 16 * 2 + 16)
+#define KL_FWD_WIDE_LDS(KS) ((KS) * 1024 + 16 * 4 * 16 * 17 * 4 + 2 * 64 * 16 * 2 + 16 * 64 * 2 + 16)
+
 // ---------------------------------------------------------------- backward scan, one layer, wide workgroups
 // For many row blocks the thin kernel above is bound by fabric traffic: W/16 workgroups
 // per row block each pull the same 16 x 4W dZ tile with write-through reads (stamps:
@@ -641,9 +651,13 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
     for (int j = 0; j < KSTEPS; ++j) bu[j] = *reinterpret_cast<const uint4*>(a.Un[0] + wrow + j * 32 + kq);
   }
   const int er = tid >> 6, eu = tid & 63;          // epilogue thread = (row, unit of 64)
-  float dc_reg[MAXRB];
-#pragma unroll
-  for (int i = 0; i < MAXRB; ++i) dc_reg[i] = 0.f;
+  // running dc of this thread's (row, unit) per row block: a register for one block, else LDS
+  // slots (the row-block loop stays rolled: unrolled it spilled 7-47 VGPRs at the 128 cap)
+  float dc_one = 0.f;
+  float* dc_slot = reinterpret_cast<float*>(smem + KL_BWD_WIDE_LDS(KSTEPS)) + tid;
+  if (MAXRB > 1) {
+    for (int i = 0; i < MAXRB; ++i) dc_slot[i * 1024] = 0.f;
+  }
   float dbacc[4] = {0.f, 0.f, 0.f, 0.f};   // bias gradient: this thread's (unit, gate) summed over its rows and steps
   const long BW = (long)B * W;
   const bf16_t* Gl = a.G[0];
@@ -657,13 +671,17 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
   const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(dZl, (long)T * BW * 4 * 2);
   unsigned* cnt_own = a.counters;
   bool alive = true;
+  int pend = -1;       // publishing waves: counter index of stores issued but not yet signalled
+  // (deferring needs a second row block whose publish releases the first one's signal: a workgroup
+  // with a single block would wait for its own deferred signal)
+  const bool defer = rg + n_rg < n_rb;
 #ifdef KL_STAMP
   const int STAMP_WG = 0;
   unsigned long long last_ = clock64();
 #endif
 
   for (int t = T - 1; t >= 0; --t) {
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < MAXRB; ++i) {
       const int rb = rg + i * n_rg;
       if (rb >= n_rb) continue;
@@ -716,8 +734,9 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
       dh += zt[wz][er][eu & 15] + zt[wz + 1][er][eu & 15] + zt[wz + 2][er][eu & 15] + zt[wz + 3][er][eu & 15];
       const float gi = bf2f(g0), gf = bf2f(g1), gg = bf2f(g2), go = bf2f(g3);
       const float tc = fast_tanh(c);
-      const float dc = dh * go * (1.f - tc * tc) + dc_reg[i];
-      dc_reg[i] = dc * gf;
+      const float dc = dh * go * (1.f - tc * tc) + (MAXRB > 1 ? dc_slot[i * 1024] : dc_one);
+      if (MAXRB > 1) dc_slot[i * 1024] = dc * gf;
+      else dc_one = dc * gf;
       const float d_o = dh * tc, d_i = dc * gg, d_g = dc * gi, d_f = dc * cp;
       const unsigned z0 = f2bf(d_i * gi * (1.f - gi)), z1 = f2bf(d_f * gf * (1.f - gf));
       const unsigned z2 = f2bf(d_g * (1.f - gg * gg)), z3 = f2bf(d_o * go * (1.f - go));
@@ -741,14 +760,24 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
       // publish dZ[t]: eight waves, one 16-byte write-through store per lane; each storing
       // wave drains its own stores and then counts itself in (8 arrivals per workgroup)
       if (tid < 512) {
+        // (several row blocks per workgroup: the previous block's drain + signal happen here, its
+        // write-through latency hidden behind this block's step)
+        if (MAXRB > 1 && pend >= 0) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(cnt_own + pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         const int g = tid >> 7, prow = (tid >> 3) & 15, seg = tid & 7;
         if (alive && r0 + prow < B) {
           const uint4 v = *reinterpret_cast<const uint4*>(pub + (g * 16 + prow) * 64 + seg * 8);
           store16_sc1(rs_own, (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2), v);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        SSTAMP(25);
-        if (lane == 0) __hip_atomic_fetch_add(cnt_own + (long)rb * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (MAXRB > 1 && defer) {
+          pend = rb * T + t;           // drained and signalled at the next publish
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          SSTAMP(25);
+          if (lane == 0) __hip_atomic_fetch_add(cnt_own + (long)rb * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       SSTAMP(26);
       if (dZT && alive && tid >= 512) {
@@ -766,6 +795,10 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
         }
       }
     }
+  }
+  if (MAXRB > 1 && tid < 512 && pend >= 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(cnt_own + pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // db[g*W + u] += sum over this workgroup's rows and all steps (16 partials per column meet in LDS)
   if (a.db) {
@@ -834,24 +867,32 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias4[g] = a.bias[(long)g * W + u0 + eu];
   }
-  float c_reg[MAXRB];
-#pragma unroll
+  // cell state of this thread's (row, unit) per row block: a register for one block, else LDS
+  // slots (the row-block loop stays rolled: unrolled it spilled 19-47 VGPRs at the 128 cap)
+  float c_one = 0.f;
+  float* c_slot = reinterpret_cast<float*>(smem + KL_FWD_WIDE_LDS(KSTEPS)) + tid;
   for (int i = 0; i < MAXRB; ++i) {
     const int rb = rg + i * n_rg;
     const int row = min(rb * 16 + er, B - 1);
-    c_reg[i] = (rb < n_rb) ? Cl[(long)row * W + u0 + eu] : 0.f;
+    const float c0 = (rb < n_rb) ? Cl[(long)row * W + u0 + eu] : 0.f;
+    if (MAXRB > 1) c_slot[i * 1024] = c0;
+    else c_one = c0;
   }
   const long BW = (long)B * W;
   const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(Hl, (long)(T + 1) * BW * 2);
   unsigned* cnt_own = a.counters;
   bool alive = true;
+  int pend = -1;       // publishing waves: counter index of stores issued but not yet signalled
+  // (deferring needs a second row block whose publish releases the first one's signal: a workgroup
+  // with a single block would wait for its own deferred signal)
+  const bool defer = rg + n_rg < n_rb;
 #ifdef KL_STAMP
   const int STAMP_WG = 0;
   unsigned long long last_ = clock64();
 #endif
 
   for (int t = 0; t < T; ++t) {
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < MAXRB; ++i) {
       const int rb = rg + i * n_rg;
       if (rb >= n_rb) continue;
@@ -863,12 +904,15 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
 #pragma unroll
         for (int g = 0; g < 4; ++g) zin[g] = p[(long)g * W];
       } else {
-        const long src = (long)erow * T + t;
-        const float* e = a.EK + (long)a.idx[src] * 4 * W + u0 + eu;
+        // the row of an epilogue thread is its wave (er = tid >> 6): the ids are wave-uniform and
+        // come through the scalar cache, so the table loads below do not queue behind the
+        // previous step's vector stores (in-order vmcnt: 0.8 us of a 4.9 us step)
+        const long src = (long)min(r0 + __builtin_amdgcn_readfirstlane(er), B - 1) * T + t;
+        const float* e = a.EK + (long)sload_i32(a.idx + src) * 4 * W + u0 + eu;
 #pragma unroll
         for (int g = 0; g < 4; ++g) zin[g] = bias4[g] + e[(long)g * W];
         for (int n = 0; n < a.n_ctx; ++n) {
-          const float* q = a.CtxK[n] + (long)a.ctx[src * a.n_ctx + n] * 4 * W + u0 + eu;
+          const float* q = a.CtxK[n] + (long)sload_i32(a.ctx + src * a.n_ctx + n) * 4 * W + u0 + eu;
 #pragma unroll
           for (int g = 0; g < 4; ++g) zin[g] += q[(long)g * W];
         }
@@ -919,8 +963,9 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
 #pragma unroll
       for (int g = 0; g < 4; ++g) z[g] = zin[g] + zt[wz][g][er][ue] + zt[wz + 1][g][er][ue] + zt[wz + 2][g][er][ue] + zt[wz + 3][g][er][ue];
       const float gi = fast_sigmoid(z[0]), gf = fast_sigmoid(z[1]), gg = fast_tanh(z[2]), go = fast_sigmoid(z[3]);
-      const float c = gf * c_reg[i] + gi * gg;
-      c_reg[i] = c;
+      const float c = gf * (MAXRB > 1 ? c_slot[i * 1024] : c_one) + gi * gg;
+      if (MAXRB > 1) c_slot[i * 1024] = c;
+      else c_one = c;
       const float h = go * fast_tanh(c);
       const bool row_ok = (r0 + er) < B;
       const unsigned hb = f2bf(h), hdb = f2bf(h * mk);
@@ -934,14 +979,25 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
       // publish h[t]: two waves, one 16-byte write-through store per lane; each storing wave
       // drains its own stores and then counts itself in (2 arrivals per workgroup)
       if (tid < 128) {
+        // With several row blocks per workgroup the drain of one block's stores is deferred to
+        // the next block's publish: the other block's whole step hides the write-through latency
+        // instead of every wave waiting for it at the next barrier.
+        if (MAXRB > 1 && pend >= 0) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(cnt_own + pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         const int prow = tid >> 3, seg = tid & 7;
         if (alive && r0 + prow < B) {
           const uint4 v = *reinterpret_cast<const uint4*>(pub + prow * 64 + seg * 8);
           store16_sc1(rs_h, (unsigned)((((long)(t + 1) * B + r0 + prow) * W + u0 + seg * 8) * 2), v);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        SSTAMP(9);
-        if (lane == 0) __hip_atomic_fetch_add(cnt_own + (long)rb * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (MAXRB > 1 && defer) {
+          pend = rb * T + t;           // drained and signalled at the next publish (see above)
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          SSTAMP(9);
+          if (lane == 0) __hip_atomic_fetch_add(cnt_own + (long)rb * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       SSTAMP(10);
       // off the hand-off chain: what only later launches read
@@ -966,6 +1022,10 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
         }
       }
     }
+  }
+  if (MAXRB > 1 && tid < 128 && pend >= 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(cnt_own + pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1062,7 +1122,7 @@ int kl_launch_scan_bwd_wide(KlScanBwd a, hipStream_t stream) {
   const int per_wg = (a.n_rb + g - 1) / g;
   if (per_wg > 4) return KL_ERR_SHAPE;
   dim3 grid(col_groups * g), block(1024);
-  const size_t lds = (size_t)4 * (W / 32) * 1024 + 16 * 16 * 17 * 4 + 2 * 4 * 64 * 16 * 2 + 16;
+  const size_t lds = (size_t)KL_BWD_WIDE_LDS(W / 32) + (per_wg > 1 ? 4 : 0) * 1024 * sizeof(float);
   if ((long)a.T * a.B * 4 * W * 2 > 0x7fffffffL) return KL_ERR_SHAPE;   // 32-bit buffer offsets
 #define KL_WIDE_CASE(KS, RB)                                                                                         \
   do {                                                                                                               \
@@ -1090,7 +1150,7 @@ int kl_launch_scan_fwd_wide(KlScanFwdWide a, hipStream_t stream) {
   const int per_wg = (a.n_rb + g - 1) / g;
   if (per_wg > 4) return KL_ERR_SHAPE;
   dim3 grid(col_groups * g), block(1024);
-  const size_t lds = (size_t)(W / 32) * 1024 + 16 * 4 * 16 * 17 * 4 + 2 * 64 * 16 * 2 + 16 * 64 * 2 + 16;
+  const size_t lds = (size_t)KL_FWD_WIDE_LDS(W / 32) + (per_wg > 1 ? 4 : 0) * 1024 * sizeof(float);
   if ((long)(a.T + 1) * a.B * W * 2 > 0x7fffffffL) return KL_ERR_SHAPE;   // 32-bit buffer offsets
 #define KL_WIDE_CASE(KS, RB)                                                                                         \
   do {                                                                                                               \
