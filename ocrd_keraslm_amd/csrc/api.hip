@@ -48,6 +48,7 @@ struct Derived {
   std::vector<bf16_t*> UT_hi, UT_lo, KT_hi, KT_lo, Un, Kn;   // per layer (KT/Kn of layer 0 = rows [0,W) of K0)
   bf16_t *E_hi = nullptr, *E_lo = nullptr, *ET = nullptr;
   std::vector<bf16_t*> WTcat;    // [4W][3*K_l] = [hi | hi | lo] blocks, K_0 = W (U), K_l = 2W (K then U): big-n step path
+  std::vector<bf16_t*> WTperm;   // WTcat with rows in (unit block of 32, gate, unit) order: fused cell epilogue (W % 32 == 0)
   bf16_t* Ecat = nullptr;        // [Vp][3W]
   float* EK = nullptr;
   std::vector<float*> CtxK;
@@ -101,6 +102,7 @@ struct kl_handle {
   bool scan_enabled = true;     // persistent scans (KL_SCAN=0 forces the launch-per-step path)
   bool seq_bwd = true;          // layer-sequential backward scans for many row blocks (KL_SEQ_BWD=0: always fused)
   bool wide_bwd = true;         // ... with 64-unit workgroups (KL_WIDE_BWD=0: thin workgroups)
+  bool fused_step = true;       // incremental step, n >= 256: cell fused into the GEMM epilogue (KL_FUSED_STEP=0: separate kernels)
   int wide_fwd_min = 256;       // layer-sequential wide forward scans from this many 64-unit workgroups (KL_WIDE_FWD_MIN; 0 = never)
   double trace_flops[2] = {0.0, 0.0};   // algorithmic FLOPs of ONE timed launch
   // optional per-launch timing of the cell-step kernels with HIP events (bench.py's
@@ -195,6 +197,9 @@ size_t carve_derived(const kl_handle* h, void* base, Derived* d) {
   o.EK = cv.take<float>(V * 4 * W);
   o.WTcat.assign(c.depth, nullptr);
   for (int l = 0; l < c.depth; ++l) o.WTcat[l] = cv.take<bf16_t>(4 * W * 3 * (l == 0 ? W : 2 * W));
+  o.WTperm.assign(c.depth, nullptr);
+  if ((W & 31) == 0)
+    for (int l = 0; l < c.depth; ++l) o.WTperm[l] = cv.take<bf16_t>(4 * W * 3 * (l == 0 ? W : 2 * W));
   o.Ecat = cv.take<bf16_t>(Vp * 3 * W);
   o.CtxK.assign(c.n_ctx, nullptr);
   for (int n = 0; n < c.n_ctx; ++n) o.CtxK[n] = cv.take<float>((size_t)c.ctx_vocab * 4 * W);
@@ -320,6 +325,7 @@ int prepare_impl(kl_handle* h, int precision, hipStream_t s) {
     }
     KL_TRY(kl_launch_f32_to_bf16_t(U, 4 * W, W, 4 * W, base + uoff, split ? base + 2 * Kl + uoff : nullptr, ld, 1, s));
     if (split) KL_TRY(kl_launch_f32_to_bf16_t(U, 4 * W, W, 4 * W, base + Kl + uoff, nullptr, ld, 1, s));
+    if (d.WTperm[l]) KL_TRY(kl_launch_permute_gate_rows(base, d.WTperm[l], W, ld, s));
   }
   KL_TRY(kl_zero_async(d.Ecat, (size_t)Vp * 3 * W * sizeof(bf16_t), s));
   KL_TRY(kl_launch_f32_to_bf16_t(E, W, V, W, d.Ecat, split ? d.Ecat + 2 * W : nullptr, 3 * W, 0, s));
@@ -612,6 +618,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->seq_bwd = !(env3 && env3[0] == '0');
   const char* env4 = getenv("KL_WIDE_BWD");
   h->wide_bwd = !(env4 && env4[0] == '0');
+  const char* env6 = getenv("KL_FUSED_STEP");
+  h->fused_step = !(env6 && env6[0] == '0');
   const char* env5 = getenv("KL_WIDE_FWD_MIN");
   if (env5) h->wide_fwd_min = atoi(env5);
   return kl_zero_page_ready();
@@ -903,6 +911,8 @@ size_t kl_step_workspace_bytes(const kl_handle* h, int n) {
   cv.take<float>((size_t)n * 4 * h->cfg.width);          // P rows when n_ctx != 1
   cv.take<float>((size_t)n * 4 * h->cfg.width);          // z of the big-n path
   cv.take<bf16_t>((size_t)n * 3 * 2 * h->cfg.width);     // [hi | lo | hi] activation rows
+  for (int l = 0; l < h->cfg.depth; ++l)                 // ... of every layer at once (fused path)
+    cv.take<bf16_t>((size_t)n * 3 * (l == 0 ? 1 : 2) * h->cfg.width);
   return align_up(cv.off, 256);
 }
 
@@ -934,6 +944,37 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
     float* z = cv.take<float>((size_t)n * 4 * W);
     bf16_t* A3 = cv.take<bf16_t>((size_t)n * 3 * 2 * W);
     const int nb = split == 3 ? 3 : 1;
+    // fused form: one gather of all layers' recurrent halves, then per layer ONE GEMM whose
+    // epilogue is the cell (gates, c', h', and h' as the next layer's input rows)
+    bool fusable = h->fused_step && (W & 31) == 0 && L <= KL_SCAN_MAXL && V < 1024;
+    for (int l = 0; l < L && fusable; ++l) fusable = d.WTperm[l] != nullptr && ((nb * (l == 0 ? W : 2 * W)) % 64) == 0;
+    if (fusable) {
+      KlGatherRec g;
+      memset(&g, 0, sizeof(g));
+      g.pool = pool; g.slot_ld = slot_ld; g.slot_in = slot_in; g.n = n; g.W = W; g.nb = nb;
+      for (int l = 0; l < L; ++l) g.out[l] = cv.take<bf16_t>((size_t)n * 3 * (l == 0 ? 1 : 2) * W);
+      KL_TRY(kl_launch_gather_recurrent(g, L, s));
+      for (int l = 0; l < L; ++l) {
+        const int Kl = l == 0 ? W : 2 * W;
+        const bool tab = l == 0 && !prow;
+        KlGateEpi e;
+        memset(&e, 0, sizeof(e));
+        if (l == 0) { e.T1 = prow ? prow : d.EK; e.i1 = tab ? idx : nullptr; e.T2 = tab ? d.CtxK[0] : nullptr; e.i2 = tab ? ctx : nullptr; }
+        e.bias = (l > 0 || tab) ? P + h->off_b[l] : nullptr;
+        e.c_prev = pool + (size_t)(2 * l + 1) * W; e.c_ld = slot_ld; e.slot_in = slot_in;
+        e.c_out = pool + (size_t)(2 * l + 1) * W; e.h_out = pool + (size_t)2 * l * W; e.out_ld = slot_ld; e.slot_out = slot_out;
+        if (l + 1 < L) { e.xn = g.out[l + 1]; e.ldn = 3L * 2 * W; e.kn = 2 * W; e.nbn = nb; }
+        e.W = W;
+        KL_TRY(kl_launch_gemm_gates(g.out[l], d.WTperm[l], n, W, nb * Kl, 3L * Kl, &e, s));
+      }
+      KlOperand op;
+      memset(&op, 0, sizeof(op));
+      op.A = pool + (size_t)2 * (L - 1) * W; op.lda = slot_ld; op.row_index = slot_out; op.a_is_f32 = 1;
+      op.WT_hi = d.E_hi; op.WT_lo = split == 3 ? d.E_lo : nullptr; op.ldw = W; op.K = W;
+      KL_TRY(kl_launch_thin_gemm(&op, n, V, probs, V, nullptr, split, s));
+      KL_TRY(kl_launch_softmax_ce(probs, V, n, V, nullptr, n, 1, 1.f, nullptr, 0, nullptr, nullptr, 0, s));
+      return 0;
+    }
     for (int l = 0; l < L; ++l) {
       const int Kl = l == 0 ? W : 2 * W;
       if (l == 0) {

@@ -15,6 +15,7 @@
 // Split-K over gridDim.z with f32 atomics for the K = B*T weight-gradient
 // shapes (M,N small, K huge).
 #include <stdlib.h>
+#include <string.h>
 
 #include "kl_common.h"
 #include "kl_kernels.h"
@@ -187,22 +188,25 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
       : "memory");
 }
 
-// WM x WN waves, each 64 rows x (128 / WN) columns: (4, 2) = the 256 x 128 tile for big grids,
-// (1, 4) = a 64 x 128 tile (4 waves, 72 KiB) for M ~ 1e3 shapes (the incremental step's GEMMs),
-// where 256-row tiles would leave 3/4 of the CUs idle.  Either way a wave issues 6 LDS-DMA
-// pieces per k-step (the counted vmcnt below).
-template <int OUT, bool ILV, int WM, int WN>
+// WM x WN waves, each RF*16 rows x (128 / WN) columns: (RF, WM, WN) = (4, 4, 2) is the 256 x 128
+// tile for big grids; (2, 2, 4) a 64 x 128 tile of 8 waves (72 KiB) for M ~ 1e3 shapes (the
+// incremental step's GEMMs), where 256-row tiles would leave 3/4 of the CUs idle and two waves
+// per SIMD are needed to hide the ds_read -> MFMA latency of the short k-loop.
+template <int OUT, bool ILV, int RF, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, int M, int N, int K, long lda, long ldb, long ldc,
-    int k_per_split, float alpha) {
+    int k_per_split, float alpha, const KlGateEpi epi) {
   constexpr int NW = WM * WN;
-  constexpr int TBM = 64 * WM;                 // tile rows
+  constexpr int WROWS = 16 * RF;               // rows per wave
+  constexpr int TBM = WROWS * WM;              // tile rows
   constexpr int WCOLS = LBN / WN;              // columns per wave
   constexpr int NT = WCOLS / 16;               // column fragments per wave
   constexpr int PA = TBM / 8 / NW;             // A pieces (8 rows each) per wave and k-step
   constexpr int PB = LBN / 8 / NW;             // B pieces
-  static_assert(PA + PB == 6, "the counted vmcnt assumes 6 pieces per wave");
+  constexpr int NP = PA + PB;                  // pieces per wave and k-step = the counted vmcnt
+  constexpr int NP0 = (NP + 1) / 2;            // ... issued with the first MFMA group
+  static_assert(PA >= 1 && PB >= 1 && NP <= 6, "piece split");
   constexpr int STAGE_BYTES = (TBM + LBN) * 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -222,21 +226,21 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
   const __amdgpu_buffer_rsrc_t rsB =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B + (long)n0 * ldb), 0, clamp31(((long)(N - n0 - 1) * ldb + K) * 2), 0x00020000);
   // per-lane source offsets of this wave's pieces (rows wave*8*P + j*8 + (lane>>3)), swizzled chunk
-  unsigned vo[6];
+  unsigned vo[NP];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
+  for (int j = 0; j < NP; ++j) {
     const int row = j < PA ? wave * 8 * PA + j * 8 + (lane >> 3) : wave * 8 * PB + (j - PA) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     vo[j] = (unsigned)((long)row * (j < PA ? lda : ldb) * 2 + c * 16);
   }
   const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
-  // pieces 0..2 and 3..5 are issued between the two MFMA groups of a k-step
+  // the pieces are issued in two halves between the two MFMA groups of a k-step
   auto issue_half = [&](int kt, int stage, int half) {
     const int soff = (kbeg + kt * BK) * 2;
     const unsigned sa = lds0 + stage * STAGE_BYTES + wave * 8 * PA * 128;
     const unsigned sb = lds0 + stage * STAGE_BYTES + TBM * 128 + wave * 8 * PB * 128;
 #pragma unroll
-    for (int j = half * 3; j < half * 3 + 3; ++j) {
+    for (int j = half ? NP0 : 0; j < (half ? NP : NP0); ++j) {
       if (j < PA) glds16(rsA, vo[j], soff, sa + j * 1024);
       else glds16(rsB, vo[j], soff, sb + (j - PA) * 1024);
     }
@@ -246,9 +250,9 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
     issue_half(kt, stage, 1);
   };
 
-  f32x4 acc[4][NT];
+  f32x4 acc[RF][NT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RF; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
   const int fr = lane & 15, fq = lane >> 4;
   int stage = 0;
   for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const bool more = kt + 2 < nkt;
@@ -267,22 +271,85 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
     const unsigned char* b_base = a_base + TBM * 128;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      frag16 fa[4], fb[NT];
+      frag16 fa[RF], fb[NT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        fa[i].u = *reinterpret_cast<const uint4*>(a_base + lds_off(wm * 64 + i * 16 + fr, s * 4 + fq));
+      for (int i = 0; i < RF; ++i)
+        fa[i].u = *reinterpret_cast<const uint4*>(a_base + lds_off(wm * WROWS + i * 16 + fr, s * 4 + fq));
 #pragma unroll
       for (int j = 0; j < NT; ++j)
         fb[j].u = *reinterpret_cast<const uint4*>(b_base + lds_off(wn * WCOLS + j * 16 + fr, s * 4 + fq));
       if (ILV && more) issue_half(kt + 2, nstage, s);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < RF; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fa[i].v, fb[j].v, acc[i][j]);
     }
     stage = stage + 1 < LSTAGES ? stage + 1 : 0;
   }
 
+  if (OUT == 3) {
+    // LSTM cell epilogue (incremental step, step_big.hip): the weight rows are permuted so that
+    // this 128-column tile holds the four gates of 32 hidden units; the tile goes through LDS
+    // and every thread finishes (row, unit) pairs: z + table rows + bias -> gates -> c', h'
+    // written to the output pool slots, and h' as bf16 (hi | lo | hi) into the next layer's
+    // activation rows.  No z round trip through HBM, no separate gate kernel.
+    constexpr int LDP = LBN + 4;
+    float* ct = reinterpret_cast<float*>(smem);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < RF; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ct[(wm * WROWS + i * 16 + fq * 4 + r) * LDP + wn * WCOLS + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    const int u = tid & 31;
+    const int U = blockIdx.x * 32 + u;
+    const int W = epi.W;
+    float bg[4] = {0.f, 0.f, 0.f, 0.f};
+    if (epi.bias) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bg[g] = epi.bias[(long)g * W + U];
+    }
+    constexpr int RPP = 64 * NW / 32;
+    for (int p = 0; p < TBM / RPP; ++p) {
+      const int lrow = p * RPP + (tid >> 5);
+      const int row = m0 + lrow;
+      if (row >= M) continue;
+      float z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) z[g] = ct[lrow * LDP + g * 32 + u] + bg[g];
+      if (epi.T1) {
+        const float* t1 = epi.T1 + (long)(epi.i1 ? epi.i1[row] : row) * 4 * W + U;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) z[g] += t1[(long)g * W];
+      }
+      if (epi.T2) {
+        const float* t2 = epi.T2 + (long)(epi.i2 ? epi.i2[row] : row) * 4 * W + U;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) z[g] += t2[(long)g * W];
+      }
+      const float gi = sigmoidf_(z[0]), gf = sigmoidf_(z[1]), gg = tanhf_(z[2]), go = sigmoidf_(z[3]);
+      const float cp = epi.c_prev[(long)epi.slot_in[row] * epi.c_ld + U];
+      const float c = gf * cp + gi * gg;
+      const float hv = go * tanhf_(c);
+      const long o = (long)epi.slot_out[row] * epi.out_ld + U;
+      epi.c_out[o] = c;
+      epi.h_out[o] = hv;
+      if (epi.xn) {
+        bf16_t hi, lo;
+        split_bf16(hv, hi, lo);
+        bf16_t* x = epi.xn + (long)row * epi.ldn + U;
+        x[0] = hi;
+        if (epi.nbn == 3) {
+          x[epi.kn] = lo;
+          x[2 * epi.kn] = hi;
+        }
+      }
+    }
+    return;
+  }
   if (OUT == 0 && (ldc & 3) == 0 && (n0 + LBN <= N) && ((size_t)Cv & 15) == 0) {
     // f32 stores in whole rows: the accumulator layout (4 rows x 1 column per lane) would
     // write 64-byte row segments; turn the tile through LDS (the ring is free now) so that
@@ -291,12 +358,12 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
     float* ct = reinterpret_cast<float*>(smem);
     __builtin_amdgcn_s_barrier();                      // every wave is done reading the last stage
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RF; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          ct[(wm * 64 + i * 16 + fq * 4 + r) * LDP + wn * WCOLS + j * 16 + fr] = acc[i][j][r] * alpha;
+          ct[(wm * WROWS + i * 16 + fq * 4 + r) * LDP + wn * WCOLS + j * 16 + fr] = acc[i][j][r] * alpha;
     __syncthreads();
     const int c4 = (tid & 31) * 4;
     f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -314,7 +381,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
     return;
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < RF; ++i) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = n0 + wn * WCOLS + j * 16 + fr;
@@ -322,7 +389,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
       const float bv = (bias != nullptr && blockIdx.z == 0) ? bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 64 + i * 16 + fq * 4 + r;
+        const int row = m0 + wm * WROWS + i * 16 + fq * 4 + r;
         if (row >= M) continue;
         const float v = acc[i][j][r] * alpha + bv;
         if (OUT == 0) {
@@ -337,28 +404,33 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
   }
 }
 
-template <int WM, int WN>
+template <int RF, int WM, int WN>
 int launch_long_t(int out_mode, dim3 grid, hipStream_t stream, const bf16_t* A, const bf16_t* B, void* C, const float* bias,
-                  int M, int N, int K, long lda, long ldb, long ldc, int k_per_split, float alpha) {
-  const size_t lds = (size_t)LSTAGES * (64 * WM + LBN) * 128;
+                  int M, int N, int K, long lda, long ldb, long ldc, int k_per_split, float alpha,
+                  const KlGateEpi* gate = nullptr) {
+  KlGateEpi epi;
+  if (gate) epi = *gate;
+  else memset(&epi, 0, sizeof(epi));
+  const size_t lds = (size_t)LSTAGES * (16 * RF * WM + LBN) * 128;
   static const bool ilv = !(getenv("KL_GEMM_ILV") && getenv("KL_GEMM_ILV")[0] == '0');
 #define KL_LONG_CASE(O)                                                                                                  \
   do {                                                                                                                   \
     static bool attr_set = false;                                                                                        \
     if (!attr_set) {                                                                                                     \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<O, true, WM, WN>),                      \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<O, true, RF, WM, WN>),                      \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH; \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<O, false, WM, WN>),                     \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<O, false, RF, WM, WN>),                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH; \
       attr_set = true;                                                                                                   \
     }                                                                                                                    \
-    if (ilv) hipLaunchKernelGGL((gemm_tn_long_kernel<O, true, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, A, B, C,  \
-                                bias, M, N, K, lda, ldb, ldc, k_per_split, alpha);                                       \
-    else hipLaunchKernelGGL((gemm_tn_long_kernel<O, false, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, A, B, C,     \
-                            bias, M, N, K, lda, ldb, ldc, k_per_split, alpha);                                           \
+    if (ilv) hipLaunchKernelGGL((gemm_tn_long_kernel<O, true, RF, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, A, B, C,  \
+                                bias, M, N, K, lda, ldb, ldc, k_per_split, alpha, epi);                                  \
+    else hipLaunchKernelGGL((gemm_tn_long_kernel<O, false, RF, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, A, B, C,     \
+                            bias, M, N, K, lda, ldb, ldc, k_per_split, alpha, epi);                                      \
   } while (0)
   if (out_mode == 0) KL_LONG_CASE(0);
   else if (out_mode == 1) KL_LONG_CASE(1);
+  else if (out_mode == 3) KL_LONG_CASE(3);
   else KL_LONG_CASE(2);
 #undef KL_LONG_CASE
   return 0;
@@ -366,7 +438,7 @@ int launch_long_t(int out_mode, dim3 grid, hipStream_t stream, const bf16_t* A, 
 
 int launch_long(int out_mode, dim3 grid, hipStream_t stream, const bf16_t* A, const bf16_t* B, void* C, const float* bias,
                 int M, int N, int K, long lda, long ldb, long ldc, int k_per_split, float alpha) {
-  return launch_long_t<4, 2>(out_mode, grid, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, k_per_split, alpha);
+  return launch_long_t<4, 4, 2>(out_mode, grid, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, k_per_split, alpha);
 }
 
 }  // namespace
@@ -405,7 +477,7 @@ int kl_launch_gemm_tn(const bf16_t* A, const bf16_t* B, void* C, const float* bi
   if (long_mode >= 2 && long_ok && splits == 1 && K >= 512 && M >= 256 &&
       (long)((M + 63) / 64) * ((N + LBN - 1) / LBN) >= 64) {
     dim3 grid((N + LBN - 1) / LBN, (M + 63) / 64, 1);
-    const int e = launch_long_t<1, 4>(out_mode, grid, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, K, alpha);
+    const int e = launch_long_t<2, 2, 4>(out_mode, grid, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, K, alpha);
     if (e != 0) return e;
     return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
   }
@@ -422,5 +494,17 @@ int kl_launch_gemm_tn(const bf16_t* A, const bf16_t* B, void* C, const float* bi
     dim3 grid(nbx, (M + 127) / 128, splits);
     launch_bm<128>(out_mode, grid, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, k_per_split, alpha);
   }
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+// z = A3 . WTperm^T with the LSTM cell as epilogue (see OUT == 3 above).  A3 [n][lda] bf16 rows,
+// WTperm [4W][lda] with rows in (unit block of 32, gate, unit) order, Kc = contracted length.
+// KL_ERR_SHAPE = not applicable (caller uses the unfused path).
+int kl_launch_gemm_gates(const bf16_t* A3, const bf16_t* WTperm, int n, int W, int Kc, long lda, const KlGateEpi* epi,
+                         hipStream_t stream) {
+  if (n < 1 || (W & 31) || (Kc % BK) != 0 || (lda & 7) || lda >= (1L << 22) || !epi) return KL_ERR_SHAPE;
+  dim3 grid(4 * W / LBN, (n + 63) / 64, 1);
+  const int e = launch_long_t<2, 2, 4>(3, grid, stream, A3, WTperm, nullptr, nullptr, n, 4 * W, Kc, lda, lda, 0, Kc, 1.f, epi);
+  if (e != 0) return e;
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }

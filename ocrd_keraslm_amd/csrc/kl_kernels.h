@@ -8,6 +8,28 @@
 typedef unsigned short bf16_t;
 
 // ---- gemm.hip -----------------------------------------------------------
+// recurrent halves of all layers' activation rows for the fused incremental step (step_big.hip)
+struct KlGatherRec {
+  const float* pool; long slot_ld; const int* slot_in;
+  int n, W, nb;
+  bf16_t* out[4];                      // per layer [n][3 * K_l], K_0 = W, K_l = 2W
+};
+int kl_launch_gather_recurrent(const KlGatherRec& a, int L, hipStream_t stream);
+int kl_launch_permute_gate_rows(const bf16_t* src, bf16_t* dst, int W, long cols, hipStream_t stream);
+
+// LSTM cell epilogue of the fused incremental-step GEMM (gemm.hip OUT == 3)
+struct KlGateEpi {
+  const float* T1; const int* i1;      // table rows added to z: T1[i1 ? i1[row] : row][4W] (null: none)
+  const float* T2; const int* i2;
+  const float* bias;                   // [4W] (null: none)
+  const float* c_prev; long c_ld; const int* slot_in;   // c_prev[slot_in[row] * c_ld + u]
+  float* c_out; float* h_out; long out_ld; const int* slot_out;
+  bf16_t* xn; long ldn; int kn; int nbn;   // next layer's activation rows: h' as (hi | lo | hi) at block stride kn (null: none)
+  int W;
+};
+int kl_launch_gemm_gates(const bf16_t* A3, const bf16_t* WTperm, int n, int W, int Kc, long lda, const KlGateEpi* epi,
+                         hipStream_t stream);
+
 int kl_launch_gemm_tn(const bf16_t* A, const bf16_t* B, void* C, const float* bias, int M, int N, int K,
                       long lda, long ldb, long ldc, int out_mode, int splits, float alpha, hipStream_t stream);
 

@@ -68,6 +68,47 @@ __global__ void gates_rows_kernel(const float* __restrict__ z, long ldz, int n, 
   }
 }
 
+// recurrent halves of every layer's activation rows in one launch: layer l (blockIdx.y) takes
+// h_l of slot_in[row] as (hi | lo | hi) blocks of stride K_l at column offset (l > 0 ? W : 0)
+__global__ void gather_recurrent_kernel(const KlGatherRec a) {
+  const int l = blockIdx.y;
+  const int W = a.W, chunks = W >> 3;
+  const long total = (long)a.n * chunks;
+  const long kl = l == 0 ? W : 2L * W;
+  bf16_t* out = a.out[l] + (l == 0 ? 0 : W);
+  const long ld_out = 3 * kl;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % chunks);
+    const int row = (int)(e / chunks);
+    const float* src = a.pool + (long)a.slot_in[row] * a.slot_ld + (long)2 * l * W + c * 8;
+    const float4 x0 = *reinterpret_cast<const float4*>(src);
+    const float4 x1 = *reinterpret_cast<const float4*>(src + 4);
+    const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    frag16 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split_bf16(xs[j], hi.s[j], lo.s[j]);
+    bf16_t* o = out + (long)row * ld_out + c * 8;
+    *reinterpret_cast<uint4*>(o) = hi.u;
+    if (a.nb == 3) {
+      *reinterpret_cast<uint4*>(o + kl) = lo.u;
+      *reinterpret_cast<uint4*>(o + 2 * kl) = hi.u;
+    }
+  }
+}
+
+// dst row (u / 32) * 128 + g * 32 + u % 32  <-  src row g * W + u   (rows of `cols` bf16)
+__global__ void permute_gate_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int W, long cols) {
+  const long chunks = cols >> 3;
+  const long total = 4L * W * chunks;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long c = e % chunks;
+    const int r = (int)(e / chunks);
+    const int g = r / W, u = r % W;
+    const long d = (long)(u >> 5) * 128 + g * 32 + (u & 31);
+    *reinterpret_cast<uint4*>(dst + d * cols + c * 8) = *reinterpret_cast<const uint4*>(src + (long)r * cols + c * 8);
+  }
+}
+
 inline int grid_for(long total, int block) {
   long g = (total + block - 1) / block;
   if (g > 4096) g = 4096;
@@ -92,5 +133,18 @@ int kl_launch_gates_rows(const float* z, long ldz, int n, int W, const float* T1
                          float* c_out, float* h_out, long out_ld, const int* slot_out, hipStream_t stream) {
   hipLaunchKernelGGL(gates_rows_kernel, dim3(grid_for((long)n * W, 256)), dim3(256), 0, stream, z, ldz, n, W, T1, i1, T2,
                      i2, bias, c_prev, c_ld, slot_in, c_out, h_out, out_ld, slot_out);
+  return ok();
+}
+
+int kl_launch_gather_recurrent(const KlGatherRec& a, int L, hipStream_t stream) {
+  if ((a.W & 7) || L < 1 || L > KL_SCAN_MAXL || (a.nb != 1 && a.nb != 3)) return KL_ERR_SHAPE;
+  const long total = (long)a.n * (a.W >> 3);
+  hipLaunchKernelGGL(gather_recurrent_kernel, dim3(grid_for(total, 256), L), dim3(256), 0, stream, a);
+  return ok();
+}
+
+int kl_launch_permute_gate_rows(const bf16_t* src, bf16_t* dst, int W, long cols, hipStream_t stream) {
+  if ((W & 31) || (cols & 7)) return KL_ERR_SHAPE;
+  hipLaunchKernelGGL(permute_gate_rows_kernel, dim3(grid_for(4L * W * (cols >> 3), 256)), dim3(256), 0, stream, src, dst, W, cols);
   return ok();
 }

@@ -64,6 +64,7 @@ class HipLM:
         self.states = None          # [B][2L][W] implicit state of the stateful streams
         self.pool = None            # [slots][2L][W] explicit states of hypotheses
         self._step_ws = None
+        self._step_ws_bytes = {}
         self._rng = np.random.default_rng(0)
 
     def __del__(self):
@@ -259,23 +260,37 @@ class HipLM:
             self.pool = new
         return self.pool
 
+    def _i32(self, a):
+        """device int32 view of `a` without a copy when it already is one"""
+        torch = self.torch
+        if isinstance(a, torch.Tensor) and a.dtype == torch.int32 and a.is_cuda and a.is_contiguous():
+            return a
+        return self._dev_i32(a)
+
     def step_slots(self, idx, ctx, slot_in, slot_out):
         """One LSTM step for n hypotheses whose states live in pool slots
-        (device-resident variant of rating.py:578-639).  Returns probs tensor [n,V]."""
+        (device-resident variant of rating.py:578-639).  Returns probs tensor [n,V].
+
+        A beam search calls this once per character, so the host side is kept short: the launches go
+        onto the caller's current stream directly (every other engine call leaves that stream ordered
+        after the engine stream, see _launch), nothing is copied when the arguments are device int32
+        tensors, and the workspace size per n is cached."""
         torch = self.torch
-        with self._launch():
-            idx_d = self._dev_i32(idx).reshape(-1)
-            n = idx_d.numel()
-            ctx_d = self._dev_i32(ctx).reshape(n, -1) if self.n_ctx else None
-            si = self._dev_i32(slot_in).reshape(-1)
-            so = self._dev_i32(slot_out).reshape(-1)
-            probs = torch.empty((n, self.voc_size), dtype=torch.float32, device=self.device)
-            nws = self.lib.kl_step_workspace_bytes(self.handle, n)
-            if self._step_ws is None or self._step_ws.numel() < nws:
-                self._step_ws = torch.empty(nws, dtype=torch.uint8, device=self.device)
-            hipabi.check(self.lib.kl_step_batch(self.handle, n, _ptr(idx_d), _ptr(ctx_d), _ptr(self.pool), _ptr(si),
-                                                _ptr(so), _ptr(probs), _ptr(self._step_ws), self._step_ws.numel(),
-                                                self._stream()), "kl_step_batch")
+        idx_d = self._i32(idx).reshape(-1)
+        n = idx_d.numel()
+        ctx_d = self._i32(ctx).reshape(n, -1) if self.n_ctx else None
+        si = self._i32(slot_in).reshape(-1)
+        so = self._i32(slot_out).reshape(-1)
+        probs = torch.empty((n, self.voc_size), dtype=torch.float32, device=self.device)
+        nws = self._step_ws_bytes.get(n)
+        if nws is None:
+            nws = self._step_ws_bytes[n] = int(self.lib.kl_step_workspace_bytes(self.handle, n))
+        if self._step_ws is None or self._step_ws.numel() < nws:
+            self._step_ws = torch.empty(nws, dtype=torch.uint8, device=self.device)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        hipabi.check(self.lib.kl_step_batch(self.handle, n, _ptr(idx_d), _ptr(ctx_d), _ptr(self.pool), _ptr(si),
+                                            _ptr(so), _ptr(probs), _ptr(self._step_ws), self._step_ws.numel(),
+                                            stream), "kl_step_batch")
         return probs
 
     def state_dist2(self, a, b, k):
