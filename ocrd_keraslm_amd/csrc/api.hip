@@ -102,6 +102,7 @@ struct kl_handle {
   bool scan_enabled = true;     // persistent scans (KL_SCAN=0 forces the launch-per-step path)
   bool seq_bwd = true;          // layer-sequential backward scans for many row blocks (KL_SEQ_BWD=0: always fused)
   bool wide_bwd = true;         // ... with 64-unit workgroups (KL_WIDE_BWD=0: thin workgroups)
+  bool sentinel = true;         // wide scans hand off by data sentinels instead of counters (KL_SENTINEL=0: counters)
   bool fused_step = true;       // incremental step, n >= 256: cell fused into the GEMM epilogue (KL_FUSED_STEP=0: separate kernels)
   int wide_fwd_min = 256;       // layer-sequential wide forward scans from this many 64-unit workgroups (KL_WIDE_FWD_MIN; 0 = never)
   double trace_flops[2] = {0.0, 0.0};   // algorithmic FLOPs of ONE timed launch
@@ -385,7 +386,11 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       a.HdT = masked ? w.HdT[l] : nullptr; a.ldt_d = (long)B * T;
       a.counters = w.scan_cnt;
       a.status = w.scan_status;
-      KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)n_rb * T, s));
+      a.sentinel = h->sentinel ? 1 : 0;
+      if (a.sentinel)   // hand-off by data: the blocks the scan is going to publish start out as sentinels
+        KL_TRY(kl_fill_u32_async((bf16_t*)w.H[l] + BW, (size_t)T * BW * sizeof(bf16_t), 0xFFFFFFFFu, s));
+      else
+        KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)n_rb * T, s));
       if (l == L - 1) h->trace_begin(0, s);
       KL_TRY(kl_launch_scan_fwd_wide(a, s));
       if (l == L - 1) {
@@ -618,6 +623,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->seq_bwd = !(env3 && env3[0] == '0');
   const char* env4 = getenv("KL_WIDE_BWD");
   h->wide_bwd = !(env4 && env4[0] == '0');
+  const char* env7 = getenv("KL_SENTINEL");
+  h->sentinel = !(env7 && env7[0] == '0');
   const char* env6 = getenv("KL_FUSED_STEP");
   h->fused_step = !(env6 && env6[0] == '0');
   const char* env5 = getenv("KL_WIDE_FWD_MIN");

@@ -441,6 +441,25 @@ int kl_zero_async(void* p, size_t bytes, hipStream_t stream) {
   return ok();
 }
 
+namespace {
+__global__ void fill16_kernel(uint4* p, size_t n16, unsigned v) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = uint4{v, v, v, v};
+}
+}  // namespace
+
+// fill a 16-byte aligned region (a multiple of 16 bytes) with one 32-bit pattern:
+// the sentinel pre-fill of the scans' exchange buffers
+int kl_fill_u32_async(void* p, size_t bytes, unsigned value, hipStream_t stream) {
+  if (bytes == 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) || (bytes & 15)) return KL_ERR_ARG;
+  const size_t n16 = bytes / 16;
+  long g = (long)((n16 + 255) / 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(fill16_kernel, dim3((unsigned)g), dim3(256), 0, stream, reinterpret_cast<uint4*>(p), n16, value);
+  return ok();
+}
+
 int kl_zero_coherent_async(unsigned* p, size_t n_words, hipStream_t stream) {
   if (n_words == 0) return 0;
   long g = (long)((n_words + 255) / 256);

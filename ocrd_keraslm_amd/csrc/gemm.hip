@@ -170,6 +170,9 @@ void launch_bm(int out_mode, dim3 grid, hipStream_t stream, const bf16_t* A, con
 // Ordering (MI355X_MICROARCH.md, LDS-DMA): a stage is read only after its issuing waves'
 // counted vmcnt AND a barrier the reader has passed; it is restaged only after a barrier
 // that every reader reaches with its ds_reads retired (they feed MFMAs issued before it).
+#ifndef KL_GEMM_PRIO
+#define KL_GEMM_PRIO 1
+#endif
 constexpr int LBM = 256, LBN = 128, LTHREADS = 512, LSTAGES = 3;
 constexpr int LSTAGE_BYTES = (LBM + LBN) * 128;
 
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, int M, int N, int K, long lda, long ldb, long ldc,
     int k_per_split, float alpha, const KlGateEpi epi) {
+  constexpr bool PRIO = KL_GEMM_PRIO;
   constexpr int NW = WM * WN;
   constexpr int WROWS = 16 * RF;               // rows per wave
   constexpr int TBM = WROWS * WM;              // tile rows
@@ -279,10 +283,12 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
       for (int j = 0; j < NT; ++j)
         fb[j].u = *reinterpret_cast<const uint4*>(b_base + lds_off(wn * WCOLS + j * 16 + fr, s * 4 + fq));
       if (ILV && more) issue_half(kt + 2, nstage, s);
+      if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < RF; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fa[i].v, fb[j].v, acc[i][j]);
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
     }
     stage = stage + 1 < LSTAGES ? stage + 1 : 0;
   }
@@ -467,7 +473,8 @@ int kl_launch_gemm_tn(const bf16_t* A, const bf16_t* B, void* C, const float* bi
     return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
   }
   // many-row shapes (activations x weights): the same ring, one tile per workgroup, no split
-  if (long_mode >= 2 && long_ok && splits == 1 && K >= 256 && (long)((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) >= 256) {
+  static const bool small_all = getenv("KL_GEMM_SMALL_ALL") && getenv("KL_GEMM_SMALL_ALL")[0] == '1';   // experiment
+  if (!small_all && long_mode >= 2 && long_ok && splits == 1 && K >= 256 && (long)((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) >= 256) {
     dim3 grid((N + LBN - 1) / LBN, (M + LBM - 1) / LBM, 1);
     const int e = launch_long(out_mode, grid, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, K, alpha);
     if (e != 0) return e;

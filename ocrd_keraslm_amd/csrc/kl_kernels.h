@@ -134,8 +134,9 @@ struct KlScanFwdWide {
   bf16_t* Hd; const float* mask;       // dropout-masked copy (null: none)
   bf16_t* HT; long ldt;                // transposed outputs [W][ldt], column (t+1)*B + row (null: none)
   bf16_t* HdT; long ldt_d;             // transposed masked outputs [W][ldt_d], column t*B + row (null: none)
-  unsigned* counters;                  // [n_rb][T]
+  unsigned* counters;                  // [n_rb][T] (counter hand-off)
   unsigned* status;
+  int sentinel;                        // 1: hand-off by data -- H blocks 1..T pre-filled with 0xFFFF halfwords, no counters
 };
 int kl_launch_scan_fwd_wide(KlScanFwdWide args, hipStream_t stream);
 
@@ -185,6 +186,7 @@ int kl_launch_state_to_rows(const float* states, int B, int W, int L, int layer,
 int kl_launch_fill_f32(float* p, size_t n, float v, hipStream_t stream);
 int kl_launch_fill_bf16(bf16_t* p, size_t n, unsigned short bits, hipStream_t stream);
 int kl_zero_async(void* p, size_t bytes, hipStream_t stream);               // kernel-based memset(0)
+int kl_fill_u32_async(void* p, size_t bytes, unsigned value, hipStream_t stream);
 int kl_zero_coherent_async(unsigned* p, size_t n_words, hipStream_t stream);  // write-through zero of polled words
 
 // ---- tables.hip ---------------------------------------------------------

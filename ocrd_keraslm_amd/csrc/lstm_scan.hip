@@ -61,7 +61,8 @@ __device__ unsigned long long kl_scan_stamps[32];   // [0,16) forward scan, [16,
 #endif
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
+  // (num_records is an unsigned 32-bit byte count: buffers up to 4 GiB - 1)
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)(bytes > 0xffffffffL ? 0xffffffffL : bytes), 0x00020000);
 }
 __device__ __forceinline__ uint4 load16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16);
@@ -73,8 +74,21 @@ __device__ __forceinline__ int sload_i32(const int* p) {
   asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
   return v;
 }
+// plain 16-byte buffer store: lane offset + wave-uniform (scalar) offset
+__device__ __forceinline__ void store16(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uniform_off, uint4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, r, (int)lane_off, (int)uniform_off, 0);
+}
 __device__ __forceinline__ void store16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, uint4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, r, (int)byte_off, 0, 16);
+}
+
+// Sentinel hand-off: exchange buffers are pre-filled with 0xFFFF halfwords (a bf16 NaN pattern
+// that neither h = o * tanh(c) nor a finite gradient ever rounds to); a 16-byte granule is valid
+// once none of its eight halfwords is the sentinel.  Checking all eight makes a granule that
+// became visible only in part count as not yet there.
+__device__ __forceinline__ bool granule_valid(uint4 v) {
+  auto bad = [](unsigned x) { return ((x & 0xFFFFu) == 0xFFFFu) || ((x >> 16) == 0xFFFFu); };
+  return !(bad(v.x) || bad(v.y) || bad(v.z) || bad(v.w));
 }
 
 // v_exp_f32 / v_rcp_f32 forms (1 ulp each): the scans are latency chains, and the
@@ -613,7 +627,8 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
 
 // dynamic LDS of the wide kernels up to (excluding) the per-row-block state slots [MAXRB][1024] f32
 #define KL_BWD_WIDE_LDS(KS) (4 * (KS) * 1024 + 16 * 16 * 17 * 4 + 2 * 4 * 64 * 16 * 2 + 16)
-#define KL_FWD_WIDE_LDS(KS) ((KS) * 1024 + 16 * 4 * 16 * 17 * 4 + 2 * 64 * 16 * 2 + 16 * 64 * 2 + 16)
+#define KL_FWD_WIDE_LDS0(KS) ((KS) * 1024 + 16 * 4 * 16 * 17 * 4 + 2 * 64 * 16 * 2 + 16 * 64 * 2 + 16)
+#define KL_FWD_WIDE_LDS(KS) (KL_FWD_WIDE_LDS0(KS) + 16 * 64 * 4 + 4 * 16 * 64 * 2 + 16 * 64 * 2 + 4 * 64 * 4)
 
 // ---------------------------------------------------------------- backward scan, one layer, wide workgroups
 // For many row blocks the thin kernel above is bound by fabric traffic: W/16 workgroups
@@ -825,12 +840,17 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
 // big GEMM (layers >= 1) or -- layer 0 -- straight from the look-up tables
 // EK[idx] + sum_n CtxK_n[ctx_n] + b (no P1 buffer at all).  The outputs are also written
 // transposed ([W][(T+1)B]) for the weight-gradient GEMMs.
-template <int KSTEPS, int MAXRB>
+template <int KSTEPS, int MAXRB, bool SENT>
 __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlScanFwdWide a) {
+  // Register budget: 1024 threads leave 128 VGPRs per lane and the resident weights take 64, so
+  // everything else is kept cheap: the hand-off flavour is a template parameter, row-wise values
+  // are wave-uniform (an epilogue thread's row IS its wave: scalar registers), and every per-thread
+  // global access is a buffer operation = a 32-bit lane offset + a scalar offset for the step.
   constexpr int W = KSTEPS * 32;
   constexpr int KQ = KSTEPS / 4;
   constexpr int NWG_RB = W / 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq4 = wave & 3, ug = wave >> 2;
   const int n_rg = a.n_rg, n_rb = a.n_rb, B = a.B, T = a.T;
   const int cg = blockIdx.x / n_rg, rg = blockIdx.x % n_rg;
@@ -842,6 +862,9 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
   bf16_t* tr = reinterpret_cast<bf16_t*>(smem + KSTEPS * 1024 + 16 * 4 * 16 * 17 * 4);   // [2][64 units][16 rows]
   bf16_t* pub = tr + 2 * 64 * 16;                                                       // [16 rows][64 units]
   int& ok_flag = *reinterpret_cast<int*>(smem + KSTEPS * 1024 + 16 * 4 * 16 * 17 * 4 + 2 * 64 * 16 * 2 + 16 * 64 * 2);
+  float* st_c = reinterpret_cast<float*>(smem + KL_FWD_WIDE_LDS0(KSTEPS));              // [16 rows][64 units] staged c
+  bf16_t* st_g = reinterpret_cast<bf16_t*>(st_c + 16 * 64);                             // [4 gates][16 rows][64 units]
+  bf16_t* st_hd = st_g + 4 * 16 * 64;                                                   // [16 rows][64 units]
 
   const int kq = (lane >> 4) * 8;
   uint4 bu[4][KQ];
@@ -851,38 +874,35 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
 #pragma unroll
     for (int j = 0; j < KQ; ++j) bu[g][j] = *reinterpret_cast<const uint4*>(a.UT + wrow + j * 32);
   }
-  const int er = tid >> 6, eu = tid & 63;
-  float* Cl = a.C;
-  bf16_t* Hl = a.H;
-  bf16_t* Gl = a.G;
-  bf16_t* Hdl = a.Hd;
-  bf16_t* HT = a.HT;
-  bf16_t* HdT = a.HdT;
-  const long ldt = a.ldt;
+  const int er = wave, eu = lane;           // epilogue thread = (row = wave, unit = lane)
   const float* maskl = a.mask;
   const float* P = a.P;
   unsigned* status = a.status;
-  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-  if (!P) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bias4[g] = a.bias[(long)g * W + u0 + eu];
-  }
-  // cell state of this thread's (row, unit) per row block: a register for one block, else LDS
-  // slots (the row-block loop stays rolled: unrolled it spilled 19-47 VGPRs at the 128 cap)
+  // layer-0 bias of this workgroup's 4 x 64 gate columns: LDS, not registers (zero in P mode)
+  float* bias_l = reinterpret_cast<float*>(st_hd + 16 * 64);                            // [4 gates][64 units]
+  if (tid < 256) bias_l[tid] = P ? 0.f : a.bias[(long)(tid >> 6) * W + u0 + (tid & 63)];
+  // cell state of this thread's (row, unit) per row block: a register for one block, else LDS slots
   float c_one = 0.f;
   float* c_slot = reinterpret_cast<float*>(smem + KL_FWD_WIDE_LDS(KSTEPS)) + tid;
   for (int i = 0; i < MAXRB; ++i) {
     const int rb = rg + i * n_rg;
     const int row = min(rb * 16 + er, B - 1);
-    const float c0 = (rb < n_rb) ? Cl[(long)row * W + u0 + eu] : 0.f;
+    const float c0 = (rb < n_rb) ? a.C[(long)row * W + u0 + eu] : 0.f;
     if (MAXRB > 1) c_slot[i * 1024] = c0;
     else c_one = c0;
   }
   const long BW = (long)B * W;
-  const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(Hl, (long)(T + 1) * BW * 2);
+  const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(a.H, (long)(T + 1) * BW * 2);
+  const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(a.C, (long)(T + 1) * BW * 4);
+  const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.G, (long)T * BW * 4 * 2);
+  const __amdgpu_buffer_rsrc_t rs_hd = make_rsrc(a.Hd, a.Hd ? (long)T * BW * 2 : 0);          // zero records: stores dropped
+  const __amdgpu_buffer_rsrc_t rs_ht = make_rsrc(a.HT, a.HT ? (long)W * a.ldt * 2 : 0);
+  const __amdgpu_buffer_rsrc_t rs_hdt = make_rsrc(a.HdT, a.HdT ? (long)W * a.ldt_d * 2 : 0);
   unsigned* cnt_own = a.counters;
   bool alive = true;
-  int pend = -1;       // publishing waves: counter index of stores issued but not yet signalled
+  if (tid == 0) ok_flag = 1;
+  __syncthreads();
+  int pend = -1;       // counter hand-off, publishing waves: counter index of stores issued but not yet signalled
   // (deferring needs a second row block whose publish releases the first one's signal: a workgroup
   // with a single block would wait for its own deferred signal)
   const bool defer = rg + n_rg < n_rb;
@@ -891,52 +911,91 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
   unsigned long long last_ = clock64();
 #endif
 
+  // layer 0: the table row ids of a step are fetched (scalar loads, the row is wave-uniform) at the
+  // end of the step before, where their latency hides behind the hand-off
+  int id_cur = 0, c0_cur = 0;
+  if (!P) {
+    const long src0 = (long)min(rg * 16 + er, B - 1) * T;
+    id_cur = sload_i32(a.idx + src0);
+    if (a.n_ctx > 0) c0_cur = sload_i32(a.ctx + src0 * a.n_ctx);
+  }
   for (int t = 0; t < T; ++t) {
 #pragma unroll 1
     for (int i = 0; i < MAXRB; ++i) {
       const int rb = rg + i * n_rg;
       if (rb >= n_rb) continue;
       const int r0 = rb * 16;
-      const int erow = min(r0 + er, B - 1);
-      float zin[4];
+      const int erow = min(r0 + er, B - 1);          // wave-uniform
+      SSTAMP(0);
+      if (!SENT) {
+        if (tid == 0) {
+          bool ok = alive;
+          if (ok && t > 0) ok = poll_counter(cnt_own + (long)rb * T + (t - 1), 2 * NWG_RB, status);
+          ok_flag = ok ? 1 : 0;
+        }
+        SSTAMP(1);
+        __syncthreads();
+        SSTAMP(2);
+        alive = ok_flag != 0;
+        if (wave < KSTEPS) {   // one fragment of the 16 x W tile of h[t-1] per wave
+          const int arow = min(r0 + (lane & 15), B - 1);
+          const uint4 v = alive ? load16_sc1(rs_h, (unsigned)((((long)t * B + arow) * W + wave * 32 + kq) * 2)) : uint4{0, 0, 0, 0};
+          *reinterpret_cast<uint4*>(a_tile + wave * 1024 + lane * 16) = v;
+        }
+      } else if (wave < KSTEPS) {
+        // sentinel hand-off: every wave fetches its own fragment and re-fetches it until all 64
+        // granules are there -- no counter, no poll lane, no barrier in front of the loads
+        const int arow = min(r0 + (lane & 15), B - 1);
+        const unsigned off = (unsigned)((((long)t * B + arow) * W + wave * 32 + kq) * 2);
+        uint4 v = uint4{0, 0, 0, 0};
+        if (alive) {
+          bool ok = false;
+          for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
+            v = load16_sc1(rs_h, off);
+            if (__all(t == 0 || granule_valid(v))) { ok = true; break; }
+            if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            __builtin_amdgcn_s_sleep(2);
+          }
+          if (!ok) {
+            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok_flag = 0;
+            v = uint4{0, 0, 0, 0};
+          }
+        }
+        *reinterpret_cast<uint4*>(a_tile + wave * 1024 + lane * 16) = v;
+      }
+      // gate inputs that do not depend on the hand-off, issued behind the tile fetch: they are
+      // consumed two barriers later, and their wait must not sit in front of the tile's (vmcnt is
+      // in order: a wait here would also wait out the previous step's write-through stores).
+      // The row is wave-uniform, so the row bases are scalar and each load takes one lane offset.
+      // (raw loads only: the sums are formed in the epilogue, behind a compiler fence, or the waits
+      // for these loads would be scheduled right here)
+      float za[4], zb[4] = {0.f, 0.f, 0.f, 0.f};
       if (P) {
-        const float* p = P + ((long)t * B + erow) * 4 * W + u0 + eu;
+        const float* p = P + ((long)t * B + erow) * 4 * W + u0;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) zin[g] = p[(long)g * W];
+        for (int g = 0; g < 4; ++g) za[g] = p[g * W + eu];
       } else {
-        // the row of an epilogue thread is its wave (er = tid >> 6): the ids are wave-uniform and
-        // come through the scalar cache, so the table loads below do not queue behind the
-        // previous step's vector stores (in-order vmcnt: 0.8 us of a 4.9 us step)
-        const long src = (long)min(r0 + __builtin_amdgcn_readfirstlane(er), B - 1) * T + t;
-        const float* e = a.EK + (long)sload_i32(a.idx + src) * 4 * W + u0 + eu;
+        const float* e = a.EK + (long)id_cur * 4 * W + u0;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) zin[g] = bias4[g] + e[(long)g * W];
-        for (int n = 0; n < a.n_ctx; ++n) {
-          const float* q = a.CtxK[n] + (long)sload_i32(a.ctx + src * a.n_ctx + n) * 4 * W + u0 + eu;
+        for (int g = 0; g < 4; ++g) za[g] = e[g * W + eu];
+        if (a.n_ctx > 0) {
+          const float* q = a.CtxK[0] + (long)c0_cur * 4 * W + u0;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) zin[g] += q[(long)g * W];
+          for (int g = 0; g < 4; ++g) zb[g] = q[g * W + eu];
+        }
+        for (int n = 1; n < a.n_ctx; ++n) {     // further context variables (rare): summed right away
+          const float* q = a.CtxK[n] + (long)sload_i32(a.ctx + ((long)erow * T + t) * a.n_ctx + n) * 4 * W + u0;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) zb[g] += q[g * W + eu];
         }
       }
       float mk = 1.f;
       if (maskl) mk = maskl[(long)erow * W + u0 + eu];
-      SSTAMP(0);
-      if (tid == 0) {
-        bool ok = alive;
-        if (ok && t > 0) ok = poll_counter(cnt_own + (long)rb * T + (t - 1), 2 * NWG_RB, status);
-        ok_flag = ok ? 1 : 0;
-      }
-      SSTAMP(1);
-      __syncthreads();
-      SSTAMP(2);
-      alive = ok_flag != 0;
-      if (wave < KSTEPS) {   // one fragment of the 16 x W tile of h[t-1] per wave
-        const int arow = min(r0 + (lane & 15), B - 1);
-        const uint4 v = alive ? load16_sc1(rs_h, (unsigned)((((long)t * B + arow) * W + wave * 32 + kq) * 2)) : uint4{0, 0, 0, 0};
-        *reinterpret_cast<uint4*>(a_tile + wave * 1024 + lane * 16) = v;
-      }
       SSTAMP(3);
       __syncthreads();
       SSTAMP(4);
+      if (SENT) alive = ok_flag != 0;
       f32x4 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -961,7 +1020,10 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
       const int wz = (eu >> 4) * 4, ue = eu & 15;
       float z[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) z[g] = zin[g] + zt[wz][g][er][ue] + zt[wz + 1][g][er][ue] + zt[wz + 2][g][er][ue] + zt[wz + 3][g][er][ue];
+      for (int g = 0; g < 4; ++g) {
+        asm volatile("" : "+v"(za[g]), "+v"(zb[g]));     // first use of the gate-input loads: here, not earlier
+        z[g] = (za[g] + zb[g] + bias_l[g * 64 + eu]) + zt[wz][g][er][ue] + zt[wz + 1][g][er][ue] + zt[wz + 2][g][er][ue] + zt[wz + 3][g][er][ue];
+      }
       const float gi = fast_sigmoid(z[0]), gf = fast_sigmoid(z[1]), gg = fast_tanh(z[2]), go = fast_sigmoid(z[3]);
       const float c = gf * (MAXRB > 1 ? c_slot[i * 1024] : c_one) + gi * gg;
       if (MAXRB > 1) c_slot[i * 1024] = c;
@@ -969,61 +1031,85 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
       const float h = go * fast_tanh(c);
       const bool row_ok = (r0 + er) < B;
       const unsigned hb = f2bf(h), hdb = f2bf(h * mk);
-      const long orow = (long)t * B + r0 + er;
+      // everything leaves through LDS as whole 16-byte pieces: the publish (waves 0, 1) and what
+      // only later launches read (waves 2..15)
       pub[er * 64 + eu] = (bf16_t)hb;
       tr[eu * 16 + er] = row_ok ? (bf16_t)hb : (bf16_t)0;
       tr[(64 + eu) * 16 + er] = row_ok ? (bf16_t)hdb : (bf16_t)0;
+      st_c[er * 64 + eu] = c;
+      st_hd[er * 64 + eu] = (bf16_t)hdb;
+      st_g[(0 * 16 + er) * 64 + eu] = f2bf(gi);
+      st_g[(1 * 16 + er) * 64 + eu] = f2bf(gf);
+      st_g[(2 * 16 + er) * 64 + eu] = f2bf(gg);
+      st_g[(3 * 16 + er) * 64 + eu] = f2bf(go);
       SSTAMP(7);
       __syncthreads();
       SSTAMP(8);
-      // publish h[t]: two waves, one 16-byte write-through store per lane; each storing wave
-      // drains its own stores and then counts itself in (2 arrivals per workgroup)
-      if (tid < 128) {
-        // With several row blocks per workgroup the drain of one block's stores is deferred to
-        // the next block's publish: the other block's whole step hides the write-through latency
-        // instead of every wave waiting for it at the next barrier.
-        if (MAXRB > 1 && pend >= 0) {
+      const unsigned trow = (unsigned)(t * B + r0);      // first time-major row of this tile (uniform)
+      if (wave < 2) {
+        // publish h[t]: two waves, one 16-byte write-through store per lane
+        if (!SENT && MAXRB > 1 && pend >= 0) {
+          // counters, several row blocks per workgroup: the previous block's drain + signal happen
+          // here, its write-through latency hidden behind this block's step
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) __hip_atomic_fetch_add(cnt_own + pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const int prow = tid >> 3, seg = tid & 7;
         if (alive && r0 + prow < B) {
           const uint4 v = *reinterpret_cast<const uint4*>(pub + prow * 64 + seg * 8);
-          store16_sc1(rs_h, (unsigned)((((long)(t + 1) * B + r0 + prow) * W + u0 + seg * 8) * 2), v);
+          store16_sc1(rs_h, (unsigned)((prow * W + seg * 8) * 2) + ((trow + B) * W + u0) * 2u, v);
         }
-        if (MAXRB > 1 && defer) {
-          pend = rb * T + t;           // drained and signalled at the next publish (see above)
+        if (SENT) {
+          // the data is its own signal: nothing to drain, nothing to count
+        } else if (MAXRB > 1 && defer) {
+          pend = rb * T + t;
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           SSTAMP(9);
           if (lane == 0) __hip_atomic_fetch_add(cnt_own + (long)rb * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-      }
-      SSTAMP(10);
-      // off the hand-off chain: what only later launches read
-      if (row_ok && alive) {
-        Cl[(orow + B) * W + u0 + eu] = c;
-        if (Hdl) Hdl[orow * W + u0 + eu] = (bf16_t)hdb;
-        if (Gl) {
-          bf16_t* gp = Gl + orow * 4 * W + u0 + eu;
-          gp[0] = f2bf(gi);
-          gp[W] = f2bf(gf);
-          gp[2 * W] = f2bf(gg);
-          gp[3 * W] = f2bf(go);
+        SSTAMP(10);
+      } else if (alive) {
+        // off the hand-off chain (buffer stores: lane offset + scalar step offset; a null buffer has
+        // zero records and drops the store)
+        const int q = tid - 128;
+        if (q < 512) {                       // gate activations: [gate][row] x 8 pieces of 8 units
+          const int g = q >> 7, prow = (q >> 3) & 15, seg = q & 7;
+          if (r0 + prow < B)
+            store16(rs_g, (unsigned)((prow * 4 * W + g * W + seg * 8) * 2), (trow * 4 * W + u0) * 2u,
+                    *reinterpret_cast<const uint4*>(st_g + (g * 16 + prow) * 64 + seg * 8));
+        } else if (q < 768) {                // cell state: [row] x 16 pieces of 4 units
+          const int prow = (q - 512) >> 4, seg = q & 15;
+          if (r0 + prow < B)
+            store16(rs_c, (unsigned)((prow * W + seg * 4) * 4), ((trow + B) * W + u0) * 4u,
+                    *reinterpret_cast<const uint4*>(st_c + prow * 64 + seg * 4));
+        } else {                             // masked outputs: [row] x 8 pieces of 8 units
+          const int prow = (q - 768) >> 3, seg = q & 7;
+          if (r0 + prow < B)
+            store16(rs_hd, (unsigned)((prow * W + seg * 8) * 2), (trow * W + u0) * 2u,
+                    *reinterpret_cast<const uint4*>(st_hd + prow * 64 + seg * 8));
+        }
+        if (q < 256) {   // transposed copies: 64 units x 16 rows, two 16-byte stores per unit (x2 buffers)
+          const int which = q >> 7, unit = (q >> 1) & 63, half = q & 1;
+          if (r0 + half * 8 < B) {
+            const uint4 v = *reinterpret_cast<const uint4*>(tr + (which * 64 + unit) * 16 + half * 8);
+            if (which) store16(rs_hdt, (unsigned)(((long)(u0 + unit) * a.ldt_d + half * 8) * 2), trow * 2u, v);
+            else store16(rs_ht, (unsigned)(((long)(u0 + unit) * a.ldt + half * 8) * 2), (trow + B) * 2u, v);
+          }
         }
       }
-      if (alive && tid < 256) {   // transposed copies: 64 units x 16 rows, two 16-byte stores per unit (x2 buffers)
-        const int which = tid >> 7, unit = (tid >> 1) & 63, half = tid & 1;
-        bf16_t* dst = which ? HdT : HT;
-        if (dst && r0 + half * 8 < B) {
-          const long tcol = (which ? (long)t * B : (long)(t + 1) * B) + r0 + half * 8;
-          *reinterpret_cast<uint4*>(dst + (long)(u0 + unit) * (which ? a.ldt_d : ldt) + tcol) =
-              *reinterpret_cast<const uint4*>(tr + (which * 64 + unit) * 16 + half * 8);
+      if (!P) {   // ids of the next (step, row block) this workgroup visits
+        int ni = i + 1, nt = t;
+        if (ni >= MAXRB || rg + ni * n_rg >= n_rb) { ni = 0; nt = t + 1; }
+        if (nt < T) {
+          const long nsrc = (long)min((rg + ni * n_rg) * 16 + er, B - 1) * T + nt;
+          id_cur = sload_i32(a.idx + nsrc);
+          if (a.n_ctx > 0) c0_cur = sload_i32(a.ctx + nsrc * a.n_ctx);
         }
       }
     }
   }
-  if (MAXRB > 1 && tid < 128 && pend >= 0) {
+  if (!SENT && MAXRB > 1 && wave < 2 && pend >= 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(cnt_own + pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -1152,14 +1238,20 @@ int kl_launch_scan_fwd_wide(KlScanFwdWide a, hipStream_t stream) {
   dim3 grid(col_groups * g), block(1024);
   const size_t lds = (size_t)KL_FWD_WIDE_LDS(W / 32) + (per_wg > 1 ? 4 : 0) * 1024 * sizeof(float);
   if ((long)(a.T + 1) * a.B * W * 2 > 0x7fffffffL) return KL_ERR_SHAPE;   // 32-bit buffer offsets
-#define KL_WIDE_CASE(KS, RB)                                                                                         \
+#define KL_WIDE_CASE2(KS, RB, S)                                                                                     \
   do {                                                                                                               \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_fwd_wide_kernel<KS, RB>),                     \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_fwd_wide_kernel<KS, RB, S>),                  \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH; \
-    hipLaunchKernelGGL((lstm_scan_fwd_wide_kernel<KS, RB>), grid, block, lds, stream, a);                            \
+    hipLaunchKernelGGL((lstm_scan_fwd_wide_kernel<KS, RB, S>), grid, block, lds, stream, a);                         \
+  } while (0)
+#define KL_WIDE_CASE(KS, RB)                          \
+  do {                                                \
+    if (a.sentinel) KL_WIDE_CASE2(KS, RB, true);      \
+    else KL_WIDE_CASE2(KS, RB, false);                \
   } while (0)
   if (W == 512) { if (per_wg == 1) KL_WIDE_CASE(16, 1); else if (per_wg == 2) KL_WIDE_CASE(16, 2); else KL_WIDE_CASE(16, 4); }
   else { if (per_wg == 1) KL_WIDE_CASE(8, 1); else if (per_wg == 2) KL_WIDE_CASE(8, 2); else KL_WIDE_CASE(8, 4); }
+#undef KL_WIDE_CASE2
 #undef KL_WIDE_CASE
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
