@@ -100,6 +100,19 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.f;
 }
 
+// The publishing waves of a workgroup count themselves in through LDS; the last one makes the ONE
+// agent-scope add for the workgroup (64 same-address atomics per counter cost ~0.7 us of serialised
+// latency, 8 do not).  Call after the wave's own s_waitcnt vmcnt(0).
+__device__ __forceinline__ void signal_once(int* arrive, int n_waves, unsigned* counter, int lane) {
+  if (lane == 0) {
+    const int old = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (old == n_waves - 1) {
+      __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // one lane polls; true = reached.  Raises/observes the abort word.
 __device__ __forceinline__ bool poll_counter(const unsigned* cnt, unsigned target, unsigned* status) {
   for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
@@ -644,7 +657,8 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
   constexpr int W = KSTEPS * 32;
   constexpr int NWG_RB = W / 64;          // producers per (row block, step)
   constexpr int JW = KSTEPS / 4;          // k-steps of a quarter that one wave fetches
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq4 = wave & 3, ug = wave >> 2;
   const int n_rg = a.n_rg, n_rb = a.n_rb, B = a.B, T = a.T;
   const int cg = blockIdx.x / n_rg, rg = blockIdx.x % n_rg;
@@ -657,6 +671,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
   // (all LDS in the dynamic region: a static object in front would shift its 16-byte alignment)
   bf16_t* pub = tr + 4 * 64 * 16;                                         // [4 gates][16 rows][64 units]
   int& ok_flag = *reinterpret_cast<int*>(smem + 4 * KSTEPS * 1024 + 16 * 16 * 17 * 4 + 2 * 4 * 64 * 16 * 2);
+  int* arrive = &ok_flag + 1;              // publishing waves that have drained their stores
 
   const int kq = (lane >> 4) * 8;
   uint4 bu[KSTEPS];
@@ -665,7 +680,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
 #pragma unroll
     for (int j = 0; j < KSTEPS; ++j) bu[j] = *reinterpret_cast<const uint4*>(a.Un[0] + wrow + j * 32 + kq);
   }
-  const int er = tid >> 6, eu = tid & 63;          // epilogue thread = (row, unit of 64)
+  const int er = wave, eu = lane;                  // epilogue thread = (row = wave: scalar, unit of 64)
   // running dc of this thread's (row, unit) per row block: a register for one block, else LDS
   // slots (the row-block loop stays rolled: unrolled it spilled 7-47 VGPRs at the 128 cap)
   float dc_one = 0.f;
@@ -678,14 +693,16 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
   const bf16_t* Gl = a.G[0];
   const float* Cl = a.C[0];
   bf16_t* dZl = a.dZ[0];
-  bf16_t* dZT = a.dZT;
-  const long ldt = a.ldt;
+  const bool has_dzt = a.dZT != nullptr;
+  const __amdgpu_buffer_rsrc_t rs_dzt = make_rsrc(a.dZT, has_dzt ? (long)4 * W * a.ldt * 2 : 0);
   const float* dH = a.dH;
   const float* maskl = a.mask[0];
   unsigned* status = a.status;
   const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(dZl, (long)T * BW * 4 * 2);
   unsigned* cnt_own = a.counters;
   bool alive = true;
+  if (tid == 0) *arrive = 0;
+  __syncthreads();
   int pend = -1;       // publishing waves: counter index of stores issued but not yet signalled
   // (deferring needs a second row block whose publish releases the first one's signal: a workgroup
   // with a single block would wait for its own deferred signal)
@@ -701,17 +718,19 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
       const int rb = rg + i * n_rg;
       if (rb >= n_rb) continue;
       const int r0 = rb * 16;
-      const int erow = min(r0 + er, B - 1);
-      const bf16_t* gp = Gl + ((long)t * B + erow) * 4 * W + u0 + eu;
-      const bf16_t g0 = gp[0], g1 = gp[W], g2 = gp[2 * W], g3 = gp[3 * W];
-      const float c = Cl[((long)(t + 1) * B + erow) * W + u0 + eu];
-      const float cp = Cl[((long)t * B + erow) * W + u0 + eu];
-      float dh = dH[((long)t * B + erow) * W + u0 + eu];
-      if (maskl) dh *= maskl[(long)erow * W + u0 + eu];
+      const int erow = min(r0 + er, B - 1);          // wave-uniform: scalar row bases, one lane offset per load
+      // (raw loads only; they are consumed in the epilogue behind a compiler fence, or their waits --
+      // in-order behind the previous step's write-through stores -- would be scheduled right here)
+      const bf16_t* gp = Gl + ((long)t * B + erow) * 4 * W + u0;
+      unsigned g0 = gp[eu], g1 = gp[W + eu], g2 = gp[2 * W + eu], g3 = gp[3 * W + eu];
+      float c = (Cl + ((long)(t + 1) * B + erow) * W + u0)[eu];
+      float cp = (Cl + ((long)t * B + erow) * W + u0)[eu];
+      float dh = (dH + ((long)t * B + erow) * W + u0)[eu];
+      float mkv = maskl ? (maskl + (long)erow * W + u0)[eu] : 1.f;
       SSTAMP(16);
       if (tid == 0) {
         bool ok = alive;
-        if (ok && t < T - 1) ok = poll_counter(cnt_own + (long)rb * T + (t + 1), 8 * NWG_RB, status);
+        if (ok && t < T - 1) ok = poll_counter(cnt_own + (long)rb * T + (t + 1), NWG_RB, status);
         ok_flag = ok ? 1 : 0;
       }
       SSTAMP(17);
@@ -746,8 +765,9 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
       __syncthreads();
       SSTAMP(22);
       const int wz = (eu >> 4) * 4;      // the four K-quarter waves of this unit group
-      dh += zt[wz][er][eu & 15] + zt[wz + 1][er][eu & 15] + zt[wz + 2][er][eu & 15] + zt[wz + 3][er][eu & 15];
-      const float gi = bf2f(g0), gf = bf2f(g1), gg = bf2f(g2), go = bf2f(g3);
+      asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(c), "+v"(cp), "+v"(dh), "+v"(mkv));
+      dh = dh * mkv + (zt[wz][er][eu & 15] + zt[wz + 1][er][eu & 15] + zt[wz + 2][er][eu & 15] + zt[wz + 3][er][eu & 15]);
+      const float gi = bf2f((bf16_t)g0), gf = bf2f((bf16_t)g1), gg = bf2f((bf16_t)g2), go = bf2f((bf16_t)g3);
       const float tc = fast_tanh(c);
       const float dc = dh * go * (1.f - tc * tc) + (MAXRB > 1 ? dc_slot[i * 1024] : dc_one);
       if (MAXRB > 1) dc_slot[i * 1024] = dc * gf;
@@ -763,7 +783,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
       pub[(1 * 16 + er) * 64 + eu] = (bf16_t)z1;
       pub[(2 * 16 + er) * 64 + eu] = (bf16_t)z2;
       pub[(3 * 16 + er) * 64 + eu] = (bf16_t)z3;
-      if (dZT) {   // stage the tile transposed for the off-chain copy below
+      if (has_dzt) {   // stage the tile transposed for the off-chain copy below
         tr[(0 * 64 + eu) * 16 + er] = row_ok ? (bf16_t)z0 : (bf16_t)0;
         tr[(1 * 64 + eu) * 16 + er] = row_ok ? (bf16_t)z1 : (bf16_t)0;
         tr[(2 * 64 + eu) * 16 + er] = row_ok ? (bf16_t)z2 : (bf16_t)0;
@@ -773,13 +793,13 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
       __syncthreads();
       SSTAMP(24);
       // publish dZ[t]: eight waves, one 16-byte write-through store per lane; each storing
-      // wave drains its own stores and then counts itself in (8 arrivals per workgroup)
+      // wave drains its own stores, the last one signals for the workgroup
       if (tid < 512) {
         // (several row blocks per workgroup: the previous block's drain + signal happen here, its
         // write-through latency hidden behind this block's step)
         if (MAXRB > 1 && pend >= 0) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) __hip_atomic_fetch_add(cnt_own + pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          signal_once(arrive, 8, cnt_own + pend, lane);
         }
         const int g = tid >> 7, prow = (tid >> 3) & 15, seg = tid & 7;
         if (alive && r0 + prow < B) {
@@ -791,29 +811,24 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           SSTAMP(25);
-          if (lane == 0) __hip_atomic_fetch_add(cnt_own + (long)rb * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          signal_once(arrive, 8, cnt_own + (long)rb * T + t, lane);
         }
       }
       SSTAMP(26);
-      if (dZT && alive && tid >= 512) {
-        // 256 columns (gate, unit) x 16 rows: two 16-byte stores per column
-        // (the waves that do not publish)
+      if (has_dzt && alive && wave >= 8) {
+        // 256 columns (gate, unit) x 16 rows: two 16-byte stores per column (the waves that do not
+        // publish); buffer store = lane offset + scalar step offset (B % 8 == 0 is a launch condition)
         const int col = (tid - 512) >> 1, half = tid & 1;
         const int g = col >> 6, u = col & 63;
-        const long trow = (long)g * W + u0 + u;
-        const long tcol = (long)t * B + r0 + half * 8;
-        if (r0 + half * 8 + 8 <= B || (B & 7) == 0) {
-          if (r0 + half * 8 < B)
-            *reinterpret_cast<uint4*>(dZT + trow * ldt + tcol) = *reinterpret_cast<const uint4*>(tr + col * 16 + half * 8);
-        } else {
-          for (int q = 0; q < 8 && r0 + half * 8 + q < B; ++q) dZT[trow * ldt + tcol + q] = tr[col * 16 + half * 8 + q];
-        }
+        if (r0 + half * 8 < B)
+          store16(rs_dzt, (unsigned)(((long)(g * W + u0 + u) * a.ldt + half * 8) * 2), (unsigned)(t * B + r0) * 2u,
+                  *reinterpret_cast<const uint4*>(tr + col * 16 + half * 8));
       }
     }
   }
   if (MAXRB > 1 && tid < 512 && pend >= 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(cnt_own + pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    signal_once(arrive, 8, cnt_own + pend, lane);
   }
   // db[g*W + u] += sum over this workgroup's rows and all steps (16 partials per column meet in LDS)
   if (a.db) {
@@ -862,6 +877,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
   bf16_t* tr = reinterpret_cast<bf16_t*>(smem + KSTEPS * 1024 + 16 * 4 * 16 * 17 * 4);   // [2][64 units][16 rows]
   bf16_t* pub = tr + 2 * 64 * 16;                                                       // [16 rows][64 units]
   int& ok_flag = *reinterpret_cast<int*>(smem + KSTEPS * 1024 + 16 * 4 * 16 * 17 * 4 + 2 * 64 * 16 * 2 + 16 * 64 * 2);
+  int* arrive = &ok_flag + 1;              // publishing waves that have drained their stores
   float* st_c = reinterpret_cast<float*>(smem + KL_FWD_WIDE_LDS0(KSTEPS));              // [16 rows][64 units] staged c
   bf16_t* st_g = reinterpret_cast<bf16_t*>(st_c + 16 * 64);                             // [4 gates][16 rows][64 units]
   bf16_t* st_hd = st_g + 4 * 16 * 64;                                                   // [16 rows][64 units]
@@ -900,7 +916,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
   const __amdgpu_buffer_rsrc_t rs_hdt = make_rsrc(a.HdT, a.HdT ? (long)W * a.ldt_d * 2 : 0);
   unsigned* cnt_own = a.counters;
   bool alive = true;
-  if (tid == 0) ok_flag = 1;
+  if (tid == 0) { ok_flag = 1; *arrive = 0; }
   __syncthreads();
   int pend = -1;       // counter hand-off, publishing waves: counter index of stores issued but not yet signalled
   // (deferring needs a second row block whose publish releases the first one's signal: a workgroup
@@ -930,7 +946,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
       if (!SENT) {
         if (tid == 0) {
           bool ok = alive;
-          if (ok && t > 0) ok = poll_counter(cnt_own + (long)rb * T + (t - 1), 2 * NWG_RB, status);
+          if (ok && t > 0) ok = poll_counter(cnt_own + (long)rb * T + (t - 1), NWG_RB, status);
           ok_flag = ok ? 1 : 0;
         }
         SSTAMP(1);
@@ -1052,7 +1068,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
           // counters, several row blocks per workgroup: the previous block's drain + signal happen
           // here, its write-through latency hidden behind this block's step
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) __hip_atomic_fetch_add(cnt_own + pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          signal_once(arrive, 2, cnt_own + pend, lane);
         }
         const int prow = tid >> 3, seg = tid & 7;
         if (alive && r0 + prow < B) {
@@ -1066,7 +1082,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           SSTAMP(9);
-          if (lane == 0) __hip_atomic_fetch_add(cnt_own + (long)rb * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          signal_once(arrive, 2, cnt_own + (long)rb * T + t, lane);
         }
         SSTAMP(10);
       } else if (alive) {
@@ -1111,7 +1127,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
   }
   if (!SENT && MAXRB > 1 && wave < 2 && pend >= 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(cnt_own + pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    signal_once(arrive, 2, cnt_own + pend, lane);
   }
 }
 
