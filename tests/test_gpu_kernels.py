@@ -322,3 +322,20 @@ def test_train_consecutive_windows_reuse_buffers(depth, width, voc, B, T):
             assert np.abs(got - g_ref[name]).max() / scale < 4e-2, (win, name)
         # keep the oracle's carried state identical to the engine's bf16-rounded one
         st = [got_st[:, k].astype(np.float64) for k in range(2 * depth)]
+
+
+@pytest.mark.parametrize("B,windows", [(512, 10), (1024, 4), (264, 6)])
+def test_handoff_flavours_agree_bitwise(B, windows):
+    """The scans' two hand-off protocols (data sentinels / counters) run the same arithmetic, so over
+    consecutive stateful windows the carried states must agree BITWISE -- a stale or torn read in either
+    protocol would show as a difference -- and the launch-per-step path must agree to bf16 accuracy
+    (tools/check_handoff.py screens hundreds of windows the same way)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "check_handoff", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_handoff.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, g, c = mod.run(B, windows, verbose=False)
+    assert bad == 0
+    assert g < 1e-3 and c < 5e-2, (g, c)
