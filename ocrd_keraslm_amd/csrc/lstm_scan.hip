@@ -100,17 +100,11 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.f;
 }
 
-// The publishing waves of a workgroup count themselves in through LDS; the last one makes the ONE
-// agent-scope add for the workgroup (64 same-address atomics per counter cost ~0.7 us of serialised
-// latency, 8 do not).  Call after the wave's own s_waitcnt vmcnt(0).
-__device__ __forceinline__ void signal_once(int* arrive, int n_waves, unsigned* counter, int lane) {
-  if (lane == 0) {
-    const int old = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (old == n_waves - 1) {
-      __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+// Every publishing wave counts itself in after draining its own stores (valid form "each storing wave
+// for itself", MI355X_MICROARCH.md); consumers wait for waves x workgroups arrivals.  (A/B on one box:
+// funnelling the arrivals through an LDS counter so that only ONE wave per workgroup adds was 3 % slower.)
+__device__ __forceinline__ void signal_wave(unsigned* counter, int lane) {
+  if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // one lane polls; true = reached.  Raises/observes the abort word.
@@ -671,7 +665,6 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
   // (all LDS in the dynamic region: a static object in front would shift its 16-byte alignment)
   bf16_t* pub = tr + 4 * 64 * 16;                                         // [4 gates][16 rows][64 units]
   int& ok_flag = *reinterpret_cast<int*>(smem + 4 * KSTEPS * 1024 + 16 * 16 * 17 * 4 + 2 * 4 * 64 * 16 * 2);
-  int* arrive = &ok_flag + 1;              // publishing waves that have drained their stores
 
   const int kq = (lane >> 4) * 8;
   uint4 bu[KSTEPS];
@@ -701,8 +694,6 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
   const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(dZl, (long)T * BW * 4 * 2);
   unsigned* cnt_own = a.counters;
   bool alive = true;
-  if (tid == 0) *arrive = 0;
-  __syncthreads();
   int pend = -1;       // publishing waves: counter index of stores issued but not yet signalled
   // (deferring needs a second row block whose publish releases the first one's signal: a workgroup
   // with a single block would wait for its own deferred signal)
@@ -730,7 +721,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
       SSTAMP(16);
       if (tid == 0) {
         bool ok = alive;
-        if (ok && t < T - 1) ok = poll_counter(cnt_own + (long)rb * T + (t + 1), NWG_RB, status);
+        if (ok && t < T - 1) ok = poll_counter(cnt_own + (long)rb * T + (t + 1), 8 * NWG_RB, status);
         ok_flag = ok ? 1 : 0;
       }
       SSTAMP(17);
@@ -765,7 +756,9 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
       __syncthreads();
       SSTAMP(22);
       const int wz = (eu >> 4) * 4;      // the four K-quarter waves of this unit group
+#ifndef KL_BWD_NOFENCE
       asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(c), "+v"(cp), "+v"(dh), "+v"(mkv));
+#endif
       dh = dh * mkv + (zt[wz][er][eu & 15] + zt[wz + 1][er][eu & 15] + zt[wz + 2][er][eu & 15] + zt[wz + 3][er][eu & 15]);
       const float gi = bf2f((bf16_t)g0), gf = bf2f((bf16_t)g1), gg = bf2f((bf16_t)g2), go = bf2f((bf16_t)g3);
       const float tc = fast_tanh(c);
@@ -793,13 +786,13 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
       __syncthreads();
       SSTAMP(24);
       // publish dZ[t]: eight waves, one 16-byte write-through store per lane; each storing
-      // wave drains its own stores, the last one signals for the workgroup
+      // wave drains its own stores and then counts itself in (8 arrivals per workgroup)
       if (tid < 512) {
         // (several row blocks per workgroup: the previous block's drain + signal happen here, its
         // write-through latency hidden behind this block's step)
         if (MAXRB > 1 && pend >= 0) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          signal_once(arrive, 8, cnt_own + pend, lane);
+          signal_wave(cnt_own + pend, lane);
         }
         const int g = tid >> 7, prow = (tid >> 3) & 15, seg = tid & 7;
         if (alive && r0 + prow < B) {
@@ -811,7 +804,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           SSTAMP(25);
-          signal_once(arrive, 8, cnt_own + (long)rb * T + t, lane);
+          signal_wave(cnt_own + (long)rb * T + t, lane);
         }
       }
       SSTAMP(26);
@@ -828,7 +821,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
   }
   if (MAXRB > 1 && tid < 512 && pend >= 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    signal_once(arrive, 8, cnt_own + pend, lane);
+    signal_wave(cnt_own + pend, lane);
   }
   // db[g*W + u] += sum over this workgroup's rows and all steps (16 partials per column meet in LDS)
   if (a.db) {
@@ -877,7 +870,6 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
   bf16_t* tr = reinterpret_cast<bf16_t*>(smem + KSTEPS * 1024 + 16 * 4 * 16 * 17 * 4);   // [2][64 units][16 rows]
   bf16_t* pub = tr + 2 * 64 * 16;                                                       // [16 rows][64 units]
   int& ok_flag = *reinterpret_cast<int*>(smem + KSTEPS * 1024 + 16 * 4 * 16 * 17 * 4 + 2 * 64 * 16 * 2 + 16 * 64 * 2);
-  int* arrive = &ok_flag + 1;              // publishing waves that have drained their stores
   float* st_c = reinterpret_cast<float*>(smem + KL_FWD_WIDE_LDS0(KSTEPS));              // [16 rows][64 units] staged c
   bf16_t* st_g = reinterpret_cast<bf16_t*>(st_c + 16 * 64);                             // [4 gates][16 rows][64 units]
   bf16_t* st_hd = st_g + 4 * 16 * 64;                                                   // [16 rows][64 units]
@@ -916,7 +908,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
   const __amdgpu_buffer_rsrc_t rs_hdt = make_rsrc(a.HdT, a.HdT ? (long)W * a.ldt_d * 2 : 0);
   unsigned* cnt_own = a.counters;
   bool alive = true;
-  if (tid == 0) { ok_flag = 1; *arrive = 0; }
+  if (tid == 0) ok_flag = 1;
   __syncthreads();
   int pend = -1;       // counter hand-off, publishing waves: counter index of stores issued but not yet signalled
   // (deferring needs a second row block whose publish releases the first one's signal: a workgroup
@@ -946,7 +938,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
       if (!SENT) {
         if (tid == 0) {
           bool ok = alive;
-          if (ok && t > 0) ok = poll_counter(cnt_own + (long)rb * T + (t - 1), NWG_RB, status);
+          if (ok && t > 0) ok = poll_counter(cnt_own + (long)rb * T + (t - 1), 2 * NWG_RB, status);
           ok_flag = ok ? 1 : 0;
         }
         SSTAMP(1);
@@ -1068,7 +1060,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
           // counters, several row blocks per workgroup: the previous block's drain + signal happen
           // here, its write-through latency hidden behind this block's step
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          signal_once(arrive, 2, cnt_own + pend, lane);
+          signal_wave(cnt_own + pend, lane);
         }
         const int prow = tid >> 3, seg = tid & 7;
         if (alive && r0 + prow < B) {
@@ -1082,7 +1074,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           SSTAMP(9);
-          signal_once(arrive, 2, cnt_own + (long)rb * T + t, lane);
+          signal_wave(cnt_own + (long)rb * T + t, lane);
         }
         SSTAMP(10);
       } else if (alive) {
@@ -1127,7 +1119,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
   }
   if (!SENT && MAXRB > 1 && wave < 2 && pend >= 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    signal_once(arrive, 2, cnt_own + pend, lane);
+    signal_wave(cnt_own + pend, lane);
   }
 }
 

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libkeraslm_hip.so")
+# (KL_LIB: another build of the same library, e.g. the -DKL_STAMP diagnostic build or an A/B candidate)
+LIB_PATH = os.environ.get("KL_LIB") or os.path.join(os.path.dirname(_HERE), "libkeraslm_hip.so")
 
 KL_PREC_BF16 = 1
 KL_PREC_SPLIT = 3

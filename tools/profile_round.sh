@@ -1,0 +1,18 @@
+#!/bin/bash
+# Reproduce the round's measurement artefacts on a GPU box (run from the repo root):
+#   bench line, rocprofv3 kernel stats of the same command, and the two PMC passes for HBM traffic.
+# Usage: bash tools/profile_round.sh <tag> [streams]      -> files under gpurun_out/<tag>_*
+set -eo pipefail
+TAG=${1:-r01}
+B=${2:-512}
+export TMPDIR=/tmp
+OUT=gpurun_out
+mkdir -p $OUT
+timeout -k 10 500 python bench.py --streams $B > $OUT/${TAG}_bench_B${B}.json 2> $OUT/${TAG}_bench.err
+tail -c 1500 $OUT/${TAG}_bench_B${B}.json
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 bench.py --streams $B --steps 10 --warmup 3 --no-cpu-baseline --no-incremental > $OUT/${TAG}_bench_B${B}_under_rocprof.json 2> $OUT/${TAG}_rp.err
+cp $OUT/${TAG}_stats/*/*_kernel_stats.csv $OUT/${TAG}_bench_B${B}_kernel_stats.csv
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 bench.py --streams $B --steps 3 --warmup 1 --no-cpu-baseline --no-incremental > $OUT/${TAG}_pmc_f.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -- python3 bench.py --streams $B --steps 3 --warmup 1 --no-cpu-baseline --no-incremental > $OUT/${TAG}_pmc_w.log 2>&1
+python tools/pmc_summary.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_hbm_traffic_B${B}.json "cfg2 B=$B T=256"
+head -8 $OUT/${TAG}_bench_B${B}_kernel_stats.csv | cut -c1-160
