@@ -756,9 +756,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
       __syncthreads();
       SSTAMP(22);
       const int wz = (eu >> 4) * 4;      // the four K-quarter waves of this unit group
-#ifndef KL_BWD_NOFENCE
       asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(c), "+v"(cp), "+v"(dh), "+v"(mkv));
-#endif
       dh = dh * mkv + (zt[wz][er][eu & 15] + zt[wz + 1][er][eu & 15] + zt[wz + 2][er][eu & 15] + zt[wz + 3][er][eu & 15]);
       const float gi = bf2f((bf16_t)g0), gf = bf2f((bf16_t)g1), gg = bf2f((bf16_t)g2), go = bf2f((bf16_t)g3);
       const float tc = fast_tanh(c);
