@@ -103,6 +103,13 @@ size_t kl_window_workspace_bytes(const kl_handle* h, int B, int T, int training)
  * state after step T-1.  probs (may be NULL) receives [B][T][V].  If tgt != NULL,
  * loss_acc[0] += mean categorical cross-entropy over all B*T positions and
  * loss_acc[1] += accuracy (Keras semantics, rating.py:178); loss_acc is f32[4]. */
+/* Window mode of kl_forward_window / kl_train_window.  0 (default) = the reference's stateful graph:
+ * a target at every position, loss and accuracy are means over all B*T positions (rating.py:161-167,
+ * TimeDistributed output).  1 = its stateless graph (top LSTM layer without return_sequences,
+ * rating.py:126-129, 1123-1126): one target per row, at the LAST position (tgt[b][T-1]); loss and
+ * accuracy are means over the B rows, the other positions carry no gradient. */
+int kl_set_window_mode(kl_handle* h, int last_only);
+
 int kl_forward_window(kl_handle* h, int B, int T, const int32_t* idx, const int32_t* ctx, const int32_t* tgt,
                       float* states, float* probs, float* loss_acc, void* ws, size_t ws_bytes, void* stream);
 

@@ -102,6 +102,7 @@ struct kl_handle {
   bool scan_enabled = true;     // persistent scans (KL_SCAN=0 forces the launch-per-step path)
   bool seq_bwd = true;          // layer-sequential backward scans for many row blocks (KL_SEQ_BWD=0: always fused)
   bool wide_bwd = true;         // ... with 64-unit workgroups (KL_WIDE_BWD=0: thin workgroups)
+  int last_only = 0;            // stateless windows: one target per row, at the last position (kl_set_window_mode)
   bool sentinel = true;         // wide scans hand off by data sentinels instead of counters (KL_SENTINEL=0: counters)
   bool fused_step = true;       // incremental step, n >= 256: cell fused into the GEMM epilogue (KL_FUSED_STEP=0: separate kernels)
   int wide_fwd_min = 128;       // layer-sequential wide forward scans from this many 64-unit workgroups (KL_WIDE_FWD_MIN; 0 = never)
@@ -660,8 +661,8 @@ static int forward_window_body(kl_handle* h, int B, int T, const int32_t* idx, c
   op.A = (float*)w.H[L - 1] + (size_t)B * W; op.lda = W; op.a_is_f32 = 1;
   op.WT_hi = h->d.E_hi; op.WT_lo = h->precision == 3 ? h->d.E_lo : nullptr; op.ldw = W; op.K = W;
   KL_TRY(kl_launch_thin_gemm(&op, B * T, V, w.logits, V, nullptr, h->precision, s));
-  KL_TRY(kl_launch_softmax_ce(w.logits, V, B * T, V, tgt, B, T, 1.0f / ((float)B * T), nullptr, 0,
-                              tgt ? loss_acc : nullptr, w.rowstat, 1, s));
+  KL_TRY(kl_launch_softmax_ce(w.logits, V, B * T, V, tgt, B, T, 1.0f / (h->last_only ? (float)B : (float)B * T), nullptr, 0,
+                              tgt ? loss_acc : nullptr, w.rowstat, 1, s, h->last_only));
   if (probs) {
     if (B == 1) KL_TRY(hip_ok(hipMemcpyAsync(probs, w.logits, (size_t)T * V * sizeof(float), hipMemcpyDeviceToDevice, s)));
     else KL_TRY(kl_launch_rows_tm_to_bm(w.logits, V, probs, B, T, V, s));
@@ -696,7 +697,8 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   const bool top_masked = masks != nullptr && L > 1;
   const bf16_t* Htop = top_masked ? w.Hd[L - 1] : (const bf16_t*)w.H[L - 1] + BW;
   KL_TRY(kl_launch_gemm_tn(Htop, d.E_hi, w.logits, nullptr, BT, V, W, W, W, V, 0, 1, 1.f, s));
-  KL_TRY(kl_launch_softmax_ce(w.logits, V, BT, V, tgt, B, T, 1.0f / (float)BT, w.dlogits, Vp, loss_acc, w.rowstat, 1, s));
+  KL_TRY(kl_launch_softmax_ce(w.logits, V, BT, V, tgt, B, T, 1.0f / (h->last_only ? (float)B : (float)BT), w.dlogits, Vp, loss_acc,
+                              w.rowstat, 1, s, h->last_only));
   // B1: dH = dlogits . E ; dE += dlogits^T . Htop
   KL_TRY(kl_launch_gemm_tn(w.dlogits, d.ET, w.dH, nullptr, BT, W, Vp, Vp, Vp, W, 0, 1, 1.f, s));
   if (BTp != BT) {
@@ -1142,6 +1144,12 @@ int run_graphed(kl_handle* h, const kl_handle::GraphKey& key, hipStream_t s, con
 
 }  // namespace
 
+extern "C" int kl_set_window_mode(kl_handle* h, int last_only) {
+  if (!h) return KL_ERR_ARG;
+  h->last_only = last_only ? 1 : 0;
+  return 0;
+}
+
 extern "C" int kl_forward_window(kl_handle* h, int B, int T, const int32_t* idx, const int32_t* ctx, const int32_t* tgt,
                                  float* states, float* probs, float* loss_acc, void* ws, size_t ws_bytes,
                                  void* stream) {
@@ -1156,7 +1164,7 @@ extern "C" int kl_forward_window(kl_handle* h, int B, int T, const int32_t* idx,
   if (h->cfg.n_ctx > 0)
     KL_TRY(hip_ok(hipMemcpyAsync(w.s_ctx, ctx, BT * h->cfg.n_ctx * sizeof(int), hipMemcpyDeviceToDevice, s)));
   if (tgt) KL_TRY(hip_ok(hipMemcpyAsync(w.s_tgt, tgt, BT * sizeof(int), hipMemcpyDeviceToDevice, s)));
-  kl_handle::GraphKey key{0, B, T, (tgt ? 1 : 0) | (probs ? 2 : 0), h->precision, states, loss_acc, ws, nullptr};
+  kl_handle::GraphKey key{0, B, T, (tgt ? 1 : 0) | (probs ? 2 : 0) | (h->last_only ? 4 : 0), h->precision, states, loss_acc, ws, nullptr};
   KL_TRY(run_graphed(h, key, s, [&]() {
     return forward_window_body(h, B, T, w.s_idx, w.s_ctx, tgt ? w.s_tgt : nullptr, states, probs ? w.s_probs : nullptr,
                                loss_acc, ws, ws_bytes, stream);
@@ -1183,7 +1191,7 @@ extern "C" int kl_train_window(kl_handle* h, int B, int T, const int32_t* idx, c
   if (masks)
     KL_TRY(hip_ok(hipMemcpyAsync(w.s_masks, masks, (size_t)h->cfg.depth * B * h->cfg.width * sizeof(float),
                                  hipMemcpyDeviceToDevice, s)));
-  kl_handle::GraphKey key{1, B, T, masks ? 1 : 0, h->precision, states, loss_acc, ws, grads};
+  kl_handle::GraphKey key{1, B, T, (masks ? 1 : 0) | (h->last_only ? 4 : 0), h->precision, states, loss_acc, ws, grads};
   return run_graphed(h, key, s, [&]() {
     return train_window_body(h, B, T, w.s_idx, w.s_ctx, w.s_tgt, states, masks ? w.s_masks : nullptr, grads, loss_acc,
                              ws, ws_bytes, stream);

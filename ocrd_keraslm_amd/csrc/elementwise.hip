@@ -90,7 +90,7 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ in, long ld_in, int
 // targets are [B][T] with -1 = all-zero one-hot row (padded tail).
 __global__ void softmax_ce_kernel(float* __restrict__ logits, long ld, int rows, int V, const int* __restrict__ tgt,
                                   int B, int T, float inv_count, bf16_t* __restrict__ dlogits, long ld_dl,
-                                  float* __restrict__ rowstat, int time_major) {
+                                  float* __restrict__ rowstat, int time_major, int last_only) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -113,10 +113,12 @@ __global__ void softmax_ce_kernel(float* __restrict__ logits, long ld, int rows,
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
   const float inv = 1.f / sum;
   int t = -2;
+  bool counts = true;        // stateless windows (last_only): only the last position has a target at all
   if (tgt) {
     const int b = time_major ? row % B : row / T;
     const int tt = time_major ? row / B : row % T;
     t = tgt[(long)b * T + tt];
+    if (last_only && tt != T - 1) { t = -1; counts = false; }
   }
   float pt = 0.f;
   for (int v = lane; v < V; v += 64) {
@@ -145,7 +147,7 @@ __global__ void softmax_ce_kernel(float* __restrict__ logits, long ld, int rows,
     }
     const int tsafe = valid ? t : 0;
     rowstat[2 * (long)row] = l;
-    rowstat[2 * (long)row + 1] = (amax == tsafe) ? inv_count : 0.f;
+    rowstat[2 * (long)row + 1] = (counts && amax == tsafe) ? inv_count : 0.f;
   }
 }
 
@@ -347,11 +349,11 @@ int kl_launch_f32_to_bf16_t(const float* in, long ld_in, int rows, int cols, bf1
 
 int kl_launch_softmax_ce(float* logits, long ld, int rows, int V, const int* tgt, int B, int T, float inv_count,
                          bf16_t* dlogits, long ld_dl, float* loss_acc, float* rowstat, int time_major,
-                         hipStream_t stream) {
+                         hipStream_t stream, int last_only) {
   dim3 grid((rows + 3) / 4);
   const bool stats = tgt != nullptr && loss_acc != nullptr && rowstat != nullptr;
   hipLaunchKernelGGL(softmax_ce_kernel, grid, dim3(256), 0, stream, logits, ld, rows, V, tgt, B, T, inv_count,
-                     dlogits, ld_dl, stats ? rowstat : nullptr, time_major);
+                     dlogits, ld_dl, stats ? rowstat : nullptr, time_major, last_only);
   if (stats) hipLaunchKernelGGL(rowstat_reduce_kernel, dim3(1), dim3(1024), 0, stream, rowstat, rows, loss_acc);
   return ok();
 }

@@ -173,7 +173,7 @@ int kl_launch_f32_to_bf16_t(const float* in, long ld_in, int rows, int cols, bf1
                             long ld_out, int transpose, hipStream_t stream);
 int kl_launch_softmax_ce(float* logits, long ld, int rows, int V, const int* tgt, int B, int T, float inv_count,
                          bf16_t* dlogits, long ld_dl, float* loss_acc, float* rowstat, int time_major,
-                         hipStream_t stream);
+                         hipStream_t stream, int last_only = 0);
 int kl_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                    float eps, float clip, hipStream_t stream);
 int kl_launch_onehot_t(const int* ids, int B, int T, int n_classes, int col, int n_cols, bf16_t* out, long ld,

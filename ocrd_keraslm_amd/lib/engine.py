@@ -65,6 +65,7 @@ class HipLM:
         self.pool = None            # [slots][2L][W] explicit states of hypotheses
         self._step_ws = None
         self._step_ws_bytes = {}
+        self.last_only = False
         self._rng = np.random.default_rng(0)
 
     def __del__(self):
@@ -157,6 +158,13 @@ class HipLM:
             self._ws = self.torch.empty(n, dtype=self.torch.uint8, device=self.device)
             self._ws_key = key
         return self._ws
+
+    def set_window_mode(self, last_only):
+        """False (default): the stateful graph -- a target at every position, means over B*T positions.
+        True: the stateless graph (rating.py:126-129) -- one target per window at its last position,
+        means over the B windows."""
+        hipabi.check(self.lib.kl_set_window_mode(self.handle, 1 if last_only else 0), "kl_set_window_mode")
+        self.last_only = bool(last_only)
 
     def reset_states(self, B=None, rows=None):
         """Keras reset_states (rating.py:475, 555; callbacks.py:58, 69)."""

@@ -51,6 +51,7 @@ SIGNATURES = {
     "kl_state_dist2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                  C.c_void_p]),
     "kl_trace_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "kl_set_window_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "kl_trace_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int]),
     "kl_trace_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int),
                                 C.POINTER(C.c_double)]),

@@ -339,3 +339,54 @@ def test_handoff_flavours_agree_bitwise(B, windows):
     bad, g, c = mod.run(B, windows, verbose=False)
     assert bad == 0
     assert g < 1e-3 and c < 5e-2, (g, c)
+
+
+@pytest.mark.parametrize("depth,width,voc,B,T", [(2, 128, 50, 6, 12), (2, 512, 64, 128, 9), (1, 64, 30, 3, 5)])
+def test_stateless_window_mode(depth, width, voc, B, T):
+    """kl_set_window_mode(1): the reference's stateless graph (rating.py:126-129, 1123-1126) -- windows start
+    from zero state, ONE target per window at its last position, loss / accuracy are means over the B
+    windows, the dropout mask is shared by the whole batch (noise_shape (1, W), rating.py:150)."""
+    import torch
+    from ocrd_keraslm_amd.lib import hipabi
+    cfg, w, lm = make_model(depth, width, voc, 1, emb_std=0.3)
+    lm.set_weights(w, hipabi.KL_PREC_BF16)
+    lm.set_window_mode(True)
+    lm.reset_states(B)
+    rng = np.random.default_rng(8)
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    idx = rng.integers(0, voc, (B, T))
+    ctx = rng.integers(0, 200, (B, 1, 1)).repeat(T, axis=1)
+    last = rng.integers(0, voc, B)
+    tgt = np.full((B, T), -1)
+    tgt[:, -1] = last
+    one = lm.draw_dropout_masks(1)
+    masks = np.repeat(one, B, axis=1)
+    om = [None] + [masks[l].astype(np.float64) for l in range(1, depth)]
+    ref_p, _, cache = O.forward_window(cfg, w64, idx, ctx, O.zero_states(cfg, B, np.float64), om, keep_cache=True)
+    p_last = np.clip(ref_p[np.arange(B), -1, last], 1e-7, 1 - 1e-7)
+    ce = float(np.mean(-np.log(p_last)))
+    acc = float(np.mean(ref_p[:, -1].argmax(axis=1) == last))
+    g_all = O.backward_window(cfg, w64, idx, ctx, tgt, ref_p, cache, om)
+    g_ce = O.backward_window(cfg, w64, idx, ctx, tgt, ref_p, cache, om, with_regularisers=False)
+    lm.loss_acc.zero_()
+    lm.train_window(idx, ctx, tgt, masks)
+    l, a, _ = lm.read_loss()
+    assert abs(l - ce) < 2e-2 * max(1.0, ce), (l, ce)
+    assert abs(a - acc) < 1e-6, (a, acc)
+    flat = lm.grads.cpu().numpy()
+    for name, off, rows, cols in lm.layout:
+        ref = T * g_ce[name] + (g_all[name] - g_ce[name])     # mean over B rows instead of B*T positions
+        got = flat[off:off + rows * cols].reshape(ref.shape)
+        scale = np.abs(ref).max() + 1e-12
+        assert np.abs(got - ref).max() / scale < 3e-2, name
+    # inference in the same mode: probabilities of the last position, loss over the B windows
+    lm.prepare(hipabi.KL_PREC_SPLIT)
+    lm.reset_states(B)
+    lm.loss_acc.zero_()
+    ref_i, _, _ = O.forward_window(cfg, w64, idx, ctx, O.zero_states(cfg, B, np.float64))
+    probs = lm.forward_window(idx, ctx, tgt).cpu().numpy()
+    assert np.abs(probs[:, -1] - ref_i[:, -1]).max() < 2e-5
+    l2, a2, _ = lm.read_loss()
+    ce_i = float(np.mean(-np.log(np.clip(ref_i[np.arange(B), -1, last], 1e-7, 1 - 1e-7))))
+    assert abs(l2 - ce_i) < 1e-4 * max(1, ce_i)
+    assert abs(a2 - float(np.mean(ref_i[:, -1].argmax(axis=1) == last))) < 1e-6
