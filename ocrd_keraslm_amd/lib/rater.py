@@ -155,9 +155,6 @@ class Rater(object):
             self.variable_length = False
             self.first_window = 0
             self.batch_size = 1
-        elif not self.incremental:
-            raise NotImplementedError("stateless non-incremental window mode is not built on the MI355X path yet "
-                                      "(use stateful=True, or incremental=True for predict/generate/rate_best)")
         self.logger.info('using MI355X HIP implementation to compile %s %s model of depth %d width %d length %s size %d',
                          'stateful' if self.stateful else 'stateless',
                          'incremental' if self.incremental else 'contiguous',
@@ -171,6 +168,8 @@ class Rater(object):
                 factory = HipLM
             self.model = factory(int(self.depth), int(self.width), int(self.voc_size), int(self.n_ctx))
             self.model.init_weights(seed=self.seed)
+            # stateless contiguous graph (rating.py:98-99, 126-129): zero state per window, ONE output per window
+            self.model.set_window_mode(not self.stateful and not self.incremental)
         else:
             self.model = None     # vocabulary unknown before the first training (rating.py:230)
         del previous
@@ -190,6 +189,8 @@ class Rater(object):
         state reset at file boundaries and before validation (callbacks.py:36-69).'''
         assert self.status > 0
         assert self.incremental is False
+        if not self.stateful:
+            return self._train_stateless(data, val_data)
         (training_data, validation_data, _split, training_epoch_size, validation_epoch_size,
          total_size, steps) = self._split_data(data, val_data)
         self.logger.info('training on %d files / %d batches per epoch / %d character tokens for %d character types',
@@ -342,8 +343,9 @@ class Rater(object):
         '''Read text files, split into training vs validation, count batches and update
         the character mapping (stateful branch of rating.py:317-385).'''
         assert self.status >= 1
-        assert self.stateful, "only the stateful mode is built"
         shuffle(data)
+        if not self.stateful:
+            return self._split_data_stateless(data, val_data)
         total_size = 0
         chars = set(self.mapping[0].keys())
         steps = self.length
@@ -372,6 +374,132 @@ class Rater(object):
         i_c = dict((i, c) for i, c in enumerate(chars, 1))
         self.mapping = (c_i, i_c)
         return training_data, validation_data, None, sizes[0], sizes[1], total_size, steps
+
+    def _split_data_stateless(self, data, val_data):
+        '''window-wise split of the stateless mode (rating.py:352-378): windows advance by 3; without
+        validation files both generators read the same data and share one uniform number per window
+        position that assigns it to training or validation'''
+        steps = 3
+        total_size, max_size = 0, 0
+        chars = set(self.mapping[0].keys())
+        for file in data:
+            file.seek(0)
+            text, size = windows.read_normalize_file(file)
+            total_size += size - self.length
+            max_size = max(max_size, size)
+            chars.update(set(text))
+        if val_data:
+            training_epoch_size = ceil(total_size / steps / self.batch_size)
+            for file in val_data:
+                file.seek(0)
+                _text, size = windows.read_normalize_file(file)
+                total_size += size - self.length
+            validation_epoch_size = ceil(total_size / steps / self.batch_size)
+            training_data, validation_data, split = data, val_data, None
+        else:
+            epoch_size = total_size / steps / self.batch_size
+            training_epoch_size = ceil(epoch_size * (1 - self.validation_split))
+            validation_epoch_size = ceil(epoch_size * self.validation_split)
+            validation_data, training_data = data, data
+            split = np.random.uniform(0, 1, (ceil(max_size / steps),))
+        if self.first_window:
+            training_epoch_size *= 1.0 + self.first_window
+        chars = sorted(list(chars))
+        self.voc_size = len(chars) + 1
+        self.mapping = (dict((c, i) for i, c in enumerate(chars, 1)), dict((i, c) for i, c in enumerate(chars, 1)))
+        return training_data, validation_data, split, training_epoch_size, validation_epoch_size, total_size, steps
+
+    def _stateless_gen(self, files, steps, train, split=None, repeat=False):
+        return windows.stateless_file_batches(
+            files, self.length, self.mapping[0], steps, repeat=repeat, batch_size=self.batch_size, train=train, split=split,
+            validation_split=self.validation_split, variable_length=self.variable_length, first_window=self.first_window,
+            char_degradation=self.char_degradation, context_degradation=self.context_degradation,
+            on_unmapped=self._unmapped_input)
+
+    @staticmethod
+    def _last_targets(x, y):
+        tgt = np.full(x.shape, -1, dtype=np.int32)
+        tgt[:, -1] = y
+        return tgt
+
+    def _train_stateless(self, data, val_data=None):
+        '''rating.py:248-310 for stateful=False: batches of `batch_size` windows from zero state, one
+        target per window; same epoch / early-stopping / checkpoint control as the stateful loop.
+        (Single process: the window-wise split has no per-rank sharding.)'''
+        (training_data, validation_data, split, training_epoch_size, validation_epoch_size,
+         total_size, steps) = self._split_data(data, val_data)
+        self.logger.info('training on %d files / %d batches per epoch / %d character tokens for %d character types',
+                         len(training_data), training_epoch_size, total_size, self.voc_size)
+        self.reconfigure_for_mapping()
+        lm = self.model
+        if getattr(lm, "precision", PREC_BF16) != PREC_BF16:
+            lm.prepare(PREC_BF16)
+        train_gen = self._stateless_gen(training_data, steps, True, split, repeat=True)
+        val_gen = self._stateless_gen(validation_data, steps, False, split, repeat=True)
+        steps_per_epoch = max(1, int(ceil(training_epoch_size)))
+        val_steps = max(1, int(ceil(validation_epoch_size)))
+        history = {'loss': [], 'accuracy': [], 'val_loss': [], 'val_accuracy': []}
+        best_val, best_weights, wait, stopped_epoch = None, None, 0, 0
+        nan_abort = False
+        for epoch in range(self.max_epochs):
+            lm.read_loss(reset=True)
+            loss_sum = acc_sum = 0.0
+            for step in range(steps_per_epoch):
+                x, z, y = next(train_gen)
+                b = x.shape[0]
+                lm.reset_states(b)
+                one = lm.draw_dropout_masks(1)      # noise_shape (1, W): one mask for the whole batch (rating.py:150)
+                lm.train_window(x, z, self._last_targets(x, y), np.repeat(one, b, axis=1))
+                lm.adam_step()
+                ce, acc, reg = lm.read_loss(reset=True)
+                loss = ce + reg
+                loss_sum += loss
+                acc_sum += acc
+                if not np.isfinite(loss):
+                    self.logger.critical('NaN loss at batch %d', step)
+                    nan_abort = True
+                    break
+            history['loss'].append(loss_sum / (step + 1))
+            history['accuracy'].append(acc_sum / (step + 1))
+            if nan_abort:
+                break
+            lm.prepare(PREC_BF16)
+            v_loss = v_acc = 0.0
+            n_rows = 0
+            for _ in range(val_steps):
+                x, z, y = next(val_gen)
+                b = x.shape[0]
+                lm.reset_states(b)
+                lm.forward_window(x, z, self._last_targets(x, y), want_probs=False)
+                ce, acc, _ = lm.read_loss(reset=True)
+                v_loss += ce * b
+                v_acc += acc * b
+                n_rows += b
+            v_loss, v_acc = v_loss / n_rows, v_acc / n_rows
+            history['val_loss'].append(v_loss)
+            history['val_accuracy'].append(v_acc)
+            self.logger.info('epoch %d: loss %.4f accuracy %.4f val_loss %.4f val_accuracy %.4f', epoch + 1,
+                             history['loss'][-1], history['accuracy'][-1], v_loss, v_acc)
+            if best_val is None or v_loss < best_val:
+                best_val, wait = v_loss, 0
+                best_weights = lm.get_weights()
+                self._checkpoint('ckpt.%02d-%.2f.h5' % (epoch + 1, v_loss))
+            else:
+                wait += 1
+                if wait >= self.patience:
+                    stopped_epoch = epoch
+                    lm.set_weights(best_weights, PREC_BF16)
+                    self.logger.info('early stopping at epoch %d, best weights restored', epoch + 1)
+                    break
+        self.history = history
+        if history['val_loss']:
+            self.logger.info('training finished with val_loss %f', min(history['val_loss']))
+            if (np.isnan(history['val_loss'][-1]) or stopped_epoch == 0) and best_weights is not None:
+                lm.set_weights(best_weights, PREC_BF16)
+            self.status = 2
+        else:
+            self.logger.critical('training failed')
+            self.status = 1
 
     def reconfigure_for_mapping(self):
         '''Reconfigure the character embedding after a change of mapping, transferring
@@ -443,6 +571,24 @@ class Rater(object):
         assert self.incremental is False
         self._ensure_precision()
         lm = self.model
+        if not self.stateful:
+            # one window per character; the batch losses are averaged weighted by batch size, and only
+            # ceil((size-1)/batch_size) generator batches per file are evaluated (rating.py:482-490)
+            epoch_size = 0
+            for file in test_data:
+                file.seek(0)
+                _text, size = windows.read_normalize_file(file)
+                epoch_size += ceil((size - 1) / self.batch_size / 1)
+            gen = self._stateless_gen(test_data, 1, False)
+            lm.read_loss(reset=True)
+            total, rows = 0.0, 0
+            for _ in range(epoch_size):
+                x, z, y = next(gen)
+                lm.reset_states(x.shape[0])
+                lm.forward_window(x, z, self._last_targets(x, y), want_probs=False)
+                total += lm.read_loss(reset=True)[0] * x.shape[0]
+                rows += x.shape[0]
+            return exp(total / max(rows, 1))
         lm.reset_states(1)
         lm.read_loss(reset=True)
         n = 0
@@ -468,8 +614,20 @@ class Rater(object):
         text = windows.normalize(text)
         size = len(text)
         preds = []
-        for x, z, _y in windows.stateful_windows(text, context, self.length, self.mapping[0],
-                                                 on_unmapped=self._unmapped_input):
+        if not self.stateful:
+            # Stateless scoring as the reference does it (rating.py:513-528): one window per character
+            # position, of which only ceil((size-1)/batch_size) generator batches are evaluated -- the
+            # partial windows of the first `length` positions count as batches of their own -- and
+            # prediction k (made FOR character k) is paired with character k+1.  Both are reproduced.
+            gen = windows.stateless_batches(text, context, self.length, self.mapping[0], 1, batch_size=self.batch_size,
+                                            train=False, variable_length=self.variable_length,
+                                            on_unmapped=self._unmapped_input)
+            for _ in range(ceil((size - 1) / self.batch_size / 1)):
+                x, z, _y = next(gen)
+                self.model.reset_states(x.shape[0])
+                preds.append(_np(self.model.forward_window(x, z))[:, -1])
+        for x, z, _y in (windows.stateful_windows(text, context, self.length, self.mapping[0],
+                                                  on_unmapped=self._unmapped_input) if self.stateful else ()):
             preds.append(_np(self.model.forward_window(x[None], z[None]))[0])
         probs = [1.0]
         if not preds:
@@ -493,6 +651,8 @@ class Rater(object):
         self._ensure_precision()
         text = windows.normalize(text)
         lm = self.model
+        if not self.stateful:
+            return self._rate2_stateless(text, context)
         lm.reset_states(1)
         z = np.asarray(context, dtype=np.int32).reshape(1, 1, -1)
         entropy = 0
@@ -512,6 +672,36 @@ class Rater(object):
                 entropy -= log(max(prob, 1e-99), 2)
                 result.append((char, prob))
             prev = idx
+        return result, pow(2.0, entropy / len(text))
+
+    def _rate2_stateless(self, text, context):
+        '''rating.py:548-576 for stateful=False: a window that slides by one character per step, filled from
+        the right; evaluated over its last i columns (variable length) or whole, left zeros included'''
+        lm = self.model
+        L, n_ctx = self.length, len(context)
+        x = np.zeros((1, L), dtype=np.int32)
+        z = np.zeros((1, L, n_ctx), dtype=np.int32)
+        entropy = 0
+        result = []
+        for i, char in enumerate(text):
+            if char not in self.mapping[0]:
+                self.logger.error('unmapped character "%s" at input position %d', char, i)
+                idx = 0
+            else:
+                idx = self.mapping[0][char]
+            if i == 0:
+                result.append((char, 1.0))
+            else:
+                xi, zi = (x[:, -i:], z[:, -i:]) if self.variable_length else (x, z)
+                lm.reset_states(1)
+                pred = _np(lm.forward_window(np.ascontiguousarray(xi), np.ascontiguousarray(zi)))[0, -1]
+                prob = float(pred[idx])
+                entropy -= log(max(prob, 1e-99), 2)
+                result.append((char, prob))
+            x = np.roll(x, -1, axis=1)
+            z = np.roll(z, -1, axis=1)
+            x[0, -1] = idx
+            z[0, -1] = np.asarray(context, dtype=np.int32)
         return result, pow(2.0, entropy / len(text))
 
     rate_once = rate2   # historic name of the one-by-one rater (north_star / BASELINE.json)

@@ -20,8 +20,8 @@ engine instead of one-hot booleans:
   * the context of a file is ceil(year/10) parsed from `author_title_year.ext`
     names, else 0 (rating.py:993-999).
 
-The stateless (non-stateful) window modes of the reference are not part of this
-round's scope.
+`stateless_batches` restates the non-stateful branch of the same functions (windows of
+`length` characters predicting ONE next character, rating.py:1040-1102): see there.
 """
 from __future__ import annotations
 
@@ -132,5 +132,116 @@ def file_windows(files, length, c_i, train=False, repeat=False, rng=None, on_new
             yield from stateful_windows(text, context_from_filename(file.name), length, c_i, train=train, rng=rng,
                                         char_degradation=char_degradation, context_degradation=context_degradation,
                                         on_unmapped=on_unmapped)
+        if not repeat:
+            break
+
+
+def _vectorize_stateless(sequences, next_ids, context, length, batch_size, c_i, on_unmapped):
+    """rating.py:1104-1158 for stateful=False: sequences RIGHT-padded with id 0 to `length`, contexts only under
+    the characters, one target id per row (0 = unmapped, -1 = row without a target)"""
+    n_ctx = len(context)
+    x = np.zeros((batch_size, length), dtype=np.int32)
+    z = np.zeros((batch_size, length, n_ctx), dtype=np.int32)
+    y = np.full(batch_size, -1, dtype=np.int32)
+    for i, seq in enumerate(sequences):
+        assert i < batch_size and len(seq) <= length
+        ids = encode(seq, c_i, on_unmapped, base=i * length)
+        x[i, :len(ids)] = ids
+        if n_ctx:
+            z[i, :len(ids)] = np.asarray(context, dtype=np.int32)
+        if next_ids is not None and i < len(next_ids) and len(seq) > 0:
+            y[i] = next_ids[i]      # (the reference sets the one-hot target inside its per-character loop,
+            #                          so a row with an EMPTY input sequence has no target at all)
+    return x, z, y
+
+
+def stateless_batches(text, context, length, c_i, steps, batch_size=128, train=False, split=None, validation_split=0.2,
+                      variable_length=True, first_window=0.1, char_degradation=0.01, context_degradation=0.1,
+                      on_unmapped=None):
+    """Stateless windows of one text (rating.py:1004-1102 with stateful=False): window i holds
+    text[i-length:i] and predicts text[i], i = 0, steps, 2*steps, ...; yields (x [b,L'], ctx [b,L',C], y [b]).
+
+      * windows with i < length are partial: in prediction mode each is its own batch of 1 (of length i
+        when `variable_length`, else right-padded to `length`); in training mode they join the batches;
+      * with `split` (one uniform number per window position) the training generator keeps the
+        positions whose number is >= validation_split and the validation generator the others;
+      * training augmentation after each FULL batch, driven by the last window's random number,
+        re-scaled and re-used: one character column zeroed for the whole batch (`char_degradation`),
+        the context zeroed (`context_degradation`), and with rate `first_window` a shortened
+        (variable length: last j columns) or left-erased copy of the batch;
+      * the characters behind the last window position form one more single-row batch.
+    Random numbers come from numpy's global generator, as in the reference."""
+    size = len(text)
+    context = clamp_context(context)
+    n_ctx = len(context)
+
+    def target(ch):
+        k = c_i.get(ch)
+        if k is None:
+            if on_unmapped is not None:
+                on_unmapped(ch, -1)
+            return 0
+        return k
+    sequences, nexts = [], []
+    i = 0
+    for i in range(0, size, steps):
+        if isinstance(split, np.ndarray):
+            if (split[int(i / steps)] < validation_split) == train:
+                continue
+            rand = (split[int(i / steps)] - validation_split) / (1 - validation_split)
+        else:
+            rand = np.random.uniform(0, 1, 1)[0]
+        if i < length:
+            if train:
+                sequences.append(text[0:i])
+            else:
+                yield _vectorize_stateless([text[0:i]], [target(text[i])], context, (i if variable_length else length) or length,
+                                           1, c_i, on_unmapped)
+                continue
+        else:
+            sequences.append(text[i - length:i])
+        nexts.append(target(text[i]))
+        if len(sequences) % batch_size == 0:
+            x, z, y = _vectorize_stateless(sequences, nexts, context, length, batch_size, c_i, on_unmapped)
+            yield x, z, y
+            sequences, nexts = [], []
+            if train:
+                rand_max = char_degradation
+                if 0 < rand < rand_max:
+                    j = int((length - 1) * rand / rand_max)
+                    xa = x.copy()
+                    xa[:, j] = 0
+                    yield xa, z, y
+                rand = (rand - rand_max) / (1 - rand_max)
+                rand_max = context_degradation
+                if 0 < rand < rand_max:
+                    j = int(n_ctx * rand / rand_max)          # == int((len(x)-1)*rand/rand_max)+1 over [chars]+contexts
+                    za = z.copy()
+                    if n_ctx:
+                        za[:, :, min(j, n_ctx - 1)] = 0
+                    yield x, za, y
+                rand = (rand - rand_max) / (1 - rand_max)
+                rand_max = first_window
+                if 0 < rand < rand_max:
+                    j = int((length - 1) * rand / rand_max) + 1
+                    if variable_length:
+                        yield x[:, -j:].copy(), z[:, -j:].copy(), y
+                    else:
+                        xa = x.copy()
+                        xa[:, 0:j] = 0
+                        yield xa, z, y
+    if sequences:
+        yield _vectorize_stateless(sequences, nexts, context, length, len(sequences), c_i, on_unmapped)
+    if i + 1 < size:
+        yield _vectorize_stateless([text[i:size - 1]], [target(text[size - 1])], context, length, 1, c_i, on_unmapped)
+
+
+def stateless_file_batches(files, length, c_i, steps, repeat=False, **kwargs):
+    """rating.py:977-1002 for stateful=False: the batches of a list of open text files"""
+    while True:
+        for file in files:
+            file.seek(0)
+            text, _ = read_normalize_file(file)
+            yield from stateless_batches(text, context_from_filename(file.name), length, c_i, steps, **kwargs)
         if not repeat:
             break

@@ -30,6 +30,21 @@ class OracleLM(object):
         self.loss = np.zeros(3)
         self._rng = np.random.default_rng(0)
         self.step_calls = []
+        self.last_only = False
+
+    def set_window_mode(self, last_only):
+        self.last_only = bool(last_only)
+
+    def _loss(self, probs, tgt):
+        """(mean CE, accuracy) in the current window mode"""
+        if not self.last_only:
+            ce, acc, _ = O.crossentropy(probs, tgt)
+            return ce, acc
+        last = np.asarray(tgt)[:, -1]
+        p = probs[:, -1]
+        has = last >= 0
+        pc = np.clip(p[np.arange(len(last)), np.where(has, last, 0)], 1e-7, 1 - 1e-7)
+        return float(np.mean(np.where(has, -np.log(pc), 0.0))), float(np.mean(p.argmax(axis=-1) == np.where(has, last, 0)))
 
     # weights
     def get_weights(self):
@@ -63,7 +78,7 @@ class OracleLM(object):
             self.reset_states(idx.shape[0])
         probs, self.states, _ = O.forward_window(self.cfg, self.w, idx, ctx, self.states)
         if tgt is not None:
-            ce, acc, _ = O.crossentropy(probs, np.asarray(tgt))
+            ce, acc = self._loss(probs, np.asarray(tgt))
             self.loss[0] += ce
             self.loss[1] += acc
         return probs if want_probs else None
@@ -90,9 +105,16 @@ class OracleLM(object):
         if masks is not None:
             om = [None] + [np.asarray(masks[l], dtype=self.dtype) for l in range(1, self.depth)]
         probs, self.states, cache = O.forward_window(self.cfg, self.w, idx, ctx, self.states, om, keep_cache=True)
-        ce, acc, _ = O.crossentropy(probs, tgt)
+        ce, acc = self._loss(probs, tgt)
         self.loss += (ce, acc, O.regularisers(self.cfg, self.w))
-        g = O.backward_window(self.cfg, self.w, idx, ctx, tgt, probs, cache, om)
+        if self.last_only:       # mean over the B windows instead of the B*T positions
+            tl = np.full(tgt.shape, -1)
+            tl[:, -1] = tgt[:, -1]
+            g_all = O.backward_window(self.cfg, self.w, idx, ctx, tl, probs, cache, om)
+            g_ce = O.backward_window(self.cfg, self.w, idx, ctx, tl, probs, cache, om, with_regularisers=False)
+            g = {k: idx.shape[1] * g_ce[k] + (g_all[k] - g_ce[k]) for k in g_all}
+        else:
+            g = O.backward_window(self.cfg, self.w, idx, ctx, tgt, probs, cache, om)
         flat = np.zeros(self.n_params, dtype=np.float32)
         for name, off, rows, cols in self.layout:
             flat[off:off + rows * cols] = g[name].reshape(-1)
