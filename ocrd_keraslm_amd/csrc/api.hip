@@ -102,6 +102,7 @@ struct kl_handle {
   bool scan_enabled = true;     // persistent scans (KL_SCAN=0 forces the launch-per-step path)
   bool seq_bwd = true;          // layer-sequential backward scans for many row blocks (KL_SEQ_BWD=0: always fused)
   bool wide_bwd = true;         // ... with 64-unit workgroups (KL_WIDE_BWD=0: thin workgroups)
+  bool inc_ready = false;       // the big-n incremental operands match the current weights
   int last_only = 0;            // stateless windows: one target per row, at the last position (kl_set_window_mode)
   bool sentinel = true;         // wide scans hand off by data sentinels instead of counters (KL_SENTINEL=0: counters)
   bool fused_step = true;       // incremental step, n >= 256: cell fused into the GEMM epilogue (KL_FUSED_STEP=0: separate kernels)
@@ -313,7 +314,21 @@ int prepare_impl(kl_handle* h, int precision, hipStream_t s) {
     const float* Kc = P + h->off_K[0] + (size_t)(W + n * c.ctx_dim) * 4 * W;
     KL_TRY(kl_launch_small_table(P + h->off_Ctx[n], c.ctx_vocab, c.ctx_dim, Kc, 4 * W, 4 * W, d.CtxK[n], 4 * W, s));
   }
-  // concatenated [hi | hi | lo] operands of the big-n incremental step (step_big.hip)
+  h->precision = precision;
+  h->inc_ready = false;      // the big-n incremental operands are rebuilt on their first use (prepare_incremental)
+  return 0;
+}
+
+// Operands only the big-n incremental step reads: concatenated [hi | hi | lo] weights, their
+// gate-permuted copies and the concatenated embedding.  Built lazily: a training step re-derives the
+// window operands after every Adam update and never touches these.
+int prepare_incremental(kl_handle* h, hipStream_t s) {
+  const kl_config& c = h->cfg;
+  const int W = c.width, V = c.voc_size, Vp = h->Vp;
+  const float* P = h->params;
+  Derived& d = h->d;
+  const bool split = h->precision == KL_PREC_SPLIT;
+  const float* E = P + h->off_E;
   for (int l = 0; l < c.depth; ++l) {
     const int Kl = l == 0 ? W : 2 * W;
     const long ld = 3L * Kl;
@@ -332,7 +347,7 @@ int prepare_impl(kl_handle* h, int precision, hipStream_t s) {
   KL_TRY(kl_zero_async(d.Ecat, (size_t)Vp * 3 * W * sizeof(bf16_t), s));
   KL_TRY(kl_launch_f32_to_bf16_t(E, W, V, W, d.Ecat, split ? d.Ecat + 2 * W : nullptr, 3 * W, 0, s));
   if (split) KL_TRY(kl_launch_f32_to_bf16_t(E, W, V, W, d.Ecat + W, nullptr, 3 * W, 0, s));
-  h->precision = precision;
+  h->inc_ready = true;
   return 0;
 }
 
@@ -947,6 +962,7 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
     KL_TRY(kl_launch_p1_gather(d.EK, ctxk.data(), c.n_ctx, P + h->off_b[0], idx, ctx, n, 1, 4 * W, prow, s));
   }
   if (n >= KL_BIG_STEP_N && ws && ws_bytes >= kl_step_workspace_bytes(h, n)) {
+    if (!h->inc_ready) KL_TRY(prepare_incremental(h, s));
     // big-tile path: gather+split -> one bf16 GEMM over the 3x contraction -> gates
     Carver cv(ws);
     cv.take<float>((size_t)n * 4 * W);

@@ -120,10 +120,13 @@ __global__ void softmax_ce_kernel(float* __restrict__ logits, long ld, int rows,
     t = tgt[(long)b * T + tt];
     if (last_only && tt != T - 1) { t = -1; counts = false; }
   }
+  // probabilities are written back over the logits for the callers that read them (rating); a
+  // training window only needs dlogits and the row statistics, so it skips that pass over HBM
+  const bool keep_probs = dlogits == nullptr;
   float pt = 0.f;
   for (int v = lane; v < V; v += 64) {
     const float p = expf(x[v] - mx) * inv;
-    x[v] = p;
+    if (keep_probs) x[v] = p;
     if (v == t) pt = p;
   }
   if (!tgt) return;
@@ -134,7 +137,7 @@ __global__ void softmax_ce_kernel(float* __restrict__ logits, long ld, int rows,
   if (dlogits) {
     bf16_t* d = dlogits + (long)row * ld_dl;
     for (int v = lane; v < ld_dl; v += 64) {   // pad columns [V, ld_dl) are written as zeros
-      float g = (active && v < V) ? x[v] : 0.f;
+      float g = (active && v < V) ? expf(x[v] - mx) * inv : 0.f;
       if (active && v == t) g -= 1.f;
       d[v] = f2bf(g * inv_count);
     }
@@ -151,11 +154,15 @@ __global__ void softmax_ce_kernel(float* __restrict__ logits, long ld, int rows,
   }
 }
 
-// sum of the per-row (loss, hit) pairs -> loss_acc[0], loss_acc[1]; one block
+// sum of the per-row (loss, hit) pairs -> loss_acc[0], loss_acc[1]; a few blocks, one atomic pair each
 __global__ void rowstat_reduce_kernel(const float* __restrict__ rowstat, int rows, float* __restrict__ loss_acc) {
-  __shared__ float red[2][1024];
+  __shared__ float red[2][256];
   float a = 0.f, b = 0.f;
-  for (int r = threadIdx.x; r < rows; r += blockDim.x) { a += rowstat[2 * (long)r]; b += rowstat[2 * (long)r + 1]; }
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+    const float2 v = reinterpret_cast<const float2*>(rowstat)[r];
+    a += v.x;
+    b += v.y;
+  }
   red[0][threadIdx.x] = a;
   red[1][threadIdx.x] = b;
   __syncthreads();
@@ -354,7 +361,11 @@ int kl_launch_softmax_ce(float* logits, long ld, int rows, int V, const int* tgt
   const bool stats = tgt != nullptr && loss_acc != nullptr && rowstat != nullptr;
   hipLaunchKernelGGL(softmax_ce_kernel, grid, dim3(256), 0, stream, logits, ld, rows, V, tgt, B, T, inv_count,
                      dlogits, ld_dl, stats ? rowstat : nullptr, time_major, last_only);
-  if (stats) hipLaunchKernelGGL(rowstat_reduce_kernel, dim3(1), dim3(1024), 0, stream, rowstat, rows, loss_acc);
+  if (stats) {
+    int nb = (rows + 4095) / 4096;
+    if (nb > 64) nb = 64;
+    hipLaunchKernelGGL(rowstat_reduce_kernel, dim3(nb), dim3(256), 0, stream, rowstat, rows, loss_acc);
+  }
   return ok();
 }
 
