@@ -21,6 +21,7 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   cpu_baseline  the CPU restatement (oracle/, numpy f32) of the same training step
                 with the reference's own batching (1 stream x 256 chars, stateful),
                 timed on this box's host cores on a bounded sample
+  cpu_baseline_torch  informative second CPU figure: the same step with torch.nn.LSTM (oneDNN) + autograd
   incremental   hypotheses*chars/s of the batched incremental step (cfg3:
                 1024 hypotheses x 512 chars), split-bf16 precision (parity mode)
 """
@@ -98,6 +99,43 @@ def cpu_baseline(seconds=15.0):
             break
     return {"value": n * LENGTH / el, "unit": "chars/s", "cores": int(threads), "kind": "port",
             "sample": "%d stateful windows of 1x%d chars (forward+backward+Adam, numpy f32 oracle, %.1f s)" % (n, LENGTH, el)}
+
+
+def cpu_baseline_torch(seconds=8.0):
+    """Second CPU figure beside the oracle's ("optimised CPU stand-in"): the same
+    1 x 256 stateful training step written with torch.nn.LSTM / oneDNN + autograd + Adam(clipvalue 1)."""
+    import torch
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    W, V, T = WIDTH, VOC, LENGTH
+    emb, ctx = torch.nn.Embedding(V, W), torch.nn.Embedding(200, 10)
+    layers = [torch.nn.LSTM(W + 10 * N_CTX if l == 0 else W, W, batch_first=True) for l in range(DEPTH)]
+    params = list(emb.parameters()) + list(ctx.parameters()) + [p for m in layers for p in m.parameters()]
+    opt = torch.optim.Adam(params, lr=1e-3, eps=1e-7)
+    ids = torch.from_numpy(synthetic_corpus(64 * T + 1, V, 0).astype(np.int64))
+    c = torch.full((1, T), 17)
+    states = [None] * DEPTH
+    n, t0 = 0, time.time()
+    while True:
+        k = n % 64
+        x, y = ids[k * T:(k + 1) * T][None], ids[k * T + 1:(k + 1) * T + 1][None]
+        h = torch.cat([emb(x), ctx(c)], -1)
+        for l, m in enumerate(layers):
+            h, st = m(h, states[l])
+            states[l] = tuple(s.detach() for s in st)
+            if l > 0:
+                h = torch.nn.functional.dropout(h, 0.1)
+        loss = torch.nn.functional.cross_entropy((h @ emb.weight.t()).view(-1, V), y.view(-1))
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_value_(params, 1.0)
+        opt.step()
+        n += 1
+        el = time.time() - t0
+        if el >= seconds or n >= 400:
+            break
+    return {"value": n * T / el, "unit": "chars/s", "cores": int(threads), "kind": "torch-cpu (oneDNN LSTM + autograd)",
+            "sample": "%d stateful windows of 1x%d chars (%.1f s)" % (n, T, el)}
 
 
 def main():
@@ -254,8 +292,13 @@ def main():
                        "mfma_frac": hv * flops_fwd_per_char() / 1e12 / MFMA_BF16_PEAK_TFLOPS}
 
     cpu = None
+    cpu_torch = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
+        try:
+            cpu_torch = cpu_baseline_torch()
+        except Exception as err:      # informative only
+            cpu_torch = {"error": repr(err)}
 
     if rank == 0:
         line = {
@@ -267,7 +310,7 @@ def main():
                                    "%d streams/GPU, synthetic 10M-char corpus (SURVEY.md 8d)" % B,
                        "streams_per_gpu": B, "global_batch": B * world, "seq_len": T,
                        "parallelism": "dp%d" % world, "final_ce": ce / max(args.steps, 1)},
-            "roofline": roofline, "cpu_baseline": cpu, "incremental": incremental,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_torch": cpu_torch, "incremental": incremental,
         }
         print(json.dumps(line))
     if world > 1:
