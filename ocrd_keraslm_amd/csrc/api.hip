@@ -789,8 +789,10 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   // twice the row groups fit -- and take the from-above term dZ_{l+1} . K_{l+1}^T for all
   // steps at once from the big GEMM.
   const int n_rb_all = (B + 15) / 16, nug = W / 16;
+  const bool thin_fits = (n_rb_all + 512 / nug - 1) / (512 / nug) <= 4;
+  const bool wide_fits = h->wide_bwd && kl_scan_bwd_wide_applicable(B, T, W) && BTp == BT && (B & 7) == 0;
   const bool sequential = h->scan_enabled && h->seq_bwd && L > 1 && L <= KL_SCAN_MAXL && (W == 512 || W == 256 || W == 128) &&
-                          n_rb_all > 512 / (L * nug) && (n_rb_all + 512 / nug - 1) / (512 / nug) <= 4;
+                          n_rb_all > 512 / (L * nug) && (thin_fits || wide_fits);
   if (sequential) {
     for (int l = L - 1; l >= 0; --l) {
       if (l < L - 1)   // dX_l = dZ_{l+1} . K_{l+1}^T  -> w.dH (free once the layer above has been scanned)

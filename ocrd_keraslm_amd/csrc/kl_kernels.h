@@ -156,6 +156,7 @@ struct KlScanBwd {
   float* db;                           // wide one-layer kernel only: += column sums of dZ (bias gradient; null: no)
 };
 int kl_launch_scan_bwd(KlScanBwd args, hipStream_t stream);
+bool kl_scan_bwd_wide_applicable(int B, int T, int W);
 int kl_launch_scan_bwd_wide(KlScanBwd args, hipStream_t stream);   // one layer per launch, 64-unit workgroups
 
 // thin split-precision contraction C[M,N] = A[M,K] . WT[N,K]^T (+bias) for

@@ -1202,9 +1202,19 @@ extern "C" int kl_test_scan_stamps(unsigned long long* out, int reset) {
 #endif
 
 // One-layer backward scan with 64-unit workgroups (a.L must be 1).  KL_ERR_SHAPE = not applicable.
+// shapes the wide backward scan serves (the launcher applies the same test)
+bool kl_scan_bwd_wide_applicable(int B, int T, int W) {
+  if ((W != 512 && W != 256) || B < 1 || T < 1) return false;
+  const int n_rb = (B + 15) / 16, col_groups = W / 64;
+  int g = 256 / col_groups;
+  if (g > n_rb) g = n_rb;
+  if ((n_rb + g - 1) / g > 4) return false;
+  return (long)T * B * 4 * W * 2 <= 0xffffffffL;      // unsigned 32-bit buffer offsets
+}
+
 int kl_launch_scan_bwd_wide(KlScanBwd a, hipStream_t stream) {
   const int W = a.W;
-  if (a.L != 1 || (W != 512 && W != 256) || a.B < 1 || a.T < 1) return KL_ERR_SHAPE;
+  if (a.L != 1 || !kl_scan_bwd_wide_applicable(a.B, a.T, W)) return KL_ERR_SHAPE;
   if (a.dZT && ((a.ldt & 7) || (a.B & 7))) return KL_ERR_SHAPE;
   a.n_rb = (a.B + 15) / 16;
   const int col_groups = W / 64;
@@ -1215,7 +1225,6 @@ int kl_launch_scan_bwd_wide(KlScanBwd a, hipStream_t stream) {
   if (per_wg > 4) return KL_ERR_SHAPE;
   dim3 grid(col_groups * g), block(1024);
   const size_t lds = (size_t)KL_BWD_WIDE_LDS(W / 32) + (per_wg > 1 ? 4 : 0) * 1024 * sizeof(float);
-  if ((long)a.T * a.B * 4 * W * 2 > 0x7fffffffL) return KL_ERR_SHAPE;   // 32-bit buffer offsets
 #define KL_WIDE_CASE(KS, RB)                                                                                         \
   do {                                                                                                               \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_bwd_wide_kernel<KS, RB>),                     \
@@ -1243,7 +1252,7 @@ int kl_launch_scan_fwd_wide(KlScanFwdWide a, hipStream_t stream) {
   if (per_wg > 4) return KL_ERR_SHAPE;
   dim3 grid(col_groups * g), block(1024);
   const size_t lds = (size_t)KL_FWD_WIDE_LDS(W / 32) + (per_wg > 1 ? 4 : 0) * 1024 * sizeof(float);
-  if ((long)(a.T + 1) * a.B * W * 2 > 0x7fffffffL) return KL_ERR_SHAPE;   // 32-bit buffer offsets
+  if ((long)a.T * a.B * 4 * W * 2 > 0xffffffffL) return KL_ERR_SHAPE;   // unsigned 32-bit buffer offsets (the gate rows are the largest)
 #define KL_WIDE_CASE2(KS, RB, S)                                                                                     \
   do {                                                                                                               \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_fwd_wide_kernel<KS, RB, S>),                  \
