@@ -301,6 +301,15 @@ class HipLM:
                                             stream), "kl_step_batch")
         return probs
 
+    def to_device_i32(self, a):
+        """one host-to-device transfer of an int32 array (rows stay contiguous views)"""
+        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.device, non_blocking=True)
+
+    def pool_heads(self, slots, k):
+        """first k state vectors of the given slots, [n][k][W] on the host"""
+        idx = self.torch.as_tensor(np.asarray(slots), device=self.device, dtype=self.torch.long)
+        return self.pool[idx, :k].cpu().numpy()
+
     def state_dist2(self, a, b, k):
         torch = self.torch
         a_d, b_d = self._dev_i32(a).reshape(-1), self._dev_i32(b).reshape(-1)

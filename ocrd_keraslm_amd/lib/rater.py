@@ -48,11 +48,12 @@ def _np(x):
 class StateRef(object):
     """Handle of one hypothesis state in the engine's device pool.  Quacks like
     the reference's state list [h1,c1,...,hL,cL] of (1,W) arrays when indexed."""
-    __slots__ = ("pool", "slot", "__weakref__")
+    __slots__ = ("pool", "slot", "head", "__weakref__")
 
     def __init__(self, pool, slot):
         self.pool = pool
         self.slot = slot
+        self.head = None      # host copy of the first `depth` state vectors (what history clustering compares)
 
     def __del__(self):
         try:
@@ -716,16 +717,32 @@ class Rater(object):
         c_i = self.mapping[0]
         return np.fromiter((c_i.get(c, 0) for c in candidates), dtype=np.int32, count=len(candidates))
 
-    def _predict_refs(self, candidates, states, context):
+    def _predict_refs(self, candidates, states, context, heads=False):
         """device-resident variant of predict(): states are StateRef (or None = zero
-        state); returns (probs [n,V] float32 array, list of new StateRef)."""
+        state); returns (probs [n,V] float32 array, list of new StateRef).  All index vectors travel to
+        the GPU in ONE transfer; with `heads` the first `depth` vectors of every new state come back with
+        the probabilities, so that history clustering (rating.py:887-916) compares them on the host
+        instead of synchronising with the GPU once per candidate pair."""
         pool = self._state_pool()
         n = len(candidates)
-        slot_in = np.fromiter((s.slot if s is not None else pool.zero_slot for s in states), dtype=np.int32, count=n)
         new = [pool.ref() for _ in range(n)]
-        slot_out = np.fromiter((r.slot for r in new), dtype=np.int32, count=n)
-        ctx = np.tile(np.asarray(windows.clamp_context(context), dtype=np.int32), (n, 1))
-        probs = _np(self.model.step_slots(self._ids(candidates), ctx, slot_in, slot_out))
+        ctx = np.asarray(windows.clamp_context(context), dtype=np.int32)
+        packed = np.empty((3 + len(ctx), n), dtype=np.int32)
+        packed[0] = self._ids(candidates)
+        packed[1] = np.fromiter((s.slot if s is not None else pool.zero_slot for s in states), dtype=np.int32, count=n)
+        packed[2] = np.fromiter((r.slot for r in new), dtype=np.int32, count=n)
+        packed[3:] = ctx[:, None]
+        lm = self.model
+        if hasattr(lm, "to_device_i32"):
+            dev = lm.to_device_i32(packed)
+            ctx_d = dev[3] if len(ctx) == 1 else dev[3:].t().contiguous()
+            probs = _np(lm.step_slots(dev[0], ctx_d, dev[1], dev[2]))
+        else:
+            probs = _np(lm.step_slots(packed[0], packed[3:].T.copy(), packed[1], packed[2]))
+        if heads:
+            hv = _np(lm.pool_heads(packed[2], self.depth))
+            for r, v in zip(new, hv):
+                r.head = v
         return probs, new
 
     def predict(self, candidates, initial_states, context=None):
@@ -859,7 +876,7 @@ class Rater(object):
                     break
                 preds, states = self._predict_refs(
                     [hyp.value[-1] if hyp.value else hyp.parent.value[-1] for hyp in beam],
-                    [hyp.state for hyp in beam], context)
+                    [hyp.state for hyp in beam], context, heads=bool(beam_clustering_dist))
                 for i, candidate in enumerate(beam):
                     alt = candidate.extras[1]
                     conf = alt.conf
@@ -913,6 +930,9 @@ class Rater(object):
 
     def _state_distance_below(self, a, b, k, distance):
         if isinstance(a, StateRef) and isinstance(b, StateRef):
+            if a.head is not None and b.head is not None:
+                d = a.head[k] - b.head[k]
+                return float(np.dot(d, d)) < distance * distance
             d2 = float(_np(self.model.state_dist2([a.slot], [b.slot], k))[0])
             return d2 < distance * distance
         return np.linalg.norm(np.asarray(a[k]) - np.asarray(b[k])) < distance

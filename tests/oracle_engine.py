@@ -163,6 +163,9 @@ class OracleLM(object):
         self.step_calls.append(n)
         return probs.astype(np.float32) if self.dtype == np.float32 else probs
 
+    def pool_heads(self, slots, k):
+        return self.pool[list(slots), :k].copy()
+
     def state_dist2(self, a, b, k):
         d = self.pool[list(a), k] - self.pool[list(b), k]
         return (d * d).sum(axis=-1)
