@@ -25,7 +25,7 @@ from __future__ import annotations
 import json
 import logging
 import signal
-from bisect import insort_left
+from bisect import bisect_left, insort_left
 from math import ceil, exp, log
 from random import shuffle
 
@@ -799,18 +799,31 @@ class Rater(object):
         for _ in range(length):
             fringe = next_fringe
             preds, states = self._predict_refs([n.value for n in fringe], [n.state for n in fringe], context)
-            next_fringe = []
+            # The reference insorts every continuation into one list ordered by cost and keeps the first
+            # 256 (rating.py:699-707).  Same result, less Python: the order is kept on a parallel list of
+            # float keys (insort_left = bisect_left, ties go in front), and a continuation that is
+            # strictly worse than the current 256th can never return into the kept part, so it is
+            # not even built.
+            next_fringe, keys = [], []
             for j, n in enumerate(fringe):
                 pred = preds[j]
                 pred_best = np.argsort(pred)[-10:]
                 pred_best = pred_best[np.searchsorted(pred[pred_best], 0.004):]
                 costs = -np.log(pred[pred_best])
                 state = states[j]
+                base = n.cum_cost
                 for best, cost in zip(pred_best, costs):
                     if best not in i_c:
                         continue
-                    insort_left(next_fringe, Node(parent=n, state=state, value=i_c[best], cost=cost))
-            next_fringe = next_fringe[:256]
+                    if len(keys) >= 256 and base + cost > keys[-1]:
+                        continue
+                    node = Node(parent=n, state=state, value=i_c[best], cost=cost)
+                    pos = bisect_left(keys, node.cum_cost)
+                    keys.insert(pos, node.cum_cost)
+                    next_fringe.insert(pos, node)
+                    if len(keys) > 256:
+                        keys.pop()
+                        next_fringe.pop()
         best = next_fringe[0:variants]
         return [''.join([n.value for n in res.to_sequence()]) for res in best]
 
