@@ -258,15 +258,23 @@ class Rater(object):
             for epoch in range(self.max_epochs):
                 lm.read_loss(reset=True)
                 loss_sum = acc_sum = 0.0
+                # The launches are asynchronous: the next batch is generated on the host while the GPU
+                # works on the current one, and only then is the loss read back (a synchronisation).
+                # Streams that entered a new file while that batch was generated are reset right before
+                # it is trained, as ResetStatesCallback.on_batch_begin does.
+                pending = (next_batch(train_gens), sorted(reset_rows))
+                reset_rows.clear()
                 for step in range(steps_per_epoch):
-                    x, z, y = next_batch(train_gens)
-                    if reset_rows:     # on_batch_begin: reset streams that entered a new file
-                        lm.reset_states(B, rows=sorted(reset_rows))
-                        reset_rows.clear()
+                    (x, z, y), rows = pending
+                    if rows:
+                        lm.reset_states(B, rows=rows)
                     masks = lm.draw_dropout_masks(B)
                     lm.train_window(x, z, y, masks)
                     sync.average(lm)
                     lm.adam_step()
+                    if step + 1 < steps_per_epoch:
+                        pending = (next_batch(train_gens), sorted(reset_rows))
+                        reset_rows.clear()
                     ce, acc, reg = lm.read_loss(reset=True)
                     loss = ce + reg
                     loss_sum += loss

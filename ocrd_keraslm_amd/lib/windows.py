@@ -59,16 +59,52 @@ def clamp_context(context):
 
 
 def encode(text, c_i, on_unmapped=None, base=0):
-    """characters -> int32 ids (0 = unmapped)"""
-    ids = np.zeros(len(text), dtype=np.int32)
-    for j, char in enumerate(text):
-        k = c_i.get(char)
-        if k is None:
-            if on_unmapped is not None:
-                on_unmapped(char, base + j)
-        else:
-            ids[j] = k
+    """characters -> int32 ids (0 = unmapped).  Vectorised: code points index a look-up table of the
+    mapped characters; only the (rare) unmapped positions go through Python, to be reported."""
+    n = len(text)
+    if n == 0:
+        return np.zeros(0, dtype=np.int32)
+    if n < 64 or not c_i:            # short strings: the plain loop is cheaper than building the table
+        ids = np.zeros(n, dtype=np.int32)
+        for j, char in enumerate(text):
+            k = c_i.get(char)
+            if k is None:
+                if on_unmapped is not None:
+                    on_unmapped(char, base + j)
+            else:
+                ids[j] = k
+        return ids
+    try:
+        cps = np.frombuffer(text.encode('utf-32-le', 'surrogatepass'), dtype='<u4')
+    except UnicodeEncodeError:       # pragma: no cover
+        cps = np.array([ord(ch) for ch in text], dtype=np.uint32)
+    lut = _lookup_table(c_i)
+    inside = cps < len(lut)
+    ids = np.where(inside, lut[np.where(inside, cps, 0)], -1).astype(np.int32)
+    hit = ids >= 0
+    ids[~hit] = 0
+    if on_unmapped is not None and not hit.all():
+        for j in np.nonzero(~hit)[0]:
+            on_unmapped(text[int(j)], base + int(j))
     return ids
+
+
+_TABLES = {}
+
+
+def _lookup_table(c_i):
+    """code point -> id (-1 = unmapped) as one array; cached by content"""
+    key = hash(frozenset(c_i.items()))
+    t = _TABLES.get(key)
+    if t is None:
+        single = [(ord(ch), k) for ch, k in c_i.items() if len(ch) == 1]
+        t = np.full((max(a for a, _ in single) + 1) if single else 1, -1, dtype=np.int32)
+        for a, b in single:
+            t[a] = b
+        if len(_TABLES) > 64:
+            _TABLES.clear()
+        _TABLES[key] = t
+    return t
 
 
 def count_windows(size, length):
