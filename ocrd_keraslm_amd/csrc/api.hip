@@ -374,8 +374,8 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
   // reads the look-up tables directly, and the scans also leave H^T for the weight gradients.
   const int n_rb = (B + 15) / 16;
   w.ht_ready = false;
-  if (training && h->scan_enabled && h->wide_fwd_min > 0 && (W == 512 || W == 256) && (B & 7) == 0 &&
-      n_rb * (W / 64) >= h->wide_fwd_min && n_rb <= 4 * (256 / (W / 64))) {
+  if (training && h->scan_enabled && h->wide_fwd_min > 0 && kl_scan_fwd_wide_applicable(B, T, W) &&
+      n_rb * (W / 64) >= h->wide_fwd_min) {
     for (int l = 0; l < L; ++l) {
       KL_TRY(kl_launch_transpose_bf16((const bf16_t*)w.H[l], W, w.HTf[l], (long)(T + 1) * B, B, W, s));
       const bool masked = masks != nullptr && l > 0;

@@ -138,6 +138,7 @@ struct KlScanFwdWide {
   unsigned* status;
   int sentinel;                        // 1: hand-off by data -- H blocks 1..T pre-filled with 0xFFFF halfwords, no counters
 };
+bool kl_scan_fwd_wide_applicable(int B, int T, int W);
 int kl_launch_scan_fwd_wide(KlScanFwdWide args, hipStream_t stream);
 
 struct KlScanBwd {

@@ -1121,13 +1121,28 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
   }
 }
 
-// Upper bound of co-resident scan workgroups (KL_SCAN_WGS overrides; default 512 =
-// two per CU).
+// Compute units of the current device (256 on MI355X).  The scans are sized for co-residency of
+// every workgroup, so their grids follow this number instead of assuming it.
+int scan_cus() {
+  static int v = 0;
+  if (!v) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      v = prop.multiProcessorCount;
+    else
+      v = 256;
+    if (v > 256) v = 256;      // (the row-group arithmetic below was laid out for at most 256)
+  }
+  return v;
+}
+
+// Upper bound of co-resident thin-scan workgroups (KL_SCAN_WGS overrides; default two per CU).
 int scan_max_wgs() {
   static int v = 0;
   if (!v) {
     const char* e = getenv("KL_SCAN_WGS");
-    v = e ? atoi(e) : 512;
+    v = e ? atoi(e) : 2 * scan_cus();
     if (v < 64) v = 64;
     if (v > 512) v = 512;
   }
@@ -1206,7 +1221,8 @@ extern "C" int kl_test_scan_stamps(unsigned long long* out, int reset) {
 bool kl_scan_bwd_wide_applicable(int B, int T, int W) {
   if ((W != 512 && W != 256) || B < 1 || T < 1) return false;
   const int n_rb = (B + 15) / 16, col_groups = W / 64;
-  int g = 256 / col_groups;
+  int g = scan_cus() / col_groups;
+  if (g < 1) return false;
   if (g > n_rb) g = n_rb;
   if ((n_rb + g - 1) / g > 4) return false;
   return (long)T * B * 4 * W * 2 <= 0xffffffffL;      // unsigned 32-bit buffer offsets
@@ -1218,7 +1234,7 @@ int kl_launch_scan_bwd_wide(KlScanBwd a, hipStream_t stream) {
   if (a.dZT && ((a.ldt & 7) || (a.B & 7))) return KL_ERR_SHAPE;
   a.n_rb = (a.B + 15) / 16;
   const int col_groups = W / 64;
-  int g = 256 / col_groups;            // one 1024-thread workgroup per CU
+  int g = scan_cus() / col_groups;     // one 1024-thread workgroup per CU
   if (g > a.n_rb) g = a.n_rb;
   a.n_rg = g;
   const int per_wg = (a.n_rb + g - 1) / g;
@@ -1237,15 +1253,27 @@ int kl_launch_scan_bwd_wide(KlScanBwd a, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 
+// shapes the wide forward scan serves (the launcher applies the same test)
+bool kl_scan_fwd_wide_applicable(int B, int T, int W) {
+  if ((W != 512 && W != 256) || B < 1 || T < 1 || (B & 7)) return false;
+  const int n_rb = (B + 15) / 16, col_groups = W / 64;
+  int g = scan_cus() / col_groups;
+  if (g < 1) return false;
+  if (g > n_rb) g = n_rb;
+  if ((n_rb + g - 1) / g > 4) return false;
+  return (long)T * B * 4 * W * 2 <= 0xffffffffL;      // unsigned 32-bit buffer offsets (the gate rows are the largest)
+}
+
 // One-layer forward scan with 64-unit workgroups.  KL_ERR_SHAPE = not applicable.
 int kl_launch_scan_fwd_wide(KlScanFwdWide a, hipStream_t stream) {
   const int W = a.W;
-  if ((W != 512 && W != 256) || a.B < 1 || a.T < 1 || (a.B & 7)) return KL_ERR_SHAPE;
+  if (!kl_scan_fwd_wide_applicable(a.B, a.T, W)) return KL_ERR_SHAPE;
   if ((a.HT && (a.ldt & 7)) || (a.HdT && (a.ldt_d & 7))) return KL_ERR_SHAPE;
   if (!a.P && (!a.EK || !a.idx || !a.bias || a.n_ctx > 8)) return KL_ERR_ARG;
   a.n_rb = (a.B + 15) / 16;
   const int col_groups = W / 64;
-  int g = 256 / col_groups;
+  int g = scan_cus() / col_groups;
+  if (g < 1) return KL_ERR_SHAPE;
   if (g > a.n_rb) g = a.n_rb;
   a.n_rg = g;
   const int per_wg = (a.n_rb + g - 1) / g;
@@ -1280,7 +1308,8 @@ int kl_launch_scan_fwd_split(KlScanFwdSplit a, hipStream_t stream) {
   if (col_tasks > 256) return KL_ERR_SHAPE;
   if ((long)(a.T + 1) * a.B * W * 2 > 0x7fffffffL) return KL_ERR_SHAPE;
   a.n_rb = (a.B + 15) / 16;
-  int g = 256 / col_tasks;               // one workgroup per CU (the weights fill the register file)
+  int g = scan_cus() / col_tasks;        // one workgroup per CU (the weights fill the register file)
+  if (g < 1) return KL_ERR_SHAPE;
   if (g > a.n_rb) g = a.n_rb;
   a.n_rg = g;
   const int per_wg = (a.n_rb + g - 1) / g;
