@@ -616,7 +616,14 @@ kl_handle* kl_create(const kl_config* cfg) {
 }
 
 void kl_destroy(kl_handle* h) {
-  if (h) h->drop_graphs();
+  if (h) {
+    h->drop_graphs();
+    for (auto& list : h->trace_ev)
+      for (auto& ev : list) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+      }
+  }
   delete h;
 }
 
