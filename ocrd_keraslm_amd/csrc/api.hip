@@ -106,7 +106,7 @@ struct kl_handle {
   int last_only = 0;            // stateless windows: one target per row, at the last position (kl_set_window_mode)
   bool sentinel = true;         // wide scans hand off by data sentinels instead of counters (KL_SENTINEL=0: counters)
   bool fused_step = true;       // incremental step, n >= 256: cell fused into the GEMM epilogue (KL_FUSED_STEP=0: separate kernels)
-  int wide_fwd_min = 128;       // layer-sequential wide forward scans from this many 64-unit workgroups (KL_WIDE_FWD_MIN; 0 = never)
+  int wide_fwd_min = 96;        // layer-sequential wide forward scans from this many 64-unit workgroups (KL_WIDE_FWD_MIN; 0 = never)
   double trace_flops[2] = {0.0, 0.0};   // algorithmic FLOPs of ONE timed launch
   // optional per-launch timing of the cell-step kernels with HIP events (bench.py's
   // roofline leg).  While tracing, windows run eagerly (events are not captured).
