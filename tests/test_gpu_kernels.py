@@ -429,3 +429,15 @@ def test_training_trajectory_matches_oracle(depth, width, voc, B, T):
     states = lm.states.cpu().numpy()
     for k in range(2 * depth):
         assert np.abs(states[:, k] - st[k]).max() < 3e-2
+
+
+def test_random_shapes_sweep():
+    """a fixed-seed slice of tools/fuzz_parity.py: random depth / width / vocabulary / contexts / batch /
+    window length (odd batch sizes, no context variable, 1-step windows ...) against the f64 oracle"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(14, 3, verbose=False) == 0
