@@ -113,7 +113,9 @@ def make_model(depth, width, voc, n_ctx=1, seed=4, emb_std=0.5):
                                                      # n >= 256: big-tile path (step_big.hip)
                                                      (2, 512, 256, 300, 1), (3, 96, 30, 260, 2), (1, 128, 40, 257, 1),
                                                      # cfg5 topology (small and big-n paths)
-                                                     (4, 1024, 64, 20, 2), (4, 1024, 64, 272, 2)])
+                                                     (4, 1024, 64, 20, 2), (4, 1024, 64, 272, 2),
+                                                     # wide vocabulary (V >= 1024): output projection through the big GEMM too
+                                                     (2, 128, 1100, 300, 1), (1, 64, 1500, 40, 0)])
 def test_step_batch_parity(depth, width, voc, n, n_ctx):
     """S1 (rating.py:578-639): chained incremental steps through pool slots."""
     torch = _torch()
