@@ -199,7 +199,7 @@ template <int OUT, bool ILV, int RF, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, int M, int N, int K, long lda, long ldb, long ldc,
-    int k_per_split, float alpha, const KlGateEpi epi) {
+    int k_per_split, float alpha, const KlGateEpi epi, int xcd_remap) {
   constexpr bool PRIO = KL_GEMM_PRIO;
   constexpr int NW = WM * WN;
   constexpr int WROWS = 16 * RF;               // rows per wave
@@ -217,9 +217,24 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.y * TBM;
-  const int n0 = blockIdx.x * LBN;
-  const int kbeg = blockIdx.z * k_per_split;
+  // XCD-aware tile order (speed only, any placement stays correct): workgroups are dealt round-robin
+  // over the 8 XCDs, each with its own L2, so consecutive ids land on different XCDs and the tiles
+  // that share an operand (all n-tiles of an m-tile; all tiles of one K split) would each pull it
+  // through a different L2.  Re-number so that id % 8 picks a contiguous eighth of the tile sequence.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
+    if (xcd_remap && (total & 7) == 0) {
+      const unsigned lin = bx + nx * (by + ny * bz);
+      const unsigned re = (lin & 7) * (total >> 3) + (lin >> 3);
+      bx = re % nx;
+      by = (re / nx) % ny;
+      bz = re / (nx * ny);
+    }
+  }
+  const int m0 = by * TBM;
+  const int n0 = bx * LBN;
+  const int kbeg = bz * k_per_split;
   const int kend = min(K, kbeg + k_per_split);
   const int nkt = (kend - kbeg) / BK;     // host guarantees whole k-tiles
 
@@ -311,7 +326,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
           ct[(wm * WROWS + i * 16 + fq * 4 + r) * LDP + wn * WCOLS + j * 16 + fr] = acc[i][j][r];
     __syncthreads();
     const int u = tid & 31;
-    const int U = blockIdx.x * 32 + u;
+    const int U = bx * 32 + u;
     const int W = epi.W;
     float bg[4] = {0.f, 0.f, 0.f, 0.f};
     if (epi.bias) {
@@ -392,7 +407,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
     for (int j = 0; j < NT; ++j) {
       const int col = n0 + wn * WCOLS + j * 16 + fr;
       if (col >= N) continue;
-      const float bv = (bias != nullptr && blockIdx.z == 0) ? bias[col] : 0.f;
+      const float bv = (bias != nullptr && bz == 0) ? bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm * WROWS + i * 16 + fq * 4 + r;
@@ -419,6 +434,7 @@ int launch_long_t(int out_mode, dim3 grid, hipStream_t stream, const bf16_t* A, 
   else memset(&epi, 0, sizeof(epi));
   const size_t lds = (size_t)LSTAGES * (16 * RF * WM + LBN) * 128;
   static const bool ilv = !(getenv("KL_GEMM_ILV") && getenv("KL_GEMM_ILV")[0] == '0');
+  static const int remap = !(getenv("KL_GEMM_XCD") && getenv("KL_GEMM_XCD")[0] == '0');
 #define KL_LONG_CASE(O)                                                                                                  \
   do {                                                                                                                   \
     static bool attr_set = false;                                                                                        \
@@ -430,9 +446,9 @@ int launch_long_t(int out_mode, dim3 grid, hipStream_t stream, const bf16_t* A, 
       attr_set = true;                                                                                                   \
     }                                                                                                                    \
     if (ilv) hipLaunchKernelGGL((gemm_tn_long_kernel<O, true, RF, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, A, B, C,  \
-                                bias, M, N, K, lda, ldb, ldc, k_per_split, alpha, epi);                                  \
+                                bias, M, N, K, lda, ldb, ldc, k_per_split, alpha, epi, remap);                           \
     else hipLaunchKernelGGL((gemm_tn_long_kernel<O, false, RF, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, A, B, C,     \
-                            bias, M, N, K, lda, ldb, ldc, k_per_split, alpha, epi);                                      \
+                            bias, M, N, K, lda, ldb, ldc, k_per_split, alpha, epi, remap);                               \
   } while (0)
   if (out_mode == 0) KL_LONG_CASE(0);
   else if (out_mode == 1) KL_LONG_CASE(1);
