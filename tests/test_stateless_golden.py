@@ -112,7 +112,8 @@ def test_rate_rate2_test_stateless(vl, factory, tol):
     assert abs(r.test([f]) - g["test_ppl"]) < 10 * tol * g["test_ppl"]
 
 
-def test_train_stateless_runs_on_the_test_double():
+def test_train_stateless_runs_on_the_test_double(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)      # (training writes its per-epoch checkpoints into the working directory)
     random.seed(1)
     np.random.seed(2)
     files = []
