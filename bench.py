@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("KL_BENCH_STREAMS", "512")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("KL_BENCH_STREAMS", "1024")),
                     help="stateful streams per GPU (B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-incremental", action="store_true")

@@ -105,6 +105,10 @@ struct kl_handle {
   bool inc_ready = false;       // the big-n incremental operands match the current weights
   int last_only = 0;            // stateless windows: one target per row, at the last position (kl_set_window_mode)
   bool sentinel = true;         // wide scans hand off by data sentinels instead of counters (KL_SENTINEL=0: counters)
+  bool xcd_local = false;       // KL_XCD_LOCAL=1: sentinel hand-off inside one XCD through its L2 (plain stores) where the placement allows
+  bool sentinel_bwd = true;
+  bool sentinel_bwd_all = false; // KL_SENTINEL_BWD=2: also with one row block per workgroup
+  bool xcd_local_bwd = false;    // KL_XCD_LOCAL_BWD=1     // the same for the wide backward scan (KL_SENTINEL_BWD=0, or KL_SENTINEL=0: counters)
   bool fused_step = true;       // incremental step, n >= 256: cell fused into the GEMM epilogue (KL_FUSED_STEP=0: separate kernels)
   int wide_fwd_min = 96;        // layer-sequential wide forward scans from this many 64-unit workgroups (KL_WIDE_FWD_MIN; 0 = never)
   double trace_flops[2] = {0.0, 0.0};   // algorithmic FLOPs of ONE timed launch
@@ -238,7 +242,7 @@ size_t carve_window(const kl_handle* h, void* base, int B, int T, int training, 
   o.s_masks = cv.take<float>(training ? L * (size_t)B * W : 1);
   o.s_probs = cv.take<float>(training ? 1 : BT * V);
   o.scan_cnt = cv.take<unsigned>(L * ((size_t)(B + 15) / 16) * T);
-  o.scan_status = cv.take<unsigned>(4);
+  o.scan_status = cv.take<unsigned>(4 + 256);   // status words [4] + XCC posts of the wide scans' workgroups [256]
   o.reg_scratch = cv.take<float>(3 * (W > (size_t)c.ctx_dim ? W : (size_t)c.ctx_dim) + (V > (size_t)c.ctx_vocab ? V : (size_t)c.ctx_vocab) + 8);
   if (training) {
     o.G.assign(L, nullptr); o.dZ.assign(L, nullptr); o.Hd.assign(L, nullptr);
@@ -403,6 +407,8 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       a.counters = w.scan_cnt;
       a.status = w.scan_status;
       a.sentinel = h->sentinel ? 1 : 0;
+      a.xcc_slots = (a.sentinel && h->xcd_local) ? w.scan_status + 4 : nullptr;
+      a.gen = (unsigned)(1 + l);                   // (the posts are zeroed once per window: a token per launch)
       if (a.sentinel)   // hand-off by data: the blocks the scan is going to publish start out as sentinels
         KL_TRY(kl_fill_u32_async((bf16_t*)w.H[l] + BW, (size_t)T * BW * sizeof(bf16_t), 0xFFFFFFFFu, s));
       else
@@ -648,6 +654,13 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->wide_bwd = !(env4 && env4[0] == '0');
   const char* env7 = getenv("KL_SENTINEL");
   h->sentinel = !(env7 && env7[0] == '0');
+  const char* env7c = getenv("KL_XCD_LOCAL");
+  h->xcd_local = env7c && env7c[0] == '1';
+  const char* env7b = getenv("KL_SENTINEL_BWD");
+  h->sentinel_bwd = h->sentinel && !(env7b && env7b[0] == '0');
+  h->sentinel_bwd_all = env7b && env7b[0] == '2';
+  const char* env7d = getenv("KL_XCD_LOCAL_BWD");
+  h->xcd_local_bwd = h->xcd_local && env7d && env7d[0] == '1';
   const char* env6 = getenv("KL_FUSED_STEP");
   h->fused_step = !(env6 && env6[0] == '0');
   const char* env5 = getenv("KL_WIDE_FWD_MIN");
@@ -676,7 +689,7 @@ static int forward_window_body(kl_handle* h, int B, int T, const int32_t* idx, c
   WindowWs w;
   if (ws_bytes < carve_window(h, ws, B, T, 0, &w)) return KL_ERR_WORKSPACE;
   const int W = h->cfg.width, V = h->cfg.voc_size, L = h->cfg.depth;
-  KL_TRY(kl_zero_async(w.scan_status, 4 * sizeof(unsigned), s));
+  KL_TRY(kl_zero_async(w.scan_status, (4 + 256) * sizeof(unsigned), s));
   KL_TRY(forward_impl(h, B, T, idx, ctx, states, nullptr, 0, w, s));
   KlOperand op;
   memset(&op, 0, sizeof(op));
@@ -712,7 +725,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   const int ksplit = BT >= 4096 ? 8 : (BT >= 1024 ? 4 : 1);
 
   KL_TRY(kl_zero_async(grads, h->n_params * sizeof(float), s));
-  KL_TRY(kl_zero_async(w.scan_status, 4 * sizeof(unsigned), s));
+  KL_TRY(kl_zero_async(w.scan_status, (4 + 256) * sizeof(unsigned), s));
   KL_TRY(forward_impl(h, B, T, idx, ctx, states, masks, 1, w, s));
 
   // F5/F6: logits over the (masked) top-layer outputs, softmax, CE, dlogits
@@ -815,7 +828,15 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       a.dH = w.dH;
       a.counters = w.scan_cnt;
       a.status = w.scan_status + 1;
-      KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)n_rb_all * T, s));
+      // (sentinels pay with several row blocks per workgroup, where the next tile is prefetched; with one
+      // block the cheap counter poll beats re-fetching 64 KiB tiles; XCD-local publishes measured slower here)
+      a.sentinel = (h->sentinel_bwd && wide_fits && (kl_scan_wide_blocks_per_wg(B, W) > 1 || h->sentinel_bwd_all)) ? 1 : 0;
+      a.xcc_slots = (a.sentinel && h->xcd_local_bwd) ? w.scan_status + 4 : nullptr;
+      a.gen = (unsigned)(1 + L + l);
+      if (a.sentinel)   // hand-off by data: the steps the scan is going to publish start out as sentinels
+        KL_TRY(kl_fill_u32_async(w.dZ[l], (size_t)T * BW * 4 * sizeof(bf16_t), 0xFFFFFFFFu, s));
+      else
+        KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)n_rb_all * T, s));
       if (l == L - 1) h->trace_begin(1, s);
       // wide (64-unit) workgroups share the dZ tile through LDS and write dZ^T themselves
       a.dZT = (BTp == BT && (B & 7) == 0) ? w.dZT : nullptr;
@@ -826,6 +847,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       if (e == KL_ERR_SHAPE) {
         a.dZT = nullptr;
         a.db = nullptr;
+        if (a.sentinel) KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)n_rb_all * T, s));   // (the thin scan counts)
         e = kl_launch_scan_bwd(a, s);
       }
       if (e != 0) return e;

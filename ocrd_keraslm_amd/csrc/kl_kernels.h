@@ -137,6 +137,7 @@ struct KlScanFwdWide {
   unsigned* counters;                  // [n_rb][T] (counter hand-off)
   unsigned* status;
   int sentinel;                        // 1: hand-off by data -- H blocks 1..T pre-filled with 0xFFFF halfwords, no counters
+  unsigned* xcc_slots; unsigned gen;   // [256] + launch token: XCD-local hand-off if the workgroups of a row group share an XCD (null: off)
 };
 bool kl_scan_fwd_wide_applicable(int B, int T, int W);
 int kl_launch_scan_fwd_wide(KlScanFwdWide args, hipStream_t stream);
@@ -155,9 +156,12 @@ struct KlScanBwd {
   unsigned* status;
   bf16_t* dZT; long ldt;               // wide one-layer kernel only: also write dZ transposed [4W][ldt] (null: no)
   float* db;                           // wide one-layer kernel only: += column sums of dZ (bias gradient; null: no)
+  int sentinel;                        // wide one-layer kernel only: 1 = hand-off by data sentinels (dZ pre-filled with 0xFFFF halfwords)
+  unsigned* xcc_slots; unsigned gen;   // as KlScanFwdWide (sentinel hand-off only)
 };
 int kl_launch_scan_bwd(KlScanBwd args, hipStream_t stream);
 bool kl_scan_bwd_wide_applicable(int B, int T, int W);
+int kl_scan_wide_blocks_per_wg(int B, int W);
 int kl_launch_scan_bwd_wide(KlScanBwd args, hipStream_t stream);   // one layer per launch, 64-unit workgroups
 
 // thin split-precision contraction C[M,N] = A[M,K] . WT[N,K]^T (+bias) for

@@ -45,19 +45,36 @@ constexpr unsigned SPIN_LIMIT = 1u << 20;
 
 // diagnostic build only (-DKL_STAMP): cycle shares of the forward scan's step phases
 #ifdef KL_STAMP
+#ifndef KL_STAMP_TID
+#define KL_STAMP_TID 0      /* the stamped thread of the stamped workgroup */
+#endif
 __device__ unsigned long long kl_scan_stamps[32];   // [0,16) forward scan, [16,32) backward scan
 #define SSTAMP(i)                                                                     \
   do {                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                \
-    if (blockIdx.x == STAMP_WG && threadIdx.x == 0) {                                 \
+    if (blockIdx.x == STAMP_WG && threadIdx.x == KL_STAMP_TID) {                      \
       const unsigned long long now_ = clock64();                                      \
-      kl_scan_stamps[i] += now_ - last_;                                              \
+      stamp_lds[i] += now_ - last_;     /* LDS: no global round trip inside the step */ \
       last_ = now_;                                                                   \
     }                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                \
   } while (0)
+#define SSTAMP_INIT(wg)                                                               \
+  const int STAMP_WG = (wg);                                                          \
+  __shared__ unsigned long long stamp_lds[32];                                        \
+  if (threadIdx.x < 32) stamp_lds[threadIdx.x] = 0;                                   \
+  __syncthreads();                                                                    \
+  unsigned long long last_ = clock64();
+#define SSTAMP_FLUSH()                                                                \
+  do {                                                                                \
+    __syncthreads();                                                                  \
+    if (blockIdx.x == STAMP_WG && threadIdx.x < 32 && stamp_lds[threadIdx.x])         \
+      atomicAdd(&kl_scan_stamps[threadIdx.x], stamp_lds[threadIdx.x]);                \
+  } while (0)
 #else
 #define SSTAMP(i)
+#define SSTAMP_INIT(wg)
+#define SSTAMP_FLUSH()
 #endif
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long bytes) {
@@ -80,6 +97,69 @@ __device__ __forceinline__ void store16(__amdgpu_buffer_rsrc_t r, unsigned lane_
 }
 __device__ __forceinline__ void store16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, uint4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, r, (int)byte_off, 0, 16);
+}
+
+// 16 bytes per lane straight into LDS (write-through-coherent read): lane l of the wave lands at
+// lds_addr + 16 l.  Inline asm: the compiler must not know about the load, or it would wait for it
+// at the next LDS access; the waits are counted by hand (wait_vm).  M0 is compiler-reserved.
+__device__ __forceinline__ void glds16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen sc1 lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(lds_addr)
+      : "memory");
+}
+// wait until at most k (wave-uniform; an under-estimate only waits longer) vector memory operations of
+// this wave are in flight
+__device__ __forceinline__ void wait_vm(int k) {
+#define KL_WAIT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+  switch (k < 0 ? 0 : (k > 10 ? 10 : k)) {
+    KL_WAIT_CASE(0) KL_WAIT_CASE(1) KL_WAIT_CASE(2) KL_WAIT_CASE(3) KL_WAIT_CASE(4) KL_WAIT_CASE(5)
+    KL_WAIT_CASE(6) KL_WAIT_CASE(7) KL_WAIT_CASE(8) KL_WAIT_CASE(9) KL_WAIT_CASE(10)
+  }
+#undef KL_WAIT_CASE
+}
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// XCD-local hand-off.  Workgroup b runs on XCD b % 8, and the wide scans place all workgroups that
+// exchange data (one row group, all column groups) on one XCD.  Data written with PLAIN stores then
+// stays in that XCD's L2, where the partners' L1-bypassing (sc1) loads find it: half the latency of the
+// write-through path and no fabric traffic (tools/micro/handoff_xcd.hip: 284 vs 585 ns one way).  Across
+// XCDs the same combination is NOT coherent, so the placement is not assumed but checked at the start
+// of every launch: each workgroup posts (launch token, its XCC id) write-through, reads its partners'
+// posts and takes the local path only if all of them sit on its own XCD.
+__device__ __forceinline__ unsigned xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xf;
+}
+// called by all threads; slot of workgroup b = slots[b]; partners = blockIdx of column group j for j < n_partners
+template <typename F>
+__device__ __forceinline__ bool xcd_local_group(unsigned* slots, unsigned gen, int n_partners, F partner_block, int* lds_flag,
+                                                unsigned* status) {
+  const unsigned mine = xcc_id();
+  if (threadIdx.x == 0) __hip_atomic_store(slots + blockIdx.x, (gen << 4) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x < 64) {
+    bool same = true;
+    if ((int)threadIdx.x < n_partners) {
+      const unsigned* slot = slots + partner_block((int)threadIdx.x);
+      unsigned v = 0;
+      bool got = false;
+      for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
+        v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 4) == gen) { got = true; break; }
+        if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (!got) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      same = got && (v & 15u) == mine;
+    }
+    const bool all_same = __all(same);
+    if (threadIdx.x == 0) *lds_flag = all_same ? 1 : 0;
+  }
+  __syncthreads();
+  return *lds_flag != 0;
 }
 
 // Sentinel hand-off: exchange buffers are pre-filled with 0xFFFF halfwords (a bf16 NaN pattern
@@ -182,10 +262,7 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_fwd_kernel(const KlScanFwd a
   unsigned* cnt_own = a.counters + (long)l * n_rb * T;
   unsigned* cnt_in = a.counters + (long)(has_in ? l - 1 : 0) * n_rb * T;
   bool alive = true;
-#ifdef KL_STAMP
-  const int STAMP_WG = gridDim.x - 1;     // a top-layer workgroup
-  unsigned long long last_ = clock64();
-#endif
+  SSTAMP_INIT(gridDim.x - 1);
 
   for (int t = 0; t < T; ++t) {
 #pragma unroll
@@ -308,6 +385,7 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_fwd_kernel(const KlScanFwd a
       SSTAMP(10);
     }
   }
+  SSTAMP_FLUSH();
 }
 
 // ---------------------------------------------------------------- forward scan, split precision (rating)
@@ -531,10 +609,7 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
   unsigned* cnt_own = a.counters + (long)l * n_rb * T;
   unsigned* cnt_up = a.counters + (long)(has_up ? l + 1 : l) * n_rb * T;
   bool alive = true;
-#ifdef KL_STAMP
-  const int STAMP_WG = 0;     // top layer when layers are scanned one by one (L = 1 view)
-  unsigned long long last_ = clock64();
-#endif
+  SSTAMP_INIT(0);
 
   for (int t = T - 1; t >= 0; --t) {
 #pragma unroll
@@ -630,6 +705,7 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
       SSTAMP(24);
     }
   }
+  SSTAMP_FLUSH();
 }
 
 // dynamic LDS of the wide kernels up to (excluding) the per-row-block state slots [MAXRB][1024] f32
@@ -646,7 +722,10 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
 // contraction only; the from-above term arrives in dH from the big GEMM).  The step's
 // dZ tile is also written transposed ([4W][T*B], plain stores after the publish) for the
 // weight-gradient GEMMs, which saves the separate transpose pass.
-template <int KSTEPS, int MAXRB>
+// SENT: data-sentinel hand-off (dZ pre-filled with 0xFFFF halfwords by the caller) instead of counters:
+// no poll, no drain, no atomics; with several row blocks per workgroup the next block's tile is
+// prefetched by LDS-DMA behind the epilogue (see lstm_scan_fwd_wide_kernel).
+template <int KSTEPS, int MAXRB, bool SENT>
 __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlScanBwd a) {
   constexpr int W = KSTEPS * 32;
   constexpr int NWG_RB = W / 64;          // producers per (row block, step)
@@ -655,7 +734,12 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq4 = wave & 3, ug = wave >> 2;
   const int n_rg = a.n_rg, n_rb = a.n_rb, B = a.B, T = a.T;
-  const int cg = blockIdx.x / n_rg, rg = blockIdx.x % n_rg;
+  // placement: XCD x = blockIdx % 8 hosts the row groups x R .. x R + R - 1 (R = ceil(n_rg / 8)), each
+  // with all its column groups: partners share an L2, and so do the row blocks whose 32-byte pieces
+  // make up one line of the transposed copies (4 adjacent blocks = 64 rows = 128 bytes)
+  const int xcd = blockIdx.x & 7, yy = blockIdx.x >> 3;
+  const int cg = yy % NWG_RB, rq = yy / NWG_RB, rg = xcd * ((n_rg + 7) >> 3) + rq;
+  if (rg >= n_rg) return;
   const int u0 = cg * 64;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -698,11 +782,36 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
   // (deferring needs a second row block whose publish releases the first one's signal: a workgroup
   // with a single block would wait for its own deferred signal)
   const bool defer = rg + n_rg < n_rb;
-#ifdef KL_STAMP
-  const int STAMP_WG = 0;
-  unsigned long long last_ = clock64();
-#endif
+  constexpr bool PREF = SENT && MAXRB > 1;
+  const bool pref_ok = (B & 15) == 0;          // whole tiles only: the counted wait assumes every store is issued
+  const int n_raw = maskl ? 8 : 7;             // epilogue inputs loaded at the top of a block, behind the DMA
+  const unsigned lds_a = (unsigned)(size_t)(lds_void_t*)a_tile;
+  // vector memory operations of a wave between its DMA and the next block's wait: the publish (waves 0-7)
+  const int pf_after = wave < 8 ? 1 : 0;       // (the transposed copy leaves late, in front of the DMA: see LATE)
+  int pf_issued = 0;
+  if (tid == 0) ok_flag = 1;
+  __syncthreads();
+  bool local = false;
+  if (SENT && a.xcc_slots)
+    local = xcd_local_group(a.xcc_slots, a.gen, NWG_RB, [&](int j) { return xcd + 8 * (rq * NWG_RB + j); }, &ok_flag + 1, status);
+  SSTAMP_INIT(0);
 
+  // the transposed copy (waves 8..15): behind the publish, or -- several row blocks per workgroup -- one
+  // phase late, at the start of the next block's MFMA phase (see LATE in lstm_scan_fwd_wide_kernel)
+  constexpr bool LATE = SENT && MAXRB > 1;
+  int t_prev = 0, r0_prev = 0;
+  bool have_prev = false;
+  auto store_transposed = [&](int t, int r0) {
+    int stid = tid;
+    if (MAXRB > 1 || SENT) asm volatile("" : "+v"(stid));
+    // 256 columns (gate, unit) x 16 rows: two 16-byte stores per column (the waves that do not
+    // publish); buffer store = lane offset + scalar step offset (B % 8 == 0 is a launch condition)
+    const int col = (stid - 512) >> 1, half = stid & 1;
+    const int g = col >> 6, u = col & 63;
+    if (r0 + half * 8 < B)
+      store16(rs_dzt, (unsigned)(((long)(g * W + u0 + u) * a.ldt + half * 8) * 2), (unsigned)(t * B + r0) * 2u,
+              *reinterpret_cast<const uint4*>(tr + col * 16 + half * 8));
+  };
   for (int t = T - 1; t >= 0; --t) {
 #pragma unroll 1
     for (int i = 0; i < MAXRB; ++i) {
@@ -719,29 +828,82 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
       float dh = (dH + ((long)t * B + erow) * W + u0)[eu];
       float mkv = maskl ? (maskl + (long)erow * W + u0)[eu] : 1.f;
       SSTAMP(16);
-      if (tid == 0) {
-        bool ok = alive;
-        if (ok && t < T - 1) ok = poll_counter(cnt_own + (long)rb * T + (t + 1), 8 * NWG_RB, status);
-        ok_flag = ok ? 1 : 0;
+      if (!SENT) {
+        if (tid == 0) {
+          bool ok = alive;
+          if (ok && t < T - 1) ok = poll_counter(cnt_own + (long)rb * T + (t + 1), 8 * NWG_RB, status);
+          ok_flag = ok ? 1 : 0;
+        }
+        SSTAMP(17);
+        __syncthreads();
+        SSTAMP(18);
+        alive = ok_flag != 0;
       }
-      SSTAMP(17);
-      __syncthreads();
-      SSTAMP(18);
-      alive = ok_flag != 0;
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       if (t < T - 1) {
         // fetch 1/16 of the 16 x 4W tile of dZ[t+1]: quarter kq4, k-steps ug*JW .. +JW
         const int arow = min(r0 + (lane & 15), B - 1);
         const unsigned base = (unsigned)((((long)(t + 1) * B + arow) * 4 * W + (long)kq4 * W + kq) * 2);
-        uint4 av[JW];
+        unsigned char* frag = a_tile + ((kq4 * KSTEPS) + ug * JW) * 1024 + lane * 16;
+        if (!SENT) {
+          uint4 av[JW];
 #pragma unroll
-        for (int j = 0; j < JW; ++j) av[j] = alive ? load16_sc1(rs_own, base + (ug * JW + j) * 64) : uint4{0, 0, 0, 0};
+          for (int j = 0; j < JW; ++j) av[j] = alive ? load16_sc1(rs_own, base + (ug * JW + j) * 64) : uint4{0, 0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < JW; ++j)
-          *reinterpret_cast<uint4*>(a_tile + ((kq4 * KSTEPS) + ug * JW + j) * 1024 + lane * 16) = av[j];
+          for (int j = 0; j < JW; ++j) *reinterpret_cast<uint4*>(frag + j * 1024) = av[j];
+        } else {
+          // sentinel hand-off: every wave brings its own granules into LDS (DMA: no registers) and
+          // re-fetches them until none carries the sentinel; with the prefetch the first round is
+          // already in flight
+          bool ok = false;
+          if (alive) {
+            // Without a prefetch in flight the wave first probes ONE of its fragments (1/4 of the
+            // traffic per round: 256 workgroups spinning on whole 64 KiB tiles slow the publishes down)
+            // and fetches the rest once that one is there.
+            bool issued = PREF && pf_issued;
+            int lo = issued ? 0 : JW - 1;          // fragments [lo, JW) are fetched and checked this round
+            for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
+              if (issued) {
+                wait_vm(pf_after + n_raw);
+              } else {
+#pragma unroll
+                for (int j = 0; j < JW; ++j)
+                  if (j >= lo) glds16_sc1(rs_own, base + (ug * JW + j) * 64, lds_a + ((kq4 * KSTEPS) + ug * JW + j) * 1024);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              }
+              bool all_ok = true;
+#pragma unroll
+              for (int j = 0; j < JW; ++j)
+                if (j >= lo) all_ok = all_ok && granule_valid(*reinterpret_cast<const uint4*>(frag + j * 1024));
+              if (__all(all_ok)) {
+                if (lo == 0) { ok = true; break; }
+                lo = 0;                            // probe passed: now everything (the probe fragment again: cheap, and keeps the loop simple)
+                issued = false;
+                continue;
+              }
+#ifdef KL_STAMP
+              if (issued && blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[28] += 1;   // a prefetch that came too early
+#endif
+              issued = false;
+              if (lo == 0 && JW > 1) lo = JW - 1;  // back to probing
+              if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+              __builtin_amdgcn_s_sleep(2);
+            }
+            if (!ok) {
+              __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ok_flag = 0;
+            }
+          }
+          if (!ok) {
+#pragma unroll
+            for (int j = 0; j < JW; ++j) *reinterpret_cast<uint4*>(frag + j * 1024) = uint4{0, 0, 0, 0};
+          }
+        }
         SSTAMP(19);
         __syncthreads();
         SSTAMP(20);
+        if (SENT) alive = ok_flag != 0;
+        if (LATE && have_prev && wave >= 8) store_transposed(t_prev, r0_prev);
 #pragma unroll
         for (int j = 0; j < KSTEPS; ++j) {
           frag16 fa, fb;
@@ -750,6 +912,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
           acc = mfma16(fa.v, fb.v, acc);
         }
       }
+      else if (LATE && have_prev && wave >= 8) store_transposed(t_prev, r0_prev);     // (first step: nothing to fetch)
 #pragma unroll
       for (int r = 0; r < 4; ++r) zt[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
       SSTAMP(21);
@@ -757,6 +920,21 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
       SSTAMP(22);
       const int wz = (eu >> 4) * 4;      // the four K-quarter waves of this unit group
       asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(c), "+v"(cp), "+v"(dh), "+v"(mkv));
+      SSTAMP(27);
+      if (PREF) {
+        // the tile buffer is free again (the MFMAs above consumed it): fetch the next block's tile
+        pf_issued = 0;
+        int ni = i + 1, nt = t;
+        if (ni >= MAXRB || rg + ni * n_rg >= n_rb) { ni = 0; nt = t - 1; }
+        if (pref_ok && alive && nt >= 0 && nt < T - 1) {
+          const int nr0 = (rg + ni * n_rg) * 16;
+          const unsigned nbase = (unsigned)((((long)(nt + 1) * B + nr0 + (lane & 15)) * 4 * W + (long)kq4 * W + kq) * 2);
+#pragma unroll
+          for (int j = 0; j < JW; ++j)
+            glds16_sc1(rs_own, nbase + (ug * JW + j) * 64, lds_a + ((kq4 * KSTEPS) + ug * JW + j) * 1024);
+          pf_issued = 1;
+        }
+      }
       dh = dh * mkv + (zt[wz][er][eu & 15] + zt[wz + 1][er][eu & 15] + zt[wz + 2][er][eu & 15] + zt[wz + 3][er][eu & 15]);
       const float gi = bf2f((bf16_t)g0), gf = bf2f((bf16_t)g1), gg = bf2f((bf16_t)g2), go = bf2f((bf16_t)g3);
       const float tc = fast_tanh(c);
@@ -785,19 +963,27 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
       SSTAMP(24);
       // publish dZ[t]: eight waves, one 16-byte write-through store per lane; each storing
       // wave drains its own stores and then counts itself in (8 arrivals per workgroup)
-      if (tid < 512) {
+      // (lane offsets re-derived every step from an opaque copy of the thread id: as hoisted loop
+      // invariants they cost registers the 128 cap does not have)
+      int stid = tid;
+      if (MAXRB > 1 || SENT) asm volatile("" : "+v"(stid));
+      if (wave < 8) {
         // (several row blocks per workgroup: the previous block's drain + signal happen here, its
         // write-through latency hidden behind this block's step)
-        if (MAXRB > 1 && pend >= 0) {
+        if (!SENT && MAXRB > 1 && pend >= 0) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           signal_wave(cnt_own + pend, lane);
         }
-        const int g = tid >> 7, prow = (tid >> 3) & 15, seg = tid & 7;
+        const int g = stid >> 7, prow = (stid >> 3) & 15, seg = stid & 7;
         if (alive && r0 + prow < B) {
           const uint4 v = *reinterpret_cast<const uint4*>(pub + (g * 16 + prow) * 64 + seg * 8);
-          store16_sc1(rs_own, (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2), v);
+          const unsigned off = (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2);
+          if (SENT && local) store16(rs_own, off, 0u, v);      // stays in this XCD's L2, where all its readers are
+          else store16_sc1(rs_own, off, v);
         }
-        if (MAXRB > 1 && defer) {
+        if (SENT) {
+          // the data is its own signal: nothing to drain, nothing to count
+        } else if (MAXRB > 1 && defer) {
           pend = rb * T + t;           // drained and signalled at the next publish
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -806,21 +992,20 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
         }
       }
       SSTAMP(26);
-      if (has_dzt && alive && wave >= 8) {
-        // 256 columns (gate, unit) x 16 rows: two 16-byte stores per column (the waves that do not
-        // publish); buffer store = lane offset + scalar step offset (B % 8 == 0 is a launch condition)
-        const int col = (tid - 512) >> 1, half = tid & 1;
-        const int g = col >> 6, u = col & 63;
-        if (r0 + half * 8 < B)
-          store16(rs_dzt, (unsigned)(((long)(g * W + u0 + u) * a.ldt + half * 8) * 2), (unsigned)(t * B + r0) * 2u,
-                  *reinterpret_cast<const uint4*>(tr + col * 16 + half * 8));
+      if (!LATE && has_dzt && alive && wave >= 8) store_transposed(t, r0);
+      if (LATE) {
+        t_prev = t;
+        r0_prev = r0;
+        have_prev = has_dzt && alive;
       }
     }
   }
-  if (MAXRB > 1 && tid < 512 && pend >= 0) {
+  if (!SENT && MAXRB > 1 && tid < 512 && pend >= 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     signal_wave(cnt_own + pend, lane);
   }
+  if (LATE && have_prev && wave >= 8) store_transposed(t_prev, r0_prev);     // the last block's
+  SSTAMP_FLUSH();
   // db[g*W + u] += sum over this workgroup's rows and all steps (16 partials per column meet in LDS)
   if (a.db) {
     __syncthreads();
@@ -859,7 +1044,12 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq4 = wave & 3, ug = wave >> 2;
   const int n_rg = a.n_rg, n_rb = a.n_rb, B = a.B, T = a.T;
-  const int cg = blockIdx.x / n_rg, rg = blockIdx.x % n_rg;
+  // placement: XCD x = blockIdx % 8 hosts the row groups x R .. x R + R - 1 (R = ceil(n_rg / 8)), each
+  // with all its column groups: partners share an L2, and so do the row blocks whose 32-byte pieces
+  // make up one line of the transposed copies (4 adjacent blocks = 64 rows = 128 bytes)
+  const int xcd = blockIdx.x & 7, yy = blockIdx.x >> 3;
+  const int cg = yy % NWG_RB, rq = yy / NWG_RB, rg = xcd * ((n_rg + 7) >> 3) + rq;
+  if (rg >= n_rg) return;
   const int u0 = cg * 64;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -908,14 +1098,24 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
   bool alive = true;
   if (tid == 0) ok_flag = 1;
   __syncthreads();
+  bool local = false;
+  if (SENT && a.xcc_slots)
+    local = xcd_local_group(a.xcc_slots, a.gen, NWG_RB, [&](int j) { return xcd + 8 * (rq * NWG_RB + j); }, &ok_flag + 1, status);
+  // Tile prefetch (sentinel hand-off, several row blocks per workgroup): the next block's tile was
+  // published a whole block ago, so its fetch is issued as an LDS-DMA right after this block's MFMA
+  // phase has released the tile buffer and lands behind the epilogue; the next block only reads its own
+  // granules back and checks them (falling back to the spin when a producer was late).
+  constexpr bool PREF = SENT && MAXRB > 1;
+  const bool pref_ok = (B & 15) == 0;          // whole tiles only: the counted wait below assumes every store is issued
+  const unsigned lds_a = (unsigned)(size_t)(lds_void_t*)a_tile;
+  // vector memory operations a wave issues between the DMA and the next block's wait: the publish
+  const int pf_after = wave < 2 ? 1 : 0;       // (the other stores leave late, in front of the DMA: see LATE)
+  int pf_issued = 0;
   int pend = -1;       // counter hand-off, publishing waves: counter index of stores issued but not yet signalled
   // (deferring needs a second row block whose publish releases the first one's signal: a workgroup
   // with a single block would wait for its own deferred signal)
   const bool defer = rg + n_rg < n_rb;
-#ifdef KL_STAMP
-  const int STAMP_WG = 0;
-  unsigned long long last_ = clock64();
-#endif
+  SSTAMP_INIT(0);
 
   // layer 0: the table row ids of a step are fetched (scalar loads, the row is wave-uniform) at the
   // end of the step before, where their latency hides behind the hand-off
@@ -925,6 +1125,46 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
     id_cur = sload_i32(a.idx + src0);
     if (a.n_ctx > 0) c0_cur = sload_i32(a.ctx + src0 * a.n_ctx);
   }
+  // What only later launches read (waves 2..15).  With one row block per workgroup it follows the publish;
+  // with several (LATE) a block's staging buffers are stored one phase late, at the start of the next
+  // block's MFMA phase when that block's tile has arrived, instead of sitting in the memory pipeline in
+  // front of the next tile's loads (same box, B = 1024 / 2048: 2-3 % of a training step; at B = 512 the
+  // late stores cost more under the epilogue's wait for its inputs than they save).
+  constexpr bool LATE = SENT && MAXRB > 1;
+  unsigned trow_prev = 0;
+  int r0_prev = 0;
+  bool have_prev = false;
+  auto offchain = [&](unsigned trow, int r0) {
+    int stid = tid;
+    if (MAXRB > 1) asm volatile("" : "+v"(stid));
+        // off the hand-off chain (buffer stores: lane offset + scalar step offset; a null buffer has
+      // zero records and drops the store)
+      const int q = stid - 128;
+      if (q < 512) {                       // gate activations: [gate][row] x 8 pieces of 8 units
+        const int g = q >> 7, prow = (q >> 3) & 15, seg = q & 7;
+        if (r0 + prow < B)
+          store16(rs_g, (unsigned)((prow * 4 * W + g * W + seg * 8) * 2), (trow * 4 * W + u0) * 2u,
+                  *reinterpret_cast<const uint4*>(st_g + (g * 16 + prow) * 64 + seg * 8));
+      } else if (q < 768) {                // cell state: [row] x 16 pieces of 4 units
+        const int prow = (q - 512) >> 4, seg = q & 15;
+        if (r0 + prow < B)
+          store16(rs_c, (unsigned)((prow * W + seg * 4) * 4), ((trow + B) * W + u0) * 4u,
+                  *reinterpret_cast<const uint4*>(st_c + prow * 64 + seg * 4));
+      } else {                             // masked outputs: [row] x 8 pieces of 8 units
+        const int prow = (q - 768) >> 3, seg = q & 7;
+        if (r0 + prow < B)
+          store16(rs_hd, (unsigned)((prow * W + seg * 8) * 2), (trow * W + u0) * 2u,
+                  *reinterpret_cast<const uint4*>(st_hd + prow * 64 + seg * 8));
+      }
+      if (q < 256) {   // transposed copies: 64 units x 16 rows, two 16-byte stores per unit (x2 buffers)
+        const int which = q >> 7, unit = (q >> 1) & 63, half = q & 1;
+        if (r0 + half * 8 < B) {
+          const uint4 v = *reinterpret_cast<const uint4*>(tr + (which * 64 + unit) * 16 + half * 8);
+          if (which) store16(rs_hdt, (unsigned)(((long)(u0 + unit) * a.ldt_d + half * 8) * 2), trow * 2u, v);
+          else store16(rs_ht, (unsigned)(((long)(u0 + unit) * a.ldt + half * 8) * 2), (trow + B) * 2u, v);
+        }
+      }
+  };
   for (int t = 0; t < T; ++t) {
 #pragma unroll 1
     for (int i = 0; i < MAXRB; ++i) {
@@ -954,9 +1194,19 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
         const int arow = min(r0 + (lane & 15), B - 1);
         const unsigned off = (unsigned)((((long)t * B + arow) * W + wave * 32 + kq) * 2);
         uint4 v = uint4{0, 0, 0, 0};
+        bool in_lds = false;
         if (alive) {
           bool ok = false;
-          for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
+          if (PREF && pf_issued) {
+            wait_vm(pf_after);
+            v = *reinterpret_cast<const uint4*>(a_tile + wave * 1024 + lane * 16);
+            ok = __all(granule_valid(v));
+            in_lds = ok;
+#ifdef KL_STAMP
+            if (!ok && blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[12] += 1;   // a prefetch that came too early
+#endif
+          }
+          if (!ok) for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
             v = load16_sc1(rs_h, off);
             if (__all(t == 0 || granule_valid(v))) { ok = true; break; }
             if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
@@ -968,7 +1218,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
             v = uint4{0, 0, 0, 0};
           }
         }
-        *reinterpret_cast<uint4*>(a_tile + wave * 1024 + lane * 16) = v;
+        if (!in_lds) *reinterpret_cast<uint4*>(a_tile + wave * 1024 + lane * 16) = v;
       }
       // gate inputs that do not depend on the hand-off, issued behind the tile fetch: they are
       // consumed two barriers later, and their wait must not sit in front of the tile's (vmcnt is
@@ -1002,6 +1252,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
       __syncthreads();
       SSTAMP(4);
       if (SENT) alive = ok_flag != 0;
+      if (LATE && have_prev && wave >= 2) offchain(trow_prev, r0_prev);
       f32x4 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1020,9 +1271,31 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int r = 0; r < 4; ++r) zt[wave][g][(lane >> 4) * 4 + r][lane & 15] = acc[g][r];
+      // next (step, row block) this workgroup visits
+      int ni = i + 1, nt = t;
+      if (ni >= MAXRB || rg + ni * n_rg >= n_rb) { ni = 0; nt = t + 1; }
+      const int nr0 = (rg + ni * n_rg) * 16;
+      if (MAXRB > 1 && !P && nt < T) {   // its table row ids (scalar loads; their wait hides among the waves arriving at the barrier)
+        const long nsrc = (long)min(nr0 + er, B - 1) * T + nt;
+        id_cur = sload_i32(a.idx + nsrc);
+        if (a.n_ctx > 0) c0_cur = sload_i32(a.ctx + nsrc * a.n_ctx);
+      }
       SSTAMP(5);
       __syncthreads();
       SSTAMP(6);
+      if (PREF) {
+        // the gate-input loads are waited for here (issued two phases ago), on every path: a wait further
+        // down would also wait for the DMA (vmcnt is in order)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(za[g]), "+v"(zb[g]));
+        asm volatile("" : "+v"(mk));
+        SSTAMP(11);
+        pf_issued = 0;
+        if (pref_ok && alive && nt < T && wave < KSTEPS) {
+          glds16_sc1(rs_h, (unsigned)((((long)nt * B + nr0 + (lane & 15)) * W + wave * 32 + kq) * 2), lds_a + wave * 1024);
+          pf_issued = 1;
+        }
+      }
       const int wz = (eu >> 4) * 4, ue = eu & 15;
       float z[4];
 #pragma unroll
@@ -1052,6 +1325,10 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
       __syncthreads();
       SSTAMP(8);
       const unsigned trow = (unsigned)(t * B + r0);      // first time-major row of this tile (uniform)
+      // (lane offsets of the stores are re-derived every step from an opaque copy of the thread id:
+      // hoisted out of the loop as invariants they were spilled to scratch at the 128-register cap)
+      int stid = tid;
+      if (MAXRB > 1) asm volatile("" : "+v"(stid));
       if (wave < 2) {
         // publish h[t]: two waves, one 16-byte write-through store per lane
         if (!SENT && MAXRB > 1 && pend >= 0) {
@@ -1060,10 +1337,12 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           signal_wave(cnt_own + pend, lane);
         }
-        const int prow = tid >> 3, seg = tid & 7;
+        const int prow = stid >> 3, seg = stid & 7;
         if (alive && r0 + prow < B) {
           const uint4 v = *reinterpret_cast<const uint4*>(pub + prow * 64 + seg * 8);
-          store16_sc1(rs_h, (unsigned)((prow * W + seg * 8) * 2) + ((trow + B) * W + u0) * 2u, v);
+          const unsigned off = (unsigned)((prow * W + seg * 8) * 2) + ((trow + B) * W + u0) * 2u;
+          if (SENT && local) store16(rs_h, off, 0u, v);        // stays in this XCD's L2, where all its readers are
+          else store16_sc1(rs_h, off, v);
         }
         if (SENT) {
           // the data is its own signal: nothing to drain, nothing to count
@@ -1075,43 +1354,18 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
           signal_wave(cnt_own + (long)rb * T + t, lane);
         }
         SSTAMP(10);
-      } else if (alive) {
-        // off the hand-off chain (buffer stores: lane offset + scalar step offset; a null buffer has
-        // zero records and drops the store)
-        const int q = tid - 128;
-        if (q < 512) {                       // gate activations: [gate][row] x 8 pieces of 8 units
-          const int g = q >> 7, prow = (q >> 3) & 15, seg = q & 7;
-          if (r0 + prow < B)
-            store16(rs_g, (unsigned)((prow * 4 * W + g * W + seg * 8) * 2), (trow * 4 * W + u0) * 2u,
-                    *reinterpret_cast<const uint4*>(st_g + (g * 16 + prow) * 64 + seg * 8));
-        } else if (q < 768) {                // cell state: [row] x 16 pieces of 4 units
-          const int prow = (q - 512) >> 4, seg = q & 15;
-          if (r0 + prow < B)
-            store16(rs_c, (unsigned)((prow * W + seg * 4) * 4), ((trow + B) * W + u0) * 4u,
-                    *reinterpret_cast<const uint4*>(st_c + prow * 64 + seg * 4));
-        } else {                             // masked outputs: [row] x 8 pieces of 8 units
-          const int prow = (q - 768) >> 3, seg = q & 7;
-          if (r0 + prow < B)
-            store16(rs_hd, (unsigned)((prow * W + seg * 8) * 2), (trow * W + u0) * 2u,
-                    *reinterpret_cast<const uint4*>(st_hd + prow * 64 + seg * 8));
-        }
-        if (q < 256) {   // transposed copies: 64 units x 16 rows, two 16-byte stores per unit (x2 buffers)
-          const int which = q >> 7, unit = (q >> 1) & 63, half = q & 1;
-          if (r0 + half * 8 < B) {
-            const uint4 v = *reinterpret_cast<const uint4*>(tr + (which * 64 + unit) * 16 + half * 8);
-            if (which) store16(rs_hdt, (unsigned)(((long)(u0 + unit) * a.ldt_d + half * 8) * 2), trow * 2u, v);
-            else store16(rs_ht, (unsigned)(((long)(u0 + unit) * a.ldt + half * 8) * 2), (trow + B) * 2u, v);
-          }
-        }
+      } else if (!LATE && alive) {
+        offchain(trow, r0);
       }
-      if (!P) {   // ids of the next (step, row block) this workgroup visits
-        int ni = i + 1, nt = t;
-        if (ni >= MAXRB || rg + ni * n_rg >= n_rb) { ni = 0; nt = t + 1; }
-        if (nt < T) {
-          const long nsrc = (long)min((rg + ni * n_rg) * 16 + er, B - 1) * T + nt;
-          id_cur = sload_i32(a.idx + nsrc);
-          if (a.n_ctx > 0) c0_cur = sload_i32(a.ctx + nsrc * a.n_ctx);
-        }
+      if (LATE) {
+        trow_prev = trow;
+        r0_prev = r0;
+        have_prev = alive;
+      }
+      if (MAXRB == 1 && !P && nt < T) {   // one block per workgroup: the ids of the next step, behind the stores
+        const long nsrc = (long)min(nr0 + er, B - 1) * T + nt;
+        id_cur = sload_i32(a.idx + nsrc);
+        if (a.n_ctx > 0) c0_cur = sload_i32(a.ctx + nsrc * a.n_ctx);
       }
     }
   }
@@ -1119,6 +1373,8 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     signal_wave(cnt_own + pend, lane);
   }
+  if (LATE && have_prev && wave >= 2) offchain(trow_prev, r0_prev);     // the last block's
+  SSTAMP_FLUSH();
 }
 
 // Compute units of the current device (256 on MI355X).  The scans are sized for co-residency of
@@ -1228,6 +1484,15 @@ bool kl_scan_bwd_wide_applicable(int B, int T, int W) {
   return (long)T * B * 4 * W * 2 <= 0xffffffffL;      // unsigned 32-bit buffer offsets
 }
 
+// row blocks each workgroup of a wide scan serves per step (both wide scans use the same grid plan)
+int kl_scan_wide_blocks_per_wg(int B, int W) {
+  const int n_rb = (B + 15) / 16, col_groups = W / 64;
+  int g = col_groups > 0 ? scan_cus() / col_groups : 0;
+  if (g < 1) return 0;
+  if (g > n_rb) g = n_rb;
+  return (n_rb + g - 1) / g;
+}
+
 int kl_launch_scan_bwd_wide(KlScanBwd a, hipStream_t stream) {
   const int W = a.W;
   if (a.L != 1 || !kl_scan_bwd_wide_applicable(a.B, a.T, W)) return KL_ERR_SHAPE;
@@ -1239,16 +1504,22 @@ int kl_launch_scan_bwd_wide(KlScanBwd a, hipStream_t stream) {
   a.n_rg = g;
   const int per_wg = (a.n_rb + g - 1) / g;
   if (per_wg > 4) return KL_ERR_SHAPE;
-  dim3 grid(col_groups * g), block(1024);
+  dim3 grid(8 * col_groups * ((g + 7) / 8)), block(1024);     // 8 XCDs x column groups x row groups per XCD (surplus ones exit)
   const size_t lds = (size_t)KL_BWD_WIDE_LDS(W / 32) + (per_wg > 1 ? 4 : 0) * 1024 * sizeof(float);
-#define KL_WIDE_CASE(KS, RB)                                                                                         \
+#define KL_WIDE_CASE2(KS, RB, S)                                                                                     \
   do {                                                                                                               \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_bwd_wide_kernel<KS, RB>),                     \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_bwd_wide_kernel<KS, RB, S>),                  \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH; \
-    hipLaunchKernelGGL((lstm_scan_bwd_wide_kernel<KS, RB>), grid, block, lds, stream, a);                            \
+    hipLaunchKernelGGL((lstm_scan_bwd_wide_kernel<KS, RB, S>), grid, block, lds, stream, a);                         \
+  } while (0)
+#define KL_WIDE_CASE(KS, RB)                          \
+  do {                                                \
+    if (a.sentinel) KL_WIDE_CASE2(KS, RB, true);      \
+    else KL_WIDE_CASE2(KS, RB, false);                \
   } while (0)
   if (W == 512) { if (per_wg == 1) KL_WIDE_CASE(16, 1); else if (per_wg == 2) KL_WIDE_CASE(16, 2); else KL_WIDE_CASE(16, 4); }
   else { if (per_wg == 1) KL_WIDE_CASE(8, 1); else if (per_wg == 2) KL_WIDE_CASE(8, 2); else KL_WIDE_CASE(8, 4); }
+#undef KL_WIDE_CASE2
 #undef KL_WIDE_CASE
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
@@ -1278,7 +1549,7 @@ int kl_launch_scan_fwd_wide(KlScanFwdWide a, hipStream_t stream) {
   a.n_rg = g;
   const int per_wg = (a.n_rb + g - 1) / g;
   if (per_wg > 4) return KL_ERR_SHAPE;
-  dim3 grid(col_groups * g), block(1024);
+  dim3 grid(8 * col_groups * ((g + 7) / 8)), block(1024);     // 8 XCDs x column groups x row groups per XCD (surplus ones exit)
   const size_t lds = (size_t)KL_FWD_WIDE_LDS(W / 32) + (per_wg > 1 ? 4 : 0) * 1024 * sizeof(float);
   if ((long)a.T * a.B * 4 * W * 2 > 0xffffffffL) return KL_ERR_SHAPE;   // unsigned 32-bit buffer offsets (the gate rows are the largest)
 #define KL_WIDE_CASE2(KS, RB, S)                                                                                     \

@@ -217,7 +217,11 @@ def test_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks):
                                                                  (3, 256, 30, 176, 5, 1, True), (1, 256, 40, 8, 9, 1, False),
                                                                  (2, 256, 40, 272, 4, 1, False),
                                                                  # the shape class that takes this path by default
-                                                                 (2, 512, 64, 512, 4, 1, True)])
+                                                                 (2, 512, 64, 512, 4, 1, True),
+                                                                 # several row blocks per workgroup: sentinel backward, prefetched
+                                                                 # tiles, late stores (even and uneven visits; width 256)
+                                                                 (2, 512, 64, 1024, 3, 1, True), (2, 512, 64, 1040, 3, 1, True),
+                                                                 (2, 256, 40, 1056, 3, 1, True)])
 def test_train_window_wide_forward(monkeypatch, depth, width, voc, B, T, n_ctx, use_masks):
     """Layer-sequential forward with 64-unit workgroups (table look-ups fused into the
     layer-0 scan, transposed outputs written by the scans): forced on for small shapes."""
@@ -326,8 +330,15 @@ def test_train_consecutive_windows_reuse_buffers(depth, width, voc, B, T):
         st = [got_st[:, k].astype(np.float64) for k in range(2 * depth)]
 
 
-@pytest.mark.parametrize("B,windows", [(512, 10), (1024, 4), (264, 6)])
-def test_handoff_flavours_agree_bitwise(B, windows):
+@pytest.mark.parametrize("B,windows,env", [
+    (512, 10, {}), (1024, 4, {}), (264, 6, {}),
+    (2048, 2, {}),                                       # four row blocks per workgroup: prefetched tiles, late stores
+    (1040, 2, {}),                                       # 65 row blocks on 32 row groups: uneven visits
+    (1032, 2, {}),                                       # a partial last tile: no prefetch
+    (512, 4, {"KL_SENTINEL_BWD": "2"}),                  # sentinel backward with ONE block per workgroup (probe-first spin)
+    (1024, 3, {"KL_XCD_LOCAL": "1", "KL_XCD_LOCAL_BWD": "1"}),   # XCD-local publishes (plain stores into the shared L2)
+    (528, 3, {"KL_XCD_LOCAL": "1", "KL_SENTINEL_BWD": "2", "KL_XCD_LOCAL_BWD": "1"})])   # ... with surplus workgroups exiting
+def test_handoff_flavours_agree_bitwise(B, windows, env):
     """The scans' two hand-off protocols (data sentinels / counters) run the same arithmetic, so over
     consecutive stateful windows the carried states must agree BITWISE -- a stale or torn read in either
     protocol would show as a difference -- and the launch-per-step path must agree to bf16 accuracy
@@ -338,7 +349,7 @@ def test_handoff_flavours_agree_bitwise(B, windows):
         "check_handoff", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_handoff.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    bad, g, c = mod.run(B, windows, verbose=False)
+    bad, g, c = mod.run(B, windows, verbose=False, env_a=env)
     assert bad == 0
     assert g < 1e-3 and c < 5e-2, (g, c)
 

@@ -4,7 +4,7 @@ by the launch-per-step path (KL_SCAN=0).  The forward recurrence has no atomics,
 the two scan engines must agree BITWISE after every window; the step path (different summation order)
 must agree to bf16 accuracy.  Gradients are compared too (split-K atomics: to 1e-3 of their max-norm).
 
-  python tools/check_handoff.py [B] [windows]"""
+  python tools/check_handoff.py [B] [windows] [KEY=VALUE ...]   (switches of the sentinel engine)"""
 import os
 import sys
 
@@ -34,9 +34,10 @@ def engine(B, env):
     return lm
 
 
-def run(B, N, verbose=True):
-    """returns (mismatches, max rel gradient difference, max abs state difference to the step path)"""
-    a = engine(B, {"KL_SENTINEL": "1"})
+def run(B, N, verbose=True, env_a=None):
+    """returns (mismatches, max rel gradient difference, max abs state difference to the step path);
+    env_a: further switches of the sentinel engine (KL_SENTINEL_BWD=2, KL_XCD_LOCAL=1, ...)"""
+    a = engine(B, dict({"KL_SENTINEL": "1"}, **(env_a or {})))
     b = engine(B, {"KL_SENTINEL": "0"})
     c = engine(B, {"KL_SCAN": "0"})
     rng = np.random.default_rng(0)
@@ -83,5 +84,5 @@ def run(B, N, verbose=True):
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-    bad, g, c = run(B, N)
+    bad, g, c = run(B, N, env_a=dict(kv.split("=", 1) for kv in sys.argv[3:]))
     sys.exit(1 if bad or g > 1e-3 or c > 5e-2 else 0)

@@ -1,4 +1,4 @@
-import sys, time, numpy as np, torch
+import os, sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 from ocrd_keraslm_amd.lib import hipabi
 from ocrd_keraslm_amd.lib.engine import HipLM
@@ -14,9 +14,9 @@ masks=torch.from_numpy(lm.draw_dropout_masks(B)).cuda()
 lm.reset_states(B)
 def step():
     lm.train_window(idx,ctx,tgt,masks); lm.adam_step()
-for _ in range(3): step()
+for _ in range(int(os.environ.get('KL_PROBE_WARM', '3'))): step()
 torch.cuda.synchronize()
-t=time.time(); n=10
+t=time.time(); n=int(os.environ.get('KL_PROBE_N', '10'))
 for _ in range(n): step()
 torch.cuda.synchronize()
 dt=(time.time()-t)/n

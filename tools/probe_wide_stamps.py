@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, '.')
 from ocrd_keraslm_amd.lib import hipabi
-hipabi.LIB_PATH = os.path.join(os.path.dirname(hipabi.LIB_PATH), 'libkeraslm_hip_stamps.so')
+hipabi.LIB_PATH = os.path.join(os.path.dirname(hipabi.LIB_PATH), os.environ.get('KL_STAMPS_LIB', 'libkeraslm_hip_stamps.so'))
 from ocrd_keraslm_amd.lib.engine import HipLM
 
 lib = hipabi.load()
@@ -38,7 +38,11 @@ names = ['loop top (zin loads)', 'poll', 'barrier1', 'tile load+LDS write', 'bar
 print(f"B={B}: wide forward scan, cycles (100 MHz clock64 ticks) per step of workgroup 0; total {v.sum():.0f}")
 for nm, x in zip(names, v):
     print(f"  {nm:24s} {x:8.1f}")
+print(f"  (wait for the gate inputs after barrier3: {st[11] / per:.1f}, taken out of 'gate math')")
+print(f"  prefetches that came too early: {st[12] / per:.3f} per block")
 vb = np.array(list(st)[16:27], dtype=np.float64) / per
 print(f"B={B}: wide backward scan; total {vb.sum():.0f}")
 for nm, x in zip(names, vb):
     print(f"  {nm:24s} {x:8.1f}")
+print(f"  (wait for the epilogue inputs after barrier3: {st[27] / per:.1f}, taken out of 'gate math')")
+print(f"  prefetches that came too early: {st[28] / per:.3f} per block")
