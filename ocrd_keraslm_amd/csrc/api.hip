@@ -105,6 +105,7 @@ struct kl_handle {
   bool inc_ready = false;       // the big-n incremental operands match the current weights
   int last_only = 0;            // stateless windows: one target per row, at the last position (kl_set_window_mode)
   bool sentinel = true;         // wide scans hand off by data sentinels instead of counters (KL_SENTINEL=0: counters)
+  bool gemm_an = true;          // weight gradients read the backward scan's dZ K-major, no transposed copy (KL_GEMM_AN=0: dZ^T)
   bool xcd_local = false;       // KL_XCD_LOCAL=1: sentinel hand-off inside one XCD through its L2 (plain stores) where the placement allows
   bool sentinel_bwd = true;
   bool sentinel_bwd_all = false; // KL_SENTINEL_BWD=2: also with one row block per workgroup
@@ -654,6 +655,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->wide_bwd = !(env4 && env4[0] == '0');
   const char* env7 = getenv("KL_SENTINEL");
   h->sentinel = !(env7 && env7[0] == '0');
+  const char* env7e = getenv("KL_GEMM_AN");
+  h->gemm_an = !(env7e && env7e[0] == '0');
   const char* env7c = getenv("KL_XCD_LOCAL");
   h->xcd_local = env7c && env7c[0] == '1';
   const char* env7b = getenv("KL_SENTINEL_BWD");
@@ -755,10 +758,14 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   // launch-per-step layer wavefront
   std::vector<char> wg_done(L, 0);
   // B4/B5: weight gradients of one layer, K = B*T contractions over transposed activations
-  auto weight_grads = [&](int l, bool dzt_ready, bool db_done) -> int {
-    if (!dzt_ready) KL_TRY(kl_launch_transpose_bf16(w.dZ[l], 4 * W, w.dZT, BTp, BT, 4 * W, s));
+  // dz_km: the contractions over the T*B rows read dZ K-major as the scan wrote it (kl_launch_gemm_an, the
+  // hardware transpose read) -- no transposed copy dZT at all; needs the transposed activations (ht_ready)
+  auto weight_grads = [&](int l, bool dzt_ready, bool db_done, bool dz_km) -> int {
+    if (!dzt_ready && !dz_km) KL_TRY(kl_launch_transpose_bf16(w.dZ[l], 4 * W, w.dZT, BTp, BT, 4 * W, s));
     // dU_l = Hprev^T . dZ   (Hprev = H blocks 0..T-1)
-    if (w.ht_ready) {
+    if (dz_km) {
+      KL_TRY(kl_launch_gemm_an(w.dZ[l], w.HTf[l], grads + h->off_U[l], 4 * W, W, BT, 4 * W, ldtf, 4 * W, 1, s));
+    } else if (w.ht_ready) {
       KL_TRY(kl_launch_gemm_tn(w.HTf[l], w.dZT, grads + h->off_U[l], nullptr, W, 4 * W, BT, ldtf, BTp, 4 * W, 2, ksplit, 1.f, s));
     } else {
       KL_TRY(kl_launch_transpose_bf16((const bf16_t*)w.H[l], W, w.HT, BTp, BT, W, s));
@@ -769,7 +776,10 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       // dK_l = X^T . dZ with X = (masked) outputs of layer l-1
       const bool masked_in = masks != nullptr && (l - 1) > 0;
       const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
-      if (w.ht_ready) {
+      if (dz_km) {
+        const bf16_t* XT = masked_in ? w.HdT[l - 1] : w.HTf[l - 1] + B;
+        KL_TRY(kl_launch_gemm_an(w.dZ[l], XT, grads + h->off_K[l], 4 * W, W, BT, 4 * W, masked_in ? (long)BT : ldtf, 4 * W, 1, s));
+      } else if (w.ht_ready) {
         const bf16_t* XT = masked_in ? w.HdT[l - 1] : w.HTf[l - 1] + B;
         KL_TRY(kl_launch_gemm_tn(XT, w.dZT, grads + h->off_K[l], nullptr, W, 4 * W, BT, masked_in ? (long)BT : ldtf, BTp, 4 * W, 2, ksplit, 1.f, s));
       } else {
@@ -781,7 +791,8 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       KL_TRY(kl_zero_async(w.OHT, (size_t)Vp * BTp * sizeof(bf16_t), s));
       KL_TRY(kl_launch_onehot_t(idx, B, T, V, 0, 1, w.OHT, BTp, s));
       KL_TRY(kl_zero_async(w.dEKT, (size_t)4 * W * Vp * sizeof(float), s));
-      KL_TRY(kl_launch_gemm_tn(w.dZT, w.OHT, w.dEKT, nullptr, 4 * W, Vp, BTp, BTp, BTp, Vp, 2, ksplit, 1.f, s));
+      if (dz_km) KL_TRY(kl_launch_gemm_an(w.dZ[l], w.OHT, w.dEKT, 4 * W, Vp, BT, 4 * W, BTp, Vp, 0, s));
+      else KL_TRY(kl_launch_gemm_tn(w.dZT, w.OHT, w.dEKT, nullptr, 4 * W, Vp, BTp, BTp, BTp, Vp, 2, ksplit, 1.f, s));
       KL_TRY(kl_launch_f32_to_bf16_t(w.dEKT, Vp, 4 * W, Vp, w.dEKT_bf, nullptr, Vp, 0, s));
       KL_TRY(kl_launch_f32_to_bf16_t(w.dEKT, Vp, 4 * W, Vp, w.dEK_bf, nullptr, 4 * W, 1, s));
       // dK0[:W] = E^T . dEK      (C[W][4W] = ET[W][Vp] . dEKT[4W][Vp]^T)
@@ -792,8 +803,9 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
         KL_TRY(kl_zero_async(w.OHC[n], (size_t)c.ctx_vocab * BTp * sizeof(bf16_t), s));
         KL_TRY(kl_launch_onehot_t(ctx, B, T, c.ctx_vocab, n, c.n_ctx, w.OHC[n], BTp, s));
         KL_TRY(kl_zero_async(w.dCtxKT[n], (size_t)4 * W * c.ctx_vocab * sizeof(float), s));
-        KL_TRY(kl_launch_gemm_tn(w.dZT, w.OHC[n], w.dCtxKT[n], nullptr, 4 * W, c.ctx_vocab, BTp, BTp, BTp,
-                                 c.ctx_vocab, 2, ksplit, 1.f, s));
+        if (dz_km) KL_TRY(kl_launch_gemm_an(w.dZ[l], w.OHC[n], w.dCtxKT[n], 4 * W, c.ctx_vocab, BT, 4 * W, BTp, c.ctx_vocab, 0, s));
+        else KL_TRY(kl_launch_gemm_tn(w.dZT, w.OHC[n], w.dCtxKT[n], nullptr, 4 * W, c.ctx_vocab, BTp, BTp, BTp,
+                                      c.ctx_vocab, 2, ksplit, 1.f, s));
         const size_t krow = (size_t)(W + n * c.ctx_dim) * 4 * W;
         KL_TRY(kl_launch_ctx_grads(P + h->off_Ctx[n], P + h->off_K[0] + krow, 4 * W, c.ctx_vocab, c.ctx_dim,
                                    w.dCtxKT[n], c.ctx_vocab, 4 * W, grads + h->off_K[0] + krow, 4 * W,
@@ -838,8 +850,10 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       else
         KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)n_rb_all * T, s));
       if (l == L - 1) h->trace_begin(1, s);
-      // wide (64-unit) workgroups share the dZ tile through LDS and write dZ^T themselves
-      a.dZT = (BTp == BT && (B & 7) == 0) ? w.dZT : nullptr;
+      // wide (64-unit) workgroups share the dZ tile through LDS; the weight-gradient GEMMs read dZ K-major
+      // as it is (dz_km), else the scan also writes dZ^T
+      const bool dz_km = h->gemm_an && wide_fits && w.ht_ready && kl_gemm_an_applicable(4 * W, W, BT, 4 * W) && BTp == BT;
+      a.dZT = (!dz_km && BTp == BT && (B & 7) == 0) ? w.dZT : nullptr;
       a.ldt = BTp;
       a.db = grads + h->off_b[l];
       int e = h->wide_bwd ? kl_launch_scan_bwd_wide(a, s) : KL_ERR_SHAPE;
@@ -858,7 +872,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
         h->trace_end(1, s);
       }
       // dZ^T lives in ONE buffer: this layer's weight gradients before the next layer's scan
-      KL_TRY(weight_grads(l, wide && a.dZT != nullptr, wide));
+      KL_TRY(weight_grads(l, wide && a.dZT != nullptr, wide, wide && dz_km));
       wg_done[l] = 1;
     }
     bscanned = true;
@@ -937,7 +951,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   }
 
   for (int l = L - 1; l >= 0; --l)
-    if (!wg_done[l]) KL_TRY(weight_grads(l, false, false));
+    if (!wg_done[l]) KL_TRY(weight_grads(l, false, false, false));
 
   // F7: embedding regularisers (training phase only)
   std::vector<const float*> ctabs(c.n_ctx);
@@ -1112,6 +1126,11 @@ int kl_state_dist2(const kl_handle* h, int n, const float* pool, const int32_t* 
 int kl_test_gemm_tn(const uint16_t* A, const uint16_t* B, void* C, const float* bias, int M, int N, int K, long lda,
                     long ldb, long ldc, int out_mode, int splits, void* stream) {
   return kl_launch_gemm_tn(A, B, C, bias, M, N, K, lda, ldb, ldc, out_mode, splits, 1.f, (hipStream_t)stream);
+}
+
+int kl_test_gemm_an(const uint16_t* A_km, const uint16_t* B, float* C, int M, int N, int K, long lda_km, long ldb,
+                    long ldc, int c_transposed, void* stream) {
+  return kl_launch_gemm_an(A_km, B, C, M, N, K, lda_km, ldb, ldc, c_transposed, (hipStream_t)stream);
 }
 
 int kl_test_thin_gemm(const float* A, long lda, const uint16_t* WT_hi, const uint16_t* WT_lo, long ldw, int M, int N,

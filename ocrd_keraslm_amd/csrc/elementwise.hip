@@ -154,6 +154,82 @@ __global__ void softmax_ce_kernel(float* __restrict__ logits, long ld, int rows,
   }
 }
 
+// The same for V <= 256 with V, ld and ld_dl multiples of 4 (the usual character vocabularies): a lane
+// keeps its four logits in registers -- ONE pass over the row (16-byte loads), one exponential per
+// element, 8-byte stores of the bf16 gradient row -- instead of four strided passes.
+__global__ void softmax_ce_v256_kernel(float* __restrict__ logits, long ld, int rows, int V, const int* __restrict__ tgt,
+                                       int B, int T, float inv_count, bf16_t* __restrict__ dlogits, long ld_dl,
+                                       float* __restrict__ rowstat, int time_major, int last_only) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* x = logits + (long)row * ld;
+  const int v0 = lane * 4;
+  const bool in = v0 < V;
+  float4 a = in ? *reinterpret_cast<const float4*>(x + v0) : float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  float e[4] = {a.x, a.y, a.z, a.w};
+  float mx = e[0];
+  int amax = v0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    if (e[k] > mx) { mx = e[k]; amax = v0 + k; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(mx, off);
+    const int oi = __shfl_xor(amax, off);
+    if (o > mx || (o == mx && oi < amax)) { mx = o; amax = oi; }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    e[k] = in ? expf(e[k] - mx) : 0.f;
+    sum += e[k];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  const float inv = 1.f / sum;
+  int t = -2;
+  bool counts = true;
+  if (tgt) {
+    const int b = time_major ? row % B : row / T;
+    const int tt = time_major ? row / B : row % T;
+    t = tgt[(long)b * T + tt];
+    if (last_only && tt != T - 1) { t = -1; counts = false; }
+  }
+  float pt = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    e[k] *= inv;
+    if (v0 + k == t) pt = e[k];
+  }
+  if (dlogits == nullptr && in) *reinterpret_cast<float4*>(x + v0) = float4{e[0], e[1], e[2], e[3]};
+  if (!tgt) return;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) pt += __shfl_xor(pt, off);
+  const bool valid = t >= 0;
+  const bool active = valid && pt >= 1e-7f && pt <= 1.f - 1e-7f;
+  if (dlogits && v0 < ld_dl) {      // pad columns [V, ld_dl) are written as zeros
+    unsigned short g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gk = (active && in) ? e[k] : 0.f;
+      if (active && v0 + k == t) gk -= 1.f;
+      g[k] = f2bf(gk * inv_count);
+    }
+    *reinterpret_cast<uint2*>(dlogits + (long)row * ld_dl + v0) = uint2{(unsigned)g[0] | ((unsigned)g[1] << 16), (unsigned)g[2] | ((unsigned)g[3] << 16)};
+  }
+  if (lane == 0 && rowstat) {
+    float l = 0.f;
+    if (valid) {
+      const float pc = fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f);
+      l = -logf(pc) * inv_count;
+    }
+    const int tsafe = valid ? t : 0;
+    rowstat[2 * (long)row] = l;
+    rowstat[2 * (long)row + 1] = (counts && amax == tsafe) ? inv_count : 0.f;
+  }
+}
+
 // sum of the per-row (loss, hit) pairs -> loss_acc[0], loss_acc[1]; a few blocks, one atomic pair each
 __global__ void rowstat_reduce_kernel(const float* __restrict__ rowstat, int rows, float* __restrict__ loss_acc) {
   __shared__ float red[2][256];
@@ -359,8 +435,13 @@ int kl_launch_softmax_ce(float* logits, long ld, int rows, int V, const int* tgt
                          hipStream_t stream, int last_only) {
   dim3 grid((rows + 3) / 4);
   const bool stats = tgt != nullptr && loss_acc != nullptr && rowstat != nullptr;
-  hipLaunchKernelGGL(softmax_ce_kernel, grid, dim3(256), 0, stream, logits, ld, rows, V, tgt, B, T, inv_count,
-                     dlogits, ld_dl, stats ? rowstat : nullptr, time_major, last_only);
+  const bool one_pass = V <= 256 && (V & 3) == 0 && (ld & 3) == 0 && (!dlogits || ((ld_dl & 3) == 0 && ld_dl <= 256));
+  if (one_pass)
+    hipLaunchKernelGGL(softmax_ce_v256_kernel, grid, dim3(256), 0, stream, logits, ld, rows, V, tgt, B, T, inv_count,
+                       dlogits, ld_dl, stats ? rowstat : nullptr, time_major, last_only);
+  else
+    hipLaunchKernelGGL(softmax_ce_kernel, grid, dim3(256), 0, stream, logits, ld, rows, V, tgt, B, T, inv_count,
+                       dlogits, ld_dl, stats ? rowstat : nullptr, time_major, last_only);
   if (stats) {
     int nb = (rows + 4095) / 4096;
     if (nb > 64) nb = 64;

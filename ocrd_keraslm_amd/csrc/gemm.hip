@@ -195,11 +195,21 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 // tile for big grids; (2, 2, 4) a 64 x 128 tile of 8 waves (72 KiB) for M ~ 1e3 shapes (the
 // incremental step's GEMMs), where 256-row tiles would leave 3/4 of the CUs idle and two waves
 // per SIMD are needed to hide the ds_read -> MFMA latency of the short k-loop.
-template <int OUT, bool ILV, int RF, int WM, int WN>
+//
+// ATR: the A operand is given K-major, A[k][m] with row stride lda (the backward scan's dZ rows as they
+// are: no transposed copy).  Its stage is the [64 k][256 m] image the DMA lays down (512-byte rows,
+// chunks XOR-swizzled at the source) and the fragments come from two ds_read_b64_tr_b16 each -- the
+// hardware transpose read: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4 x 16
+// block and lane i receives column i (cdna_hip_programming.md T10).  c_t (OUT == 2): accumulate C^T.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <int OUT, bool ILV, int RF, int WM, int WN, bool ATR = false>
 __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, int M, int N, int K, long lda, long ldb, long ldc,
-    int k_per_split, float alpha, const KlGateEpi epi, int xcd_remap) {
+    int k_per_split, float alpha, const KlGateEpi epi, int xcd_remap, int c_t) {
+  static_assert(!ATR || (RF == 4 && WM == 4 && WN == 2), "K-major A: 256-row tiles only");
   constexpr bool PRIO = KL_GEMM_PRIO;
   constexpr int NW = WM * WN;
   constexpr int WROWS = 16 * RF;               // rows per wave
@@ -240,14 +250,22 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
 
   // buffer resources based at this workgroup's first rows; rows past the matrix read as zero
   auto clamp31 = [](long v) { return (int)(v > 0x7fffffffL ? 0x7fffffffL : (v < 0 ? 0 : v)); };
-  const __amdgpu_buffer_rsrc_t rsA =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A + (long)m0 * lda), 0, clamp31(((long)(M - m0 - 1) * lda + K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA = ATR
+      ? __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A + (long)kbeg * lda + m0), 0, clamp31(((long)(kend - kbeg - 1) * lda + (M - m0)) * 2), 0x00020000)
+      : __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A + (long)m0 * lda), 0, clamp31(((long)(M - m0 - 1) * lda + K) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B + (long)n0 * ldb), 0, clamp31(((long)(N - n0 - 1) * ldb + K) * 2), 0x00020000);
   // per-lane source offsets of this wave's pieces (rows wave*8*P + j*8 + (lane>>3)), swizzled chunk
   unsigned vo[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
+    if (ATR && j < PA) {
+      // piece p = two k-rows of 512 bytes: lanes 0..31 row 2p, lanes 32..63 row 2p + 1
+      const int krow = 2 * (wave * PA + j) + (lane >> 5);
+      const int c = (lane & 31) ^ (2 * ((krow & 3) | (((krow >> 3) & 1) << 2)));
+      vo[j] = (unsigned)((long)krow * lda * 2 + c * 16);
+      continue;
+    }
     const int row = j < PA ? wave * 8 * PA + j * 8 + (lane >> 3) : wave * 8 * PB + (j - PA) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     vo[j] = (unsigned)((long)row * (j < PA ? lda : ldb) * 2 + c * 16);
@@ -256,11 +274,12 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
   // the pieces are issued in two halves between the two MFMA groups of a k-step
   auto issue_half = [&](int kt, int stage, int half) {
     const int soff = (kbeg + kt * BK) * 2;
+    const int soff_a = ATR ? (int)((long)kt * BK * lda * 2) : soff;     // (K-major A: based at kbeg already)
     const unsigned sa = lds0 + stage * STAGE_BYTES + wave * 8 * PA * 128;
     const unsigned sb = lds0 + stage * STAGE_BYTES + TBM * 128 + wave * 8 * PB * 128;
 #pragma unroll
     for (int j = half ? NP0 : 0; j < (half ? NP : NP0); ++j) {
-      if (j < PA) glds16(rsA, vo[j], soff, sa + j * 1024);
+      if (j < PA) glds16(rsA, vo[j], soff_a, sa + j * 1024);
       else glds16(rsB, vo[j], soff, sb + (j - PA) * 1024);
     }
   };
@@ -278,6 +297,16 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
   if (nkt > 0) issue(0, 0);
   if (nkt > 1) issue(1, 1);
   const int fr = lane & 15, fq = lane >> 4;
+  // K-major A: this lane's part of the transposed-read addresses, one per row fragment (the swizzle
+  // term is a lane constant: k-rows s*32 + fq*8 + half*4 + q have (krow & 3) = q, bit 3 = fq & 1)
+  unsigned atr_off[RF];
+  if (ATR) {
+    const int q = fr >> 2, pp = fr & 3;
+    const int fl = 2 * (q | ((fq & 1) << 2));
+#pragma unroll
+    for (int i = 0; i < RF; ++i)
+      atr_off[i] = (unsigned)((fq * 8 + q) * 512 + ((((wm * WROWS + i * 16) >> 3) ^ fl) + (pp >> 1)) * 16 + 8 * (pp & 1));
+  }
   int stage = 0;
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
@@ -292,8 +321,17 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
     for (int s = 0; s < 2; ++s) {
       frag16 fa[RF], fb[NT];
 #pragma unroll
-      for (int i = 0; i < RF; ++i)
-        fa[i].u = *reinterpret_cast<const uint4*>(a_base + lds_off(wm * WROWS + i * 16 + fr, s * 4 + fq));
+      for (int i = 0; i < RF; ++i) {
+        if (ATR) {
+          const unsigned char* ap = a_base + atr_off[i] + s * 32 * 512;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + 4 * 512));
+          fa[i].s[0] = (bf16_t)lo.x; fa[i].s[1] = (bf16_t)lo.y; fa[i].s[2] = (bf16_t)lo.z; fa[i].s[3] = (bf16_t)lo.w;
+          fa[i].s[4] = (bf16_t)hi.x; fa[i].s[5] = (bf16_t)hi.y; fa[i].s[6] = (bf16_t)hi.z; fa[i].s[7] = (bf16_t)hi.w;
+        } else {
+          fa[i].u = *reinterpret_cast<const uint4*>(a_base + lds_off(wm * WROWS + i * 16 + fr, s * 4 + fq));
+        }
+      }
 #pragma unroll
       for (int j = 0; j < NT; ++j)
         fb[j].u = *reinterpret_cast<const uint4*>(b_base + lds_off(wn * WCOLS + j * 16 + fr, s * 4 + fq));
@@ -418,7 +456,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
         } else if (OUT == 1) {
           reinterpret_cast<bf16_t*>(Cv)[(long)row * ldc + col] = f2bf(v);
         } else {
-          atomicAdd(reinterpret_cast<float*>(Cv) + (long)row * ldc + col, v);
+          if (c_t) atomicAdd(reinterpret_cast<float*>(Cv) + (long)col * ldc + row, v);
+          else atomicAdd(reinterpret_cast<float*>(Cv) + (long)row * ldc + col, v);
         }
       }
     }
@@ -446,9 +485,9 @@ int launch_long_t(int out_mode, dim3 grid, hipStream_t stream, const bf16_t* A, 
       attr_set = true;                                                                                                   \
     }                                                                                                                    \
     if (ilv) hipLaunchKernelGGL((gemm_tn_long_kernel<O, true, RF, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, A, B, C,  \
-                                bias, M, N, K, lda, ldb, ldc, k_per_split, alpha, epi, remap);                           \
+                                bias, M, N, K, lda, ldb, ldc, k_per_split, alpha, epi, remap, 0);                        \
     else hipLaunchKernelGGL((gemm_tn_long_kernel<O, false, RF, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, A, B, C,     \
-                            bias, M, N, K, lda, ldb, ldc, k_per_split, alpha, epi, remap);                               \
+                            bias, M, N, K, lda, ldb, ldc, k_per_split, alpha, epi, remap, 0);                            \
   } while (0)
   if (out_mode == 0) KL_LONG_CASE(0);
   else if (out_mode == 1) KL_LONG_CASE(1);
@@ -517,6 +556,50 @@ int kl_launch_gemm_tn(const bf16_t* A, const bf16_t* B, void* C, const float* bi
     dim3 grid(nbx, (M + 127) / 128, splits);
     launch_bm<128>(out_mode, grid, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, k_per_split, alpha);
   }
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+// C (+)= A^T-view . B^T for a K-major A: A_km [K][M] (row stride lda_km), B [N][K] (row stride ldb), both
+// bf16; C f32 accumulated with atomics over the K splits, as C[m][n] (c_transposed 0) or C[n][m] (1), row
+// stride ldc.  This is the weight-gradient contraction over the T*B rows taken straight from the backward
+// scan's row-major dZ.  KL_ERR_SHAPE = not applicable (the caller transposes and uses kl_launch_gemm_tn).
+// shapes kl_launch_gemm_an serves (N, ldb: any the tn kernel takes)
+bool kl_gemm_an_applicable(int M, int N, int K, long lda_km) {
+  if (M <= 0 || N <= 0 || K <= 0 || (M % LBM) || (K % BK) || (lda_km & 7)) return false;
+  const int tiles = (M / LBM) * ((N + LBN - 1) / LBN);
+  int sp = (256 + tiles - 1) / tiles;
+  const int nk = K / BK;
+  if (sp > nk / 16) sp = nk / 16;
+  if (sp < 1) sp = 1;
+  const int kps = ((nk + sp - 1) / sp) * BK;
+  return (long)kps * lda_km * 2 < 0x7fffffffL;
+}
+
+int kl_launch_gemm_an(const bf16_t* A_km, const bf16_t* B, float* C, int M, int N, int K, long lda_km, long ldb, long ldc,
+                      int c_transposed, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (!kl_gemm_an_applicable(M, N, K, lda_km) || (ldb & 7) || ldb >= (1L << 22)) return KL_ERR_SHAPE;
+  const int tiles = (M / LBM) * ((N + LBN - 1) / LBN);
+  int sp = (256 + tiles - 1) / tiles;          // ~ one workgroup per CU
+  const int nk = K / BK;
+  if (sp > nk / 16) sp = nk / 16;              // at least 16 k-steps per workgroup
+  if (sp < 1) sp = 1;
+  const int kps = ((nk + sp - 1) / sp) * BK;
+  sp = (K + kps - 1) / kps;
+  if ((long)kps * lda_km * 2 >= 0x7fffffffL) return KL_ERR_SHAPE;     // 32-bit offsets inside one split
+  dim3 grid((N + LBN - 1) / LBN, M / LBM, sp);
+  KlGateEpi epi;
+  memset(&epi, 0, sizeof(epi));
+  const size_t lds = (size_t)LSTAGES * (LBM + LBN) * 128;
+  static const int remap = !(getenv("KL_GEMM_XCD") && getenv("KL_GEMM_XCD")[0] == '0');
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<2, true, 4, 4, 2, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_tn_long_kernel<2, true, 4, 4, 2, true>), grid, dim3(512), lds, stream, A_km, B, (void*)C,
+                     (const float*)nullptr, M, N, K, lda_km, ldb, ldc, kps, 1.f, epi, remap, c_transposed);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 

@@ -32,6 +32,10 @@ int kl_launch_gemm_gates(const bf16_t* A3, const bf16_t* WTperm, int n, int W, i
 
 int kl_launch_gemm_tn(const bf16_t* A, const bf16_t* B, void* C, const float* bias, int M, int N, int K,
                       long lda, long ldb, long ldc, int out_mode, int splits, float alpha, hipStream_t stream);
+// the same contraction with a K-major A operand [K][M] (split-K, f32 atomics; optionally C^T): gemm.hip
+bool kl_gemm_an_applicable(int M, int N, int K, long lda_km);
+int kl_launch_gemm_an(const bf16_t* A_km, const bf16_t* B, float* C, int M, int N, int K, long lda_km, long ldb, long ldc,
+                      int c_transposed, hipStream_t stream);
 
 // ---- lstm_step.hip ------------------------------------------------------
 // One (activation, weight) operand pair of a thin fused step: rows of A are

@@ -76,6 +76,29 @@ def test_gemm_tn(M, N, K, out_mode, splits):
     assert np.abs(got - ref).max() <= tol * scale, (np.abs(got - ref).max(), scale)
 
 
+@pytest.mark.parametrize("M,N,K,lda,c_t", [(256, 128, 1024, 256, 0), (2048, 512, 16384, 2048, 1), (512, 200, 8256, 640, 0),
+                                           (1024, 256, 4096, 1024, 1), (256, 64, 64, 256, 0)])
+def test_gemm_an(M, N, K, lda, c_t):
+    """the weight-gradient contraction with the K-major A operand (rows of dZ as the backward scan writes
+    them, read with the hardware transpose): C (+)= A^T . B^T, optionally accumulated transposed"""
+    torch = _torch()
+    from ocrd_keraslm_amd.lib import hipabi
+    lib = hipabi.load()
+    rng = np.random.default_rng(M + 3 * N + K)
+    A = bf16_bits(rng.standard_normal((K, lda)).astype(np.float32) * (1 + np.arange(lda)[None, :] % 3))
+    B = bf16_bits(rng.standard_normal((N, K)).astype(np.float32) * (1 + np.arange(N)[:, None] % 5))
+    ref = bits_to_f32(A)[:, :M].astype(np.float64).T @ bits_to_f32(B).astype(np.float64).T
+    Ad, Bd = dev(A), dev(B)
+    Cd = torch.zeros((N, M) if c_t else (M, N), dtype=torch.float32, device="cuda")
+    hipabi.check(lib.kl_test_gemm_an(ptr(Ad), ptr(Bd), ptr(Cd), M, N, K, lda, K, M if c_t else N, c_t, None))
+    torch.cuda.synchronize()
+    got = Cd.cpu().numpy()
+    if c_t:
+        got = got.T
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 1e-5 * scale, (np.abs(got - ref).max(), scale)
+
+
 @pytest.mark.parametrize("M,N,K,split", [(5, 20, 64, 3), (33, 256, 512, 3), (256, 100, 128, 1), (64, 2048, 512, 3)])
 def test_thin_gemm(M, N, K, split):
     torch = _torch()
