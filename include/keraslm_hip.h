@@ -161,9 +161,9 @@ const char* kl_trace_kernel_name(kl_handle* h, int kind);
 int kl_test_gemm_tn(const uint16_t* A, const uint16_t* B, void* C, const float* bias, int M, int N, int K, long lda,
                     long ldb, long ldc, int out_mode, int splits, void* stream);
 /* the weight-gradient contraction with a K-major A operand: C[m][n] (or C[n][m] if c_transposed) +=
- * sum_k A_km[k][m] * B[n][k]; KL_ERR_SHAPE where it does not apply (M % 256, K % 64) */
+ * sum_k A_km[k][m] * B[n][k] (b_km: B_km[k][n]); KL_ERR_SHAPE where it does not apply (M % 256, K % 64) */
 int kl_test_gemm_an(const uint16_t* A_km, const uint16_t* B, float* C, int M, int N, int K, long lda_km, long ldb,
-                    long ldc, int c_transposed, void* stream);
+                    long ldc, int c_transposed, int b_km, void* stream);
 int kl_test_thin_gemm(const float* A, long lda, const uint16_t* WT_hi, const uint16_t* WT_lo, long ldw, int M, int N,
                       int K, float* C, long ldc, int split, void* stream);
 

@@ -69,6 +69,7 @@ struct WindowWs {
   std::vector<bf16_t*> Xhi, Xlo;      // inference: state planes exchanged by the split-precision scan [(T+1)B][W]
   std::vector<bf16_t*> HTf, HdT;      // transposed outputs written by the wide forward scans: [W][(T+1)B], [W][BT]
   bool ht_ready = false;              // ... valid for this window
+  bool km_plan = false;               // the weight-gradient GEMMs will read dZ and the activations K-major (row-major as written): no transposed copies
   bf16_t *dZT, *HT, *dlogits, *dlogitsT, *OHT, *dEKT_bf, *dEK_bf;
   std::vector<bf16_t*> OHC;
   float *dH, *dEKT;
@@ -382,7 +383,7 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
   if (training && h->scan_enabled && h->wide_fwd_min > 0 && kl_scan_fwd_wide_applicable(B, T, W) &&
       n_rb * (W / 64) >= h->wide_fwd_min) {
     for (int l = 0; l < L; ++l) {
-      KL_TRY(kl_launch_transpose_bf16((const bf16_t*)w.H[l], W, w.HTf[l], (long)(T + 1) * B, B, W, s));
+      if (!w.km_plan) KL_TRY(kl_launch_transpose_bf16((const bf16_t*)w.H[l], W, w.HTf[l], (long)(T + 1) * B, B, W, s));
       const bool masked = masks != nullptr && l > 0;
       KlScanFwdWide a;
       memset(&a, 0, sizeof(a));
@@ -403,8 +404,8 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       a.H = (bf16_t*)w.H[l]; a.C = w.C[l]; a.G = w.G[l];
       a.Hd = masked ? w.Hd[l] : nullptr;
       a.mask = masked ? masks + (size_t)l * BW : nullptr;
-      a.HT = w.HTf[l]; a.ldt = (long)(T + 1) * B;
-      a.HdT = masked ? w.HdT[l] : nullptr; a.ldt_d = (long)B * T;
+      a.HT = w.km_plan ? nullptr : w.HTf[l]; a.ldt = (long)(T + 1) * B;       // (K-major GEMMs: no transposed outputs)
+      a.HdT = (masked && !w.km_plan) ? w.HdT[l] : nullptr; a.ldt_d = (long)B * T;
       a.counters = w.scan_cnt;
       a.status = w.scan_status;
       a.sentinel = h->sentinel ? 1 : 0;
@@ -424,7 +425,7 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       }
     }
     scanned = true;
-    w.ht_ready = true;
+    w.ht_ready = !w.km_plan;
   }
   if (!scanned)
     KL_TRY(kl_launch_p1_gather(d.EK, ctxk.data(), c.n_ctx, P + h->off_b[0], idx, ctx, B, T, 4 * W, w.P1, s));
@@ -729,6 +730,8 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
 
   KL_TRY(kl_zero_async(grads, h->n_params * sizeof(float), s));
   KL_TRY(kl_zero_async(w.scan_status, (4 + 256) * sizeof(unsigned), s));
+  // (M = 4W rows of dZ as the K-major A operand: W % 64 == 0, T*B % 64 == 0)
+  w.km_plan = h->gemm_an && BTp == BT && kl_gemm_an_applicable(4 * W, W, BT, 4 * W);
   KL_TRY(forward_impl(h, B, T, idx, ctx, states, masks, 1, w, s));
 
   // F5/F6: logits over the (masked) top-layer outputs, softmax, CE, dlogits
@@ -744,9 +747,13 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
     KL_TRY(kl_zero_async(w.HT, (size_t)W * BTp * sizeof(bf16_t), s));
     KL_TRY(kl_zero_async(w.dZT, (size_t)4 * W * BTp * sizeof(bf16_t), s));
   }
-  KL_TRY(kl_launch_transpose_bf16(w.dlogits, Vp, w.dlogitsT, BTp, BT, Vp, s));
   const long ldtf = (long)(T + 1) * B;
-  if (w.ht_ready) {
+  const bool km_e = w.km_plan && Vp == V && kl_gemm_an_applicable(V, W, BT, Vp);
+  if (!km_e) KL_TRY(kl_launch_transpose_bf16(w.dlogits, Vp, w.dlogitsT, BTp, BT, Vp, s));
+  if (km_e) {
+    // dE += dlogits^T . Htop with both operands as they lie in memory
+    KL_TRY(kl_launch_gemm_an(w.dlogits, Htop, grads + h->off_E, V, W, BT, Vp, W, W, 0, s, 1));
+  } else if (w.ht_ready) {
     const bf16_t* HtopT = top_masked ? w.HdT[L - 1] : w.HTf[L - 1] + B;
     KL_TRY(kl_launch_gemm_tn(w.dlogitsT, HtopT, grads + h->off_E, nullptr, V, W, BT, BTp, top_masked ? (long)BT : ldtf, W, 2, ksplit, 1.f, s));
   } else {
@@ -758,13 +765,13 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   // launch-per-step layer wavefront
   std::vector<char> wg_done(L, 0);
   // B4/B5: weight gradients of one layer, K = B*T contractions over transposed activations
-  // dz_km: the contractions over the T*B rows read dZ K-major as the scan wrote it (kl_launch_gemm_an, the
-  // hardware transpose read) -- no transposed copy dZT at all; needs the transposed activations (ht_ready)
+  // dz_km: the contractions over the T*B rows read dZ and the activations K-major, as the scans wrote them
+  // (kl_launch_gemm_an, the hardware transpose read) -- no transposed copies at all
   auto weight_grads = [&](int l, bool dzt_ready, bool db_done, bool dz_km) -> int {
     if (!dzt_ready && !dz_km) KL_TRY(kl_launch_transpose_bf16(w.dZ[l], 4 * W, w.dZT, BTp, BT, 4 * W, s));
     // dU_l = Hprev^T . dZ   (Hprev = H blocks 0..T-1)
     if (dz_km) {
-      KL_TRY(kl_launch_gemm_an(w.dZ[l], w.HTf[l], grads + h->off_U[l], 4 * W, W, BT, 4 * W, ldtf, 4 * W, 1, s));
+      KL_TRY(kl_launch_gemm_an(w.dZ[l], (const bf16_t*)w.H[l], grads + h->off_U[l], 4 * W, W, BT, 4 * W, W, 4 * W, 1, s, 1));
     } else if (w.ht_ready) {
       KL_TRY(kl_launch_gemm_tn(w.HTf[l], w.dZT, grads + h->off_U[l], nullptr, W, 4 * W, BT, ldtf, BTp, 4 * W, 2, ksplit, 1.f, s));
     } else {
@@ -777,8 +784,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       const bool masked_in = masks != nullptr && (l - 1) > 0;
       const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
       if (dz_km) {
-        const bf16_t* XT = masked_in ? w.HdT[l - 1] : w.HTf[l - 1] + B;
-        KL_TRY(kl_launch_gemm_an(w.dZ[l], XT, grads + h->off_K[l], 4 * W, W, BT, 4 * W, masked_in ? (long)BT : ldtf, 4 * W, 1, s));
+        KL_TRY(kl_launch_gemm_an(w.dZ[l], X, grads + h->off_K[l], 4 * W, W, BT, 4 * W, W, 4 * W, 1, s, 1));
       } else if (w.ht_ready) {
         const bf16_t* XT = masked_in ? w.HdT[l - 1] : w.HTf[l - 1] + B;
         KL_TRY(kl_launch_gemm_tn(XT, w.dZT, grads + h->off_K[l], nullptr, W, 4 * W, BT, masked_in ? (long)BT : ldtf, BTp, 4 * W, 2, ksplit, 1.f, s));
@@ -852,8 +858,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       if (l == L - 1) h->trace_begin(1, s);
       // wide (64-unit) workgroups share the dZ tile through LDS; the weight-gradient GEMMs read dZ K-major
       // as it is (dz_km), else the scan also writes dZ^T
-      const bool dz_km = h->gemm_an && wide_fits && w.ht_ready && kl_gemm_an_applicable(4 * W, W, BT, 4 * W) && BTp == BT;
-      a.dZT = (!dz_km && BTp == BT && (B & 7) == 0) ? w.dZT : nullptr;
+      a.dZT = (!w.km_plan && BTp == BT && (B & 7) == 0) ? w.dZT : nullptr;
       a.ldt = BTp;
       a.db = grads + h->off_b[l];
       int e = h->wide_bwd ? kl_launch_scan_bwd_wide(a, s) : KL_ERR_SHAPE;
@@ -872,7 +877,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
         h->trace_end(1, s);
       }
       // dZ^T lives in ONE buffer: this layer's weight gradients before the next layer's scan
-      KL_TRY(weight_grads(l, wide && a.dZT != nullptr, wide, wide && dz_km));
+      KL_TRY(weight_grads(l, wide && a.dZT != nullptr, wide, w.km_plan));
       wg_done[l] = 1;
     }
     bscanned = true;
@@ -951,7 +956,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   }
 
   for (int l = L - 1; l >= 0; --l)
-    if (!wg_done[l]) KL_TRY(weight_grads(l, false, false, false));
+    if (!wg_done[l]) KL_TRY(weight_grads(l, false, false, w.km_plan));
 
   // F7: embedding regularisers (training phase only)
   std::vector<const float*> ctabs(c.n_ctx);
@@ -1129,8 +1134,8 @@ int kl_test_gemm_tn(const uint16_t* A, const uint16_t* B, void* C, const float* 
 }
 
 int kl_test_gemm_an(const uint16_t* A_km, const uint16_t* B, float* C, int M, int N, int K, long lda_km, long ldb,
-                    long ldc, int c_transposed, void* stream) {
-  return kl_launch_gemm_an(A_km, B, C, M, N, K, lda_km, ldb, ldc, c_transposed, (hipStream_t)stream);
+                    long ldc, int c_transposed, int b_km, void* stream) {
+  return kl_launch_gemm_an(A_km, B, C, M, N, K, lda_km, ldb, ldc, c_transposed, (hipStream_t)stream, b_km);
 }
 
 int kl_test_thin_gemm(const float* A, long lda, const uint16_t* WT_hi, const uint16_t* WT_lo, long ldw, int M, int N,

@@ -200,16 +200,17 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 // are: no transposed copy).  Its stage is the [64 k][256 m] image the DMA lays down (512-byte rows,
 // chunks XOR-swizzled at the source) and the fragments come from two ds_read_b64_tr_b16 each -- the
 // hardware transpose read: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4 x 16
-// block and lane i receives column i (cdna_hip_programming.md T10).  c_t (OUT == 2): accumulate C^T.
+// block and lane i receives column i (cdna_hip_programming.md T10).  BTR: the same for B, B[k][n] with
+// row stride ldb ([64 k][128 n] image, 256-byte rows).  c_t (OUT == 2): accumulate C^T.
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-template <int OUT, bool ILV, int RF, int WM, int WN, bool ATR = false>
+template <int OUT, bool ILV, int RF, int WM, int WN, bool ATR = false, bool BTR = false>
 __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, int M, int N, int K, long lda, long ldb, long ldc,
     int k_per_split, float alpha, const KlGateEpi epi, int xcd_remap, int c_t) {
-  static_assert(!ATR || (RF == 4 && WM == 4 && WN == 2), "K-major A: 256-row tiles only");
+  static_assert(!(ATR || BTR) || (RF == 4 && WM == 4 && WN == 2), "K-major operands: 256 x 128 tiles only");
   constexpr bool PRIO = KL_GEMM_PRIO;
   constexpr int NW = WM * WN;
   constexpr int WROWS = 16 * RF;               // rows per wave
@@ -253,8 +254,9 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
   const __amdgpu_buffer_rsrc_t rsA = ATR
       ? __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A + (long)kbeg * lda + m0), 0, clamp31(((long)(kend - kbeg - 1) * lda + (M - m0)) * 2), 0x00020000)
       : __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A + (long)m0 * lda), 0, clamp31(((long)(M - m0 - 1) * lda + K) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B + (long)n0 * ldb), 0, clamp31(((long)(N - n0 - 1) * ldb + K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = BTR
+      ? __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B + (long)kbeg * ldb + n0), 0, clamp31(((long)(kend - kbeg - 1) * ldb + (N - n0)) * 2), 0x00020000)
+      : __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B + (long)n0 * ldb), 0, clamp31(((long)(N - n0 - 1) * ldb + K) * 2), 0x00020000);
   // per-lane source offsets of this wave's pieces (rows wave*8*P + j*8 + (lane>>3)), swizzled chunk
   unsigned vo[NP];
 #pragma unroll
@@ -266,6 +268,13 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
       vo[j] = (unsigned)((long)krow * lda * 2 + c * 16);
       continue;
     }
+    if (BTR && j >= PA) {
+      // piece p = four k-rows of 256 bytes, 16 lanes each
+      const int krow = 4 * (wave * PB + (j - PA)) + (lane >> 4);
+      const int c = (lane & 15) ^ (2 * ((krow & 3) | (((krow >> 3) & 1) << 2)));
+      vo[j] = (unsigned)((long)krow * ldb * 2 + c * 16);
+      continue;
+    }
     const int row = j < PA ? wave * 8 * PA + j * 8 + (lane >> 3) : wave * 8 * PB + (j - PA) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     vo[j] = (unsigned)((long)row * (j < PA ? lda : ldb) * 2 + c * 16);
@@ -275,12 +284,13 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
   auto issue_half = [&](int kt, int stage, int half) {
     const int soff = (kbeg + kt * BK) * 2;
     const int soff_a = ATR ? (int)((long)kt * BK * lda * 2) : soff;     // (K-major A: based at kbeg already)
+    const int soff_b = BTR ? (int)((long)kt * BK * ldb * 2) : soff;
     const unsigned sa = lds0 + stage * STAGE_BYTES + wave * 8 * PA * 128;
     const unsigned sb = lds0 + stage * STAGE_BYTES + TBM * 128 + wave * 8 * PB * 128;
 #pragma unroll
     for (int j = half ? NP0 : 0; j < (half ? NP : NP0); ++j) {
       if (j < PA) glds16(rsA, vo[j], soff_a, sa + j * 1024);
-      else glds16(rsB, vo[j], soff, sb + (j - PA) * 1024);
+      else glds16(rsB, vo[j], soff_b, sb + (j - PA) * 1024);
     }
   };
   auto issue = [&](int kt, int stage) {
@@ -306,6 +316,14 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
 #pragma unroll
     for (int i = 0; i < RF; ++i)
       atr_off[i] = (unsigned)((fq * 8 + q) * 512 + ((((wm * WROWS + i * 16) >> 3) ^ fl) + (pp >> 1)) * 16 + 8 * (pp & 1));
+  }
+  unsigned btr_off[NT];
+  if (BTR) {
+    const int q = fr >> 2, pp = fr & 3;
+    const int fl = 2 * (q | ((fq & 1) << 2));
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      btr_off[j] = (unsigned)((fq * 8 + q) * 256 + ((((wn * WCOLS + j * 16) >> 3) ^ fl) + (pp >> 1)) * 16 + 8 * (pp & 1));
   }
   int stage = 0;
   for (int kt = 0; kt < nkt; ++kt) {
@@ -333,8 +351,17 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
         }
       }
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        fb[j].u = *reinterpret_cast<const uint4*>(b_base + lds_off(wn * WCOLS + j * 16 + fr, s * 4 + fq));
+      for (int j = 0; j < NT; ++j) {
+        if (BTR) {
+          const unsigned char* bp = b_base + btr_off[j] + s * 32 * 256;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp + 4 * 256));
+          fb[j].s[0] = (bf16_t)lo.x; fb[j].s[1] = (bf16_t)lo.y; fb[j].s[2] = (bf16_t)lo.z; fb[j].s[3] = (bf16_t)lo.w;
+          fb[j].s[4] = (bf16_t)hi.x; fb[j].s[5] = (bf16_t)hi.y; fb[j].s[6] = (bf16_t)hi.z; fb[j].s[7] = (bf16_t)hi.w;
+        } else {
+          fb[j].u = *reinterpret_cast<const uint4*>(b_base + lds_off(wn * WCOLS + j * 16 + fr, s * 4 + fq));
+        }
+      }
       if (ILV && more) issue_half(kt + 2, nstage, s);
       if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -559,7 +586,7 @@ int kl_launch_gemm_tn(const bf16_t* A, const bf16_t* B, void* C, const float* bi
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 
-// C (+)= A^T-view . B^T for a K-major A: A_km [K][M] (row stride lda_km), B [N][K] (row stride ldb), both
+// C (+)= A^T-view . B^T for a K-major A: A_km [K][M] (row stride lda_km), B [N][K] or -- b_km -- [K][N] (row stride ldb), both
 // bf16; C f32 accumulated with atomics over the K splits, as C[m][n] (c_transposed 0) or C[n][m] (1), row
 // stride ldc.  This is the weight-gradient contraction over the T*B rows taken straight from the backward
 // scan's row-major dZ.  KL_ERR_SHAPE = not applicable (the caller transposes and uses kl_launch_gemm_tn).
@@ -576,9 +603,9 @@ bool kl_gemm_an_applicable(int M, int N, int K, long lda_km) {
 }
 
 int kl_launch_gemm_an(const bf16_t* A_km, const bf16_t* B, float* C, int M, int N, int K, long lda_km, long ldb, long ldc,
-                      int c_transposed, hipStream_t stream) {
+                      int c_transposed, hipStream_t stream, int b_km) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  if (!kl_gemm_an_applicable(M, N, K, lda_km) || (ldb & 7) || ldb >= (1L << 22)) return KL_ERR_SHAPE;
+  if (!kl_gemm_an_applicable(M, N, K, lda_km) || (ldb & 7) || (!b_km && ldb >= (1L << 22))) return KL_ERR_SHAPE;
   const int tiles = (M / LBM) * ((N + LBN - 1) / LBN);
   int sp = (256 + tiles - 1) / tiles;          // ~ one workgroup per CU
   const int nk = K / BK;
@@ -587,6 +614,7 @@ int kl_launch_gemm_an(const bf16_t* A_km, const bf16_t* B, float* C, int M, int 
   const int kps = ((nk + sp - 1) / sp) * BK;
   sp = (K + kps - 1) / kps;
   if ((long)kps * lda_km * 2 >= 0x7fffffffL) return KL_ERR_SHAPE;     // 32-bit offsets inside one split
+  if (b_km && (long)kps * ldb * 2 >= 0x7fffffffL) return KL_ERR_SHAPE;
   dim3 grid((N + LBN - 1) / LBN, M / LBM, sp);
   KlGateEpi epi;
   memset(&epi, 0, sizeof(epi));
@@ -594,12 +622,18 @@ int kl_launch_gemm_an(const bf16_t* A_km, const bf16_t* B, float* C, int M, int 
   static const int remap = !(getenv("KL_GEMM_XCD") && getenv("KL_GEMM_XCD")[0] == '0');
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<2, true, 4, 4, 2, true>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<2, true, 4, 4, 2, true, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<2, true, 4, 4, 2, true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_tn_long_kernel<2, true, 4, 4, 2, true>), grid, dim3(512), lds, stream, A_km, B, (void*)C,
-                     (const float*)nullptr, M, N, K, lda_km, ldb, ldc, kps, 1.f, epi, remap, c_transposed);
+  if (b_km)
+    hipLaunchKernelGGL((gemm_tn_long_kernel<2, true, 4, 4, 2, true, true>), grid, dim3(512), lds, stream, A_km, B, (void*)C,
+                       (const float*)nullptr, M, N, K, lda_km, ldb, ldc, kps, 1.f, epi, remap, c_transposed);
+  else
+    hipLaunchKernelGGL((gemm_tn_long_kernel<2, true, 4, 4, 2, true, false>), grid, dim3(512), lds, stream, A_km, B, (void*)C,
+                       (const float*)nullptr, M, N, K, lda_km, ldb, ldc, kps, 1.f, epi, remap, c_transposed);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 

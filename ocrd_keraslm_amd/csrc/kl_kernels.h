@@ -35,7 +35,7 @@ int kl_launch_gemm_tn(const bf16_t* A, const bf16_t* B, void* C, const float* bi
 // the same contraction with a K-major A operand [K][M] (split-K, f32 atomics; optionally C^T): gemm.hip
 bool kl_gemm_an_applicable(int M, int N, int K, long lda_km);
 int kl_launch_gemm_an(const bf16_t* A_km, const bf16_t* B, float* C, int M, int N, int K, long lda_km, long ldb, long ldc,
-                      int c_transposed, hipStream_t stream);
+                      int c_transposed, hipStream_t stream, int b_km = 0);
 
 // ---- lstm_step.hip ------------------------------------------------------
 // One (activation, weight) operand pair of a thin fused step: rows of A are

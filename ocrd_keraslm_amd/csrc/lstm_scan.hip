@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
       }
       if (q < 256) {   // transposed copies: 64 units x 16 rows, two 16-byte stores per unit (x2 buffers)
         const int which = q >> 7, unit = (q >> 1) & 63, half = q & 1;
-        if (r0 + half * 8 < B) {
+        if (r0 + half * 8 < B && (which ? a.HdT != nullptr : a.HT != nullptr)) {
           const uint4 v = *reinterpret_cast<const uint4*>(tr + (which * 64 + unit) * 16 + half * 8);
           if (which) store16(rs_hdt, (unsigned)(((long)(u0 + unit) * a.ldt_d + half * 8) * 2), trow * 2u, v);
           else store16(rs_ht, (unsigned)(((long)(u0 + unit) * a.ldt + half * 8) * 2), (trow + B) * 2u, v);
@@ -1313,8 +1313,8 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
       // everything leaves through LDS as whole 16-byte pieces: the publish (waves 0, 1) and what
       // only later launches read (waves 2..15)
       pub[er * 64 + eu] = (bf16_t)hb;
-      tr[eu * 16 + er] = row_ok ? (bf16_t)hb : (bf16_t)0;
-      tr[(64 + eu) * 16 + er] = row_ok ? (bf16_t)hdb : (bf16_t)0;
+      if (a.HT) tr[eu * 16 + er] = row_ok ? (bf16_t)hb : (bf16_t)0;
+      if (a.HdT) tr[(64 + eu) * 16 + er] = row_ok ? (bf16_t)hdb : (bf16_t)0;
       st_c[er * 64 + eu] = c;
       st_hd[er * 64 + eu] = (bf16_t)hdb;
       st_g[(0 * 16 + er) * 64 + eu] = f2bf(gi);

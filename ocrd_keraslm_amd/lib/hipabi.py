@@ -58,7 +58,7 @@ SIGNATURES = {
     "kl_test_gemm_tn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_long, C.c_long, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     "kl_test_gemm_an": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long,
-                                  C.c_long, C.c_int, C.c_void_p]),
+                                  C.c_long, C.c_int, C.c_int, C.c_void_p]),
     "kl_test_thin_gemm": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p]),
 }

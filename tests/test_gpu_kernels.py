@@ -76,21 +76,30 @@ def test_gemm_tn(M, N, K, out_mode, splits):
     assert np.abs(got - ref).max() <= tol * scale, (np.abs(got - ref).max(), scale)
 
 
-@pytest.mark.parametrize("M,N,K,lda,c_t", [(256, 128, 1024, 256, 0), (2048, 512, 16384, 2048, 1), (512, 200, 8256, 640, 0),
-                                           (1024, 256, 4096, 1024, 1), (256, 64, 64, 256, 0)])
-def test_gemm_an(M, N, K, lda, c_t):
-    """the weight-gradient contraction with the K-major A operand (rows of dZ as the backward scan writes
-    them, read with the hardware transpose): C (+)= A^T . B^T, optionally accumulated transposed"""
+@pytest.mark.parametrize("M,N,K,lda,c_t,b_km", [(256, 128, 1024, 256, 0, 0), (2048, 512, 16384, 2048, 1, 0), (512, 200, 8256, 640, 0, 0),
+                                                (1024, 256, 4096, 1024, 1, 0), (256, 64, 64, 256, 0, 0),
+                                                # ... with the B operand K-major too (activations as the forward scan writes them)
+                                                (2048, 512, 16384, 2048, 1, 1), (256, 512, 8192, 256, 0, 1), (512, 200, 4160, 512, 1, 1),
+                                                (256, 128, 64, 320, 0, 1)])
+def test_gemm_an(M, N, K, lda, c_t, b_km):
+    """the weight-gradient contraction with K-major operands (rows of dZ / of the activations as the scans
+    write them, read with the hardware transpose): C (+)= A^T . B^T, optionally accumulated transposed"""
     torch = _torch()
     from ocrd_keraslm_amd.lib import hipabi
     lib = hipabi.load()
     rng = np.random.default_rng(M + 3 * N + K)
     A = bf16_bits(rng.standard_normal((K, lda)).astype(np.float32) * (1 + np.arange(lda)[None, :] % 3))
-    B = bf16_bits(rng.standard_normal((N, K)).astype(np.float32) * (1 + np.arange(N)[:, None] % 5))
-    ref = bits_to_f32(A)[:, :M].astype(np.float64).T @ bits_to_f32(B).astype(np.float64).T
+    ldb = (N + 40) if b_km else K
+    if b_km:
+        B = bf16_bits(rng.standard_normal((K, ldb)).astype(np.float32) * (1 + np.arange(ldb)[None, :] % 5))
+        Bmat = bits_to_f32(B)[:, :N].T
+    else:
+        B = bf16_bits(rng.standard_normal((N, K)).astype(np.float32) * (1 + np.arange(N)[:, None] % 5))
+        Bmat = bits_to_f32(B)
+    ref = bits_to_f32(A)[:, :M].astype(np.float64).T @ Bmat.astype(np.float64).T
     Ad, Bd = dev(A), dev(B)
     Cd = torch.zeros((N, M) if c_t else (M, N), dtype=torch.float32, device="cuda")
-    hipabi.check(lib.kl_test_gemm_an(ptr(Ad), ptr(Bd), ptr(Cd), M, N, K, lda, K, M if c_t else N, c_t, None))
+    hipabi.check(lib.kl_test_gemm_an(ptr(Ad), ptr(Bd), ptr(Cd), M, N, K, lda, ldb, M if c_t else N, c_t, b_km, None))
     torch.cuda.synchronize()
     got = Cd.cpu().numpy()
     if c_t:
