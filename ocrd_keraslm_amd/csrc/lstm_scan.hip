@@ -81,6 +81,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long 
   // (num_records is an unsigned 32-bit byte count: buffers up to 4 GiB - 1)
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)(bytes > 0xffffffffL ? 0xffffffffL : bytes), 0x00020000);
 }
+__device__ __forceinline__ uint4 load16_nt(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 2);
+  return uint4{v.x, v.y, v.z, v.w};
+}
 __device__ __forceinline__ uint4 load16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16);
   return uint4{v.x, v.y, v.z, v.w};
@@ -106,6 +110,16 @@ __device__ __forceinline__ void glds16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen sc1 lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(lds_addr)
+      : "memory");
+}
+// the same as a streaming ("nt") load: no L1 allocation, served by the XCD's L2 without the coherence
+// actions of an sc1 load -- for partners that were verified to share that L2 (XCD-local hand-off)
+__device__ __forceinline__ void glds16_nt(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(voff), "s"(rsrc), "s"(lds_addr)
       : "memory");
@@ -868,7 +882,10 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
               } else {
 #pragma unroll
                 for (int j = 0; j < JW; ++j)
-                  if (j >= lo) glds16_sc1(rs_own, base + (ug * JW + j) * 64, lds_a + ((kq4 * KSTEPS) + ug * JW + j) * 1024);
+                  if (j >= lo) {
+                    if (local) glds16_nt(rs_own, base + (ug * JW + j) * 64, lds_a + ((kq4 * KSTEPS) + ug * JW + j) * 1024);
+                    else glds16_sc1(rs_own, base + (ug * JW + j) * 64, lds_a + ((kq4 * KSTEPS) + ug * JW + j) * 1024);
+                  }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
               }
               bool all_ok = true;
@@ -931,7 +948,8 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
           const unsigned nbase = (unsigned)((((long)(nt + 1) * B + nr0 + (lane & 15)) * 4 * W + (long)kq4 * W + kq) * 2);
 #pragma unroll
           for (int j = 0; j < JW; ++j)
-            glds16_sc1(rs_own, nbase + (ug * JW + j) * 64, lds_a + ((kq4 * KSTEPS) + ug * JW + j) * 1024);
+            if (local) glds16_nt(rs_own, nbase + (ug * JW + j) * 64, lds_a + ((kq4 * KSTEPS) + ug * JW + j) * 1024);
+            else glds16_sc1(rs_own, nbase + (ug * JW + j) * 64, lds_a + ((kq4 * KSTEPS) + ug * JW + j) * 1024);
           pf_issued = 1;
         }
       }
@@ -1207,7 +1225,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
 #endif
           }
           if (!ok) for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
-            v = load16_sc1(rs_h, off);
+            v = local ? load16_nt(rs_h, off) : load16_sc1(rs_h, off);
             if (__all(t == 0 || granule_valid(v))) { ok = true; break; }
             if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
             __builtin_amdgcn_s_sleep(2);
@@ -1292,7 +1310,9 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlSca
         SSTAMP(11);
         pf_issued = 0;
         if (pref_ok && alive && nt < T && wave < KSTEPS) {
-          glds16_sc1(rs_h, (unsigned)((((long)nt * B + nr0 + (lane & 15)) * W + wave * 32 + kq) * 2), lds_a + wave * 1024);
+          const unsigned noff = (unsigned)((((long)nt * B + nr0 + (lane & 15)) * W + wave * 32 + kq) * 2);
+          if (local) glds16_nt(rs_h, noff, lds_a + wave * 1024);
+          else glds16_sc1(rs_h, noff, lds_a + wave * 1024);
           pf_issued = 1;
         }
       }
