@@ -177,6 +177,7 @@ constexpr int LBM = 256, LBN = 128, LTHREADS = 512, LSTAGES = 3;
 constexpr int LSTAGE_BYTES = (LBM + LBN) * 128;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4g;
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from rsrc[voff + soff] to LDS [lds_addr, +1 KiB).
 // Inline asm on purpose: behind the builtin hipcc drains vmcnt(0) in front of the next
@@ -491,6 +492,185 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
   }
 }
 
+// ---------------------------------------------------------------- persistent ring GEMM, plain f32 stores
+// The many-row products of a training window (P = H K^T, dX = dZ Kn^T, logits, dH: M = T*B rows, K of a
+// few hundred) have 8-32 k-steps per 256 x 128 tile: with one workgroup per tile every tile pays the ring's
+// start-up latency, a 128 KiB turn of the tile through LDS and the launch of its workgroup, none of it
+// overlapped (diagnostic at M = 262144, N = 2048, K = 512: 0.19 ms of 1.1 ms with neither main loop nor stores,
+// 0.48 ms main loop, 0.45 ms stores).  Here a workgroup stays on its CU and walks through its tiles: the
+// ring runs across tile boundaries (the next tile's first stages are in flight during the last k-steps),
+// and the accumulators leave straight from registers -- a 4 x 4 transpose inside each lane quad (DPP)
+// turns "4 rows x 1 column" per lane into 16 contiguous bytes of one row, so the ring's LDS is never
+// borrowed and the stores (buffer stores, out-of-range lanes dropped by the bounds check: always 16 per
+// wave, which the counted vmcnt below relies on) overlap the next tile's main loop.
+__device__ __forceinline__ float dpp_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+}
+// lane k of a quad holds m[r] = M[k][r]; afterwards m[r] = M[r][k]
+__device__ __forceinline__ void quad_transpose(f32x4& m, int k) {
+  const bool odd = k & 1, hi = k & 2;
+  {
+    const float s0 = odd ? m[0] : m[1], s1 = odd ? m[2] : m[3];
+    const float r0 = dpp_xor1(s0), r1 = dpp_xor1(s1);
+    if (odd) { m[0] = r0; m[2] = r1; } else { m[1] = r0; m[3] = r1; }
+  }
+  {
+    const float s0 = hi ? m[0] : m[2], s1 = hi ? m[1] : m[3];
+    const float r0 = dpp_xor2(s0), r1 = dpp_xor2(s1);
+    if (hi) { m[0] = r0; m[1] = r1; } else { m[2] = r0; m[3] = r1; }
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_tn_pers_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* __restrict__ C, const float* __restrict__ bias,
+    int M, int N, int K, long lda, long ldb, long ldc, float alpha, int tiles_n, int total) {
+  constexpr int RF = 4, WM = 4, WN = 2, NW = 8;
+  constexpr int WROWS = 64, TBM = 256, WCOLS = 64, NT = 4;
+  constexpr int PA = 4, PB = 2, NP = 6, NP0 = 3;
+  constexpr int STAGE_BYTES = (TBM + LBN) * 128;
+  constexpr int NST = RF * NT;                 // stores per lane and tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nkt = K / BK;
+  // tiles of this workgroup: XCD x (= blockIdx % 8) takes a contiguous run of the n-fastest tile order in
+  // every round, so the n-tiles of an m-tile (same A rows) meet in one L2
+  const int per_xcd = gridDim.x >> 3;
+  const int first = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int my_n = first < total ? (total - first + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  if (my_n == 0) return;
+  const int G = my_n * nkt;                    // flat k-steps of this workgroup
+
+  auto clamp31 = [](long v) { return (int)(v > 0x7fffffffL ? 0x7fffffffL : (v < 0 ? 0 : v)); };
+  unsigned vo[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int row = j < PA ? wave * 8 * PA + j * 8 + (lane >> 3) : wave * 8 * PB + (j - PA) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    vo[j] = (unsigned)((long)row * (j < PA ? lda : ldb) * 2 + c * 16);
+  }
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
+  // the bias row lives in LDS behind the ring: a global load in the epilogue would sit in the in-order
+  // vmcnt queue behind the next tile's DMA
+  float* bias_l = reinterpret_cast<float*>(smem + LSTAGES * STAGE_BYTES);
+  if (bias != nullptr) {
+    for (int c = tid; c < N; c += 512) bias_l[c] = bias[c];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // issue side: tile and k-step the next DMA belongs to
+  int it_i = 0, kt_i = 0;
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  auto set_issue_tile = [&](int it) {
+    const int L = first + it * (int)gridDim.x;
+    const int m0 = (L / tiles_n) * TBM, n0 = (L % tiles_n) * LBN;
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A + (long)m0 * lda), 0, clamp31(((long)(M - m0 - 1) * lda + K) * 2), 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B + (long)n0 * ldb), 0, clamp31(((long)(N - n0 - 1) * ldb + K) * 2), 0x00020000);
+  };
+  set_issue_tile(0);
+  auto issue_half = [&](int stage, int half) {
+    const int soff = kt_i * BK * 2;
+    const unsigned sa = lds0 + stage * STAGE_BYTES + wave * 8 * PA * 128;
+    const unsigned sb = lds0 + stage * STAGE_BYTES + TBM * 128 + wave * 8 * PB * 128;
+#pragma unroll
+    for (int j = half ? NP0 : 0; j < (half ? NP : NP0); ++j) {
+      if (j < PA) glds16(rsA, vo[j], soff, sa + j * 1024);
+      else glds16(rsB, vo[j], soff, sb + (j - PA) * 1024);
+    }
+    if (half) {     // the step is issued: advance
+      if (++kt_i == nkt) {
+        kt_i = 0;
+        if (++it_i < my_n) set_issue_tile(it_i);
+      }
+    }
+  };
+
+  f32x4 acc[RF][NT];
+#pragma unroll
+  for (int i = 0; i < RF; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue_half(0, 0);
+  issue_half(0, 1);
+  if (G > 1) {
+    issue_half(1, 0);
+    issue_half(1, 1);
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  int stage = 0, it_c = 0, kt_c = 0;
+  // A tile that ends in step e issues its NST stores behind the DMA of steps e+1 and e+2 (both already in
+  // flight), so the waits of those two steps may leave them outstanding: vmcnt is in order and only counts.
+  int stored = 0;
+  for (int g = 0; g < G; ++g) {
+    if (g + 1 < G) {
+      if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP + NST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+    } else {
+      if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (stored) --stored;
+    __builtin_amdgcn_s_barrier();
+    const bool more = g + 2 < G;
+    const int nstage = stage >= 1 ? stage - 1 : LSTAGES - 1;
+    const unsigned char* a_base = smem + stage * STAGE_BYTES;
+    const unsigned char* b_base = a_base + TBM * 128;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      frag16 fa[RF], fb[NT];
+#pragma unroll
+      for (int i = 0; i < RF; ++i)
+        fa[i].u = *reinterpret_cast<const uint4*>(a_base + lds_off(wm * WROWS + i * 16 + fr, s * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        fb[j].u = *reinterpret_cast<const uint4*>(b_base + lds_off(wn * WCOLS + j * 16 + fr, s * 4 + fq));
+      if (more) issue_half(nstage, s);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < RF; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fa[i].v, fb[j].v, acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    stage = stage + 1 < LSTAGES ? stage + 1 : 0;
+    if (++kt_c == nkt) {
+      // the tile is complete: out it goes, straight from the accumulators
+      const int L = first + it_c * (int)gridDim.x;
+      const int m0 = (L / tiles_n) * TBM, n0 = (L % tiles_n) * LBN;
+      const long bytes = ((long)(M - m0 - 1) * ldc + (N - n0)) * 4;
+      const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
+          C + (long)m0 * ldc + n0, 0, (int)(unsigned)(bytes > 0xffffffffL ? 0xffffffffL : bytes), 0x00020000);
+      const int k = fr & 3, c4 = fr & ~3;
+#pragma unroll
+      for (int i = 0; i < RF; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          f32x4 v = acc[i][j];
+          quad_transpose(v, k);
+          const int row = wm * WROWS + i * 16 + fq * 4 + k;
+          const int col = wn * WCOLS + j * 16 + c4;
+          f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (bias != nullptr && n0 + col + 3 < N) bv = *reinterpret_cast<const f32x4*>(bias_l + n0 + col);
+          v = v * alpha + bv;
+          // (a column past N would land in the next row's bytes: push it out of the buffer instead)
+          const unsigned off = (n0 + col < N) ? (unsigned)(((long)row * ldc + col) * 4) : 0xfffffff0u;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4g, v), rsC, (int)off, 0, 0);
+          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      kt_c = 0;
+      ++it_c;
+      stored = 2;
+    }
+  }
+}
+
 template <int RF, int WM, int WN>
 int launch_long_t(int out_mode, dim3 grid, hipStream_t stream, const bf16_t* A, const bf16_t* B, void* C, const float* bias,
                   int M, int N, int K, long lda, long ldb, long ldc, int k_per_split, float alpha,
@@ -556,6 +736,31 @@ int kl_launch_gemm_tn(const bf16_t* A, const bf16_t* B, void* C, const float* bi
   }
   // many-row shapes (activations x weights): the same ring, one tile per workgroup, no split
   static const bool small_all = getenv("KL_GEMM_SMALL_ALL") && getenv("KL_GEMM_SMALL_ALL")[0] == '1';   // experiment
+  static const bool pers = !(getenv("KL_GEMM_PERS") && getenv("KL_GEMM_PERS")[0] == '0');
+  // (measured at M = 262144: K = 512 -- P, logits -- 8-10 % faster than one workgroup per tile; K = 2048 and K = 256 not)
+  if (pers && !small_all && long_mode >= 2 && long_ok && out_mode == 0 && K >= 6 * BK && K <= 16 * BK && (N & 3) == 0 && (ldc & 3) == 0 &&
+      ((size_t)C & 15) == 0 && (bias == nullptr || N <= 2048) &&
+      (long)((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) >= 512) {
+    // many-row shapes with several tiles per CU: persistent workgroups (see gemm_tn_pers_kernel)
+    static int n_wg = 0;
+    if (!n_wg) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      n_wg = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
+                 ? (prop.multiProcessorCount & ~7) : 256;
+    }
+    const int tiles_n = (N + LBN - 1) / LBN, total = ((M + LBM - 1) / LBM) * tiles_n;
+    const size_t lds = (size_t)LSTAGES * (LBM + LBN) * 128 + (bias ? (size_t)N * 4 : 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_pers_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((size_t)LSTAGES * (LBM + LBN) * 128 + 2048 * 4)) != hipSuccess) return KL_ERR_LAUNCH;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_pers_kernel, dim3(n_wg), dim3(512), lds, stream, A, B, (float*)C, bias, M, N, K, lda, ldb, ldc,
+                       alpha, tiles_n, total);
+    return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+  }
   if (!small_all && long_mode >= 2 && long_ok && splits == 1 && K >= 256 && (long)((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) >= 256) {
     dim3 grid((N + LBN - 1) / LBN, (M + LBM - 1) / LBM, 1);
     const int e = launch_long(out_mode, grid, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, K, alpha);

@@ -48,6 +48,8 @@ def ptr(t):
     (512, 256, 16384, 2, 8), (300, 200, 8192, 2, 4), (256, 128, 8256, 2, 1), (100, 520, 12352, 2, 2),
     # ... with plain stores: many-row shapes (row-contiguous f32 epilogue through LDS; ragged last row tile)
     (65536, 128, 256, 0, 1), (33000, 256, 320, 0, 1), (32768, 384, 256, 1, 1),
+    # ... several tiles per CU: persistent workgroups, register epilogue (ragged last row tile, ragged column tile, one k-step more than the ring)
+    (131072, 128, 512, 0, 1), (66000, 256, 448, 0, 1), (140000, 200, 384, 0, 1), (70000, 512, 64 * 9, 0, 1),
     # ... and its 64 x 128 tile variant for M ~ 1e3 (the incremental step's shapes)
     (1024, 2048, 1536, 0, 1), (600, 3072, 576, 0, 1), (1024, 3072, 512, 1, 1)])
 def test_gemm_tn(M, N, K, out_mode, splits):
