@@ -109,6 +109,7 @@ struct kl_handle {
   bool gemm_an = true;          // weight gradients read the backward scan's dZ K-major, no transposed copy (KL_GEMM_AN=0: dZ^T)
   bool xcd_local = false;       // KL_XCD_LOCAL=1: sentinel hand-off inside one XCD through its L2 (plain stores) where the placement allows
   bool sentinel_bwd = true;
+  bool sentinel_roll = true;    // KL_SENTINEL_ROLL=0: pre-fill all of dZ instead of re-arming two steps ahead inside the scan
   bool sentinel_bwd_all = false; // KL_SENTINEL_BWD=2: also with one row block per workgroup
   bool xcd_local_bwd = false;    // KL_XCD_LOCAL_BWD=1     // the same for the wide backward scan (KL_SENTINEL_BWD=0, or KL_SENTINEL=0: counters)
   bool fused_step = true;       // incremental step, n >= 256: cell fused into the GEMM epilogue (KL_FUSED_STEP=0: separate kernels)
@@ -663,6 +664,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   const char* env7b = getenv("KL_SENTINEL_BWD");
   h->sentinel_bwd = h->sentinel && !(env7b && env7b[0] == '0');
   h->sentinel_bwd_all = env7b && env7b[0] == '2';
+  const char* env7f = getenv("KL_SENTINEL_ROLL");
+  h->sentinel_roll = !(env7f && env7f[0] == '0');
   const char* env7d = getenv("KL_XCD_LOCAL_BWD");
   h->xcd_local_bwd = h->xcd_local && env7d && env7d[0] == '1';
   const char* env6 = getenv("KL_FUSED_STEP");
@@ -851,7 +854,11 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       a.sentinel = (h->sentinel_bwd && wide_fits && (kl_scan_wide_blocks_per_wg(B, W) > 1 || h->sentinel_bwd_all)) ? 1 : 0;
       a.xcc_slots = (a.sentinel && h->xcd_local_bwd) ? w.scan_status + 4 : nullptr;
       a.gen = (unsigned)(1 + L + l);
-      if (a.sentinel)   // hand-off by data: the steps the scan is going to publish start out as sentinels
+      if (a.sentinel && h->sentinel_roll && T >= 3) {
+        // rolling sentinels: the scan re-arms step t - 2 while it publishes step t; only the first two start armed
+        a.sentinel = 2;
+        KL_TRY(kl_fill_u32_async(w.dZ[l] + (size_t)(T - 2) * BW * 4, (size_t)2 * BW * 4 * sizeof(bf16_t), 0xFFFFFFFFu, s));
+      } else if (a.sentinel)   // hand-off by data: the steps the scan is going to publish start out as sentinels
         KL_TRY(kl_fill_u32_async(w.dZ[l], (size_t)T * BW * 4 * sizeof(bf16_t), 0xFFFFFFFFu, s));
       else
         KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)n_rb_all * T, s));

@@ -801,7 +801,14 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
   const int n_raw = maskl ? 8 : 7;             // epilogue inputs loaded at the top of a block, behind the DMA
   const unsigned lds_a = (unsigned)(size_t)(lds_void_t*)a_tile;
   // vector memory operations of a wave between its DMA and the next block's wait: the publish (waves 0-7)
-  const int pf_after = wave < 8 ? 1 : 0;       // (the transposed copy leaves late, in front of the DMA: see LATE)
+  // Rolling sentinels (a.sentinel == 2): instead of a pre-fill of all of dZ by the caller (1 GiB per layer at
+  // B = 1024), the publishing lanes write the sentinel over their piece of step t - 2 together with the data
+  // of step t (the caller pre-fills only steps T-1 and T-2).  Safe: a consumer touches step t - 2 only after it
+  // has seen this workgroup's data of step t - 1, which was stored after the wait for this block's epilogue
+  // inputs (vmcnt(0): the sentinel store of step t had completed by then).
+  const bool roll = SENT && a.sentinel == 2;
+  const __amdgpu_buffer_rsrc_t rs_null = make_rsrc(dZl, 0);
+  const int pf_after = wave < 8 ? (roll ? 2 : 1) : 0;
   int pf_issued = 0;
   if (tid == 0) ok_flag = 1;
   __syncthreads();
@@ -998,6 +1005,12 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
           const unsigned off = (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2);
           if (SENT && local) store16(rs_own, off, 0u, v);      // stays in this XCD's L2, where all its readers are
           else store16_sc1(rs_own, off, v);
+          if (roll) {    // (steps T-1, T-2 have no t + 2: a null buffer drops the store, the count stays)
+            const unsigned soff = off - (unsigned)((long)2 * B * 4 * W * 2);
+            const uint4 ones = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (local) store16(t >= 2 ? rs_own : rs_null, soff, 0u, ones);
+            else store16_sc1(t >= 2 ? rs_own : rs_null, soff, ones);
+          }
         }
         if (SENT) {
           // the data is its own signal: nothing to drain, nothing to count
