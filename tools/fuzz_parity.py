@@ -20,10 +20,10 @@ def run(n_cases, seed, verbose=True):
       width = int(rng.choice([32, 64, 96, 128, 160, 256, 512]))
       voc = int(rng.integers(5, 300))
       n_ctx = int(rng.integers(0, 3))
-      B = int(rng.choice([1, 2, 3, 7, 8, 15, 16, 17, 24, 40, 100, 144, 200, 264, 512]))
+      B = int(rng.choice([1, 2, 3, 7, 8, 15, 16, 17, 24, 40, 100, 144, 200, 264, 512, 768, 1024, 1040, 1536]))
       T = int(rng.integers(1, 12))
-      if B * T * width > 3e6:
-          T = max(1, int(3e6 / (B * width)))
+      if B * T * width > 4e6:
+          T = max(1, int(4e6 / (B * width)))
       use_masks = bool(rng.integers(0, 2))
       cfg = O.ModelConfig(depth, width, voc, n_ctx)
       w = O.init_weights(cfg, seed=int(rng.integers(1 << 30)), emb_std=0.3, dtype=np.float32)
