@@ -31,6 +31,13 @@
 // Residency: at most 512 workgroups of 256 threads (<= 256 VGPRs, 18 KiB LDS), i.e.
 // two per CU on a full chip; a grid that oversubscribes the chip (tried: 1024)
 // times out cleanly through the bounded spins.
+//
+// The above describes the fused thin scans (lstm_scan_fwd_kernel / lstm_scan_bwd_kernel, few row blocks).
+// For many streams the layer-sequential WIDE scans further down take over: one layer per launch,
+// 1024-thread workgroups of 64 hidden units that fetch the state tile once and share it through LDS,
+// hand-off by data sentinels instead of counters (re-armed inside the backward scan), the next row
+// block's tile prefetched by LDS-DMA, optional XCD-local publishes -- see the comments at those kernels
+// and DESIGN.md section 4.
 #include <stdlib.h>
 #include <string.h>
 
