@@ -1009,6 +1009,54 @@ class Rater(object):
         self.model.set_weights(weights, PREC_SPLIT if (self.incremental or True) else PREC_BF16)
         self.status = 2
 
+    # ---- offline views of the embeddings (rating.py:1169-1237; matplotlib / scikit-learn are imported on use)
+    def _embedding(self, name):
+        assert self.status == 2
+        weights = self.model.get_weights()
+        if name not in weights:
+            raise KeyError("the model has no embedding '%s'" % name)
+        return np.asarray(weights[name], dtype=np.float64)
+
+    def plot_char_embeddings_similarity(self, filename):
+        '''Paint a heat map of character embeddings: |E E^T| as a grayscale PNG (rating.py:1169-1187).'''
+        import logging
+        logging.getLogger('matplotlib').setLevel(logging.WARNING)
+        from matplotlib import pyplot as plt
+        from matplotlib import cm
+        charwgt = self._embedding('E')
+        plt.imsave(filename, np.abs(np.dot(charwgt, charwgt.T)), cmap=cm.gray)
+
+    def plot_context_embeddings_similarity(self, filename, n=1):
+        '''Paint a heat map of the n-th context variable's embeddings (rating.py:1189-1207).'''
+        import logging
+        logging.getLogger('matplotlib').setLevel(logging.WARNING)
+        from matplotlib import pyplot as plt
+        from matplotlib import cm
+        ctxtwgt = self._embedding('Ctx%d' % (n - 1))
+        plt.imsave(filename, np.abs(np.dot(ctxtwgt, ctxtwgt.T)), cmap=cm.gray)
+
+    def plot_context_embeddings_projection(self, filename, n=1):
+        '''Scatter plot of a 2-d PCA projection of the n-th context variable's embeddings, every point
+        labelled with its decade (rating.py:1209-1237).  Labels are de-overlapped when adjustText is there.'''
+        import logging
+        logging.getLogger('matplotlib').setLevel(logging.WARNING)
+        import matplotlib
+        matplotlib.use('Agg')
+        from matplotlib import pyplot as plt
+        from sklearn.decomposition import PCA
+        ctxtprj = PCA(n_components=2).fit_transform(self._embedding('Ctx%d' % (n - 1)))
+        plt.figure(figsize=(11.7, 8.3))
+        plt.plot(ctxtprj[:, 0], ctxtprj[:, 1], 'bo', markersize=2)
+        texts = [plt.text(xy[0], xy[1], str(year) + 'x', c='b', size='xx-small') for year, xy in enumerate(ctxtprj)]
+        try:
+            from adjustText import adjust_text
+            adjust_text(texts, time_lim=20, iter_lim=20, expand_axes=True, arrowprops=dict(arrowstyle="-", color='b', lw=0.5))
+        except ImportError:
+            pass
+        plt.tick_params(left=False, right=False, bottom=False, labelleft=False, labelbottom=False)
+        plt.savefig(filename)
+        plt.close()
+
     def print_charset(self):
         '''Print the mapped characters (rating.py:1160-1167).'''
         import unicodedata

@@ -2,8 +2,8 @@
 """`keraslm-rate` command line (drop-in for ocrd_keraslm/scripts/run.py:31-221).
 
 Same commands, options, defaults and outputs as the reference CLI: train, test,
-apply, generate, print-history, print-charset, prune-charset.  (The three plot-*
-commands are offline tooling outside the accelerated path, SURVEY.md section 2 #9.)
+apply, generate, print-history, print-charset, prune-charset and the three plot-* views of the
+embeddings (matplotlib / scikit-learn imported on use).
 Additional option on `train`: --streams (stateful streams per GPU, default 1 = the
 reference's batching).  Under `python -m torch.distributed.run` training is
 data-parallel over the launched ranks (lib/distributed.py).
@@ -19,7 +19,8 @@ import click
 
 from .. import lib
 
-COMMAND_ORDER = ['train', 'test', 'apply', 'generate', 'print-history', 'print-charset', 'prune-charset']
+COMMAND_ORDER = ['train', 'test', 'apply', 'generate', 'print-history', 'print-charset', 'prune-charset',
+                 'plot-char-embeddings-similarity', 'plot-context-embeddings-similarity', 'plot-context-embeddings-projection']
 
 
 class OrderedGroup(click.Group):
@@ -179,6 +180,29 @@ def prune_charset(model, char):
     rater = _load(model)
     if rater.remove_from_mapping(char=char):
         rater.save(model)
+
+
+@cli.command(short_help='Paint a heat map of character embeddings')
+@click.option('-m', '--model', required=True, help='model file', type=click.Path(dir_okay=False, exists=True))
+@click.argument('filename', type=click.Path(dir_okay=False, writable=True))
+def plot_char_embeddings_similarity(model, filename):
+    _load(model).plot_char_embeddings_similarity(filename)
+
+
+@cli.command(short_help='Paint a heat map of context embeddings')
+@click.option('-m', '--model', required=True, help='model file', type=click.Path(dir_okay=False, exists=True))
+@click.option('-n', '--number', default=1, help='which context variable', type=click.IntRange(min=1, max=100))
+@click.argument('filename', type=click.Path(dir_okay=False, writable=True))
+def plot_context_embeddings_similarity(model, filename, number):
+    _load(model).plot_context_embeddings_similarity(filename, n=number)
+
+
+@cli.command(short_help='Paint a 2-d PCA projection of context embeddings')
+@click.option('-m', '--model', required=True, help='model file', type=click.Path(dir_okay=False, exists=True))
+@click.option('-n', '--number', default=1, help='which context variable', type=click.IntRange(min=1, max=100))
+@click.argument('filename', type=click.Path(dir_okay=False, writable=True))
+def plot_context_embeddings_projection(model, filename, number):
+    _load(model).plot_context_embeddings_projection(filename, n=number)
 
 
 if __name__ == '__main__':

@@ -84,3 +84,29 @@ def test_train_save_load_rate(factory, width, length, size):
             assert np.isfinite(p) and 1.0 < p < 2 * r2.voc_size
         finally:
             os.chdir(cwd)
+
+
+def test_embedding_plots(tmp_path):
+    """the three offline views of the embeddings (rating.py:1169-1237) write PNG files of the right size"""
+    pytest.importorskip("matplotlib")
+    pytest.importorskip("sklearn")
+    import matplotlib
+    matplotlib.use("Agg")
+    from matplotlib import pyplot as plt
+    r = Rater(engine_factory=OracleLM)
+    r.width, r.depth, r.length = 16, 1, 8
+    chars = "abcdefgh \n"
+    r.mapping = ({c: i + 1 for i, c in enumerate(chars)}, {i + 1: c for i, c in enumerate(chars)})
+    r.voc_size = len(chars) + 1
+    r.configure()
+    r.model.init_weights(seed=3, emb_std=0.5)
+    r.status = 2
+    f1, f2, f3 = (str(tmp_path / n) for n in ("chars.png", "ctx.png", "proj.png"))
+    r.plot_char_embeddings_similarity(f1)
+    r.plot_context_embeddings_similarity(f2, n=1)
+    r.plot_context_embeddings_projection(f3, n=1)
+    assert plt.imread(f1).shape[:2] == (r.voc_size, r.voc_size)
+    assert plt.imread(f2).shape[:2] == (200, 200)        # one row per decade of the context variable
+    assert os.path.getsize(f3) > 1000
+    with pytest.raises(KeyError):
+        r.plot_context_embeddings_similarity(f2, n=5)    # no such context variable
