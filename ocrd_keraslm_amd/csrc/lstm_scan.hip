@@ -740,11 +740,13 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
 // 46 % of a step).  Here a workgroup is 16 waves = 4 K-quarters x 4 unit groups = 64
 // hidden units, the tile is fetched ONCE per workgroup (each wave 1/16 of it) into LDS
 // and shared, so only W/64 workgroups read it.  One layer per launch (recurrent
-// contraction only; the from-above term arrives in dH from the big GEMM).  The step's
-// dZ tile is also written transposed ([4W][T*B], plain stores after the publish) for the
-// weight-gradient GEMMs, which saves the separate transpose pass.
-// SENT: data-sentinel hand-off (dZ pre-filled with 0xFFFF halfwords by the caller) instead of counters:
-// no poll, no drain, no atomics; with several row blocks per workgroup the next block's tile is
+// contraction only; the from-above term arrives in dH from the big GEMM).  On request (a.dZT: the
+// TN weight-gradient GEMMs, KL_GEMM_AN=0) the step's dZ tile is also written transposed ([4W][T*B]);
+// by default the weight-gradient GEMMs read the row-major dZ K-major and nothing transposed is
+// written: these scattered 16-byte stores cost 15-21 % of a step.
+// SENT: data-sentinel hand-off instead of counters (a.sentinel 1: dZ pre-filled with 0xFFFF halfwords
+// by the caller; 2: only the first two steps pre-filled, the publishing lanes re-arm step t-2): no
+// poll, no drain, no atomics; with several row blocks per workgroup the next block's tile is
 // prefetched by LDS-DMA behind the epilogue (see lstm_scan_fwd_wide_kernel).
 template <int KSTEPS, int MAXRB, bool SENT>
 __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlScanBwd a) {
@@ -1067,8 +1069,9 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide_kernel(const KlSca
 // per workgroup (one fragment per wave) and shared through LDS.  Only the recurrent
 // contraction is carried; the input side arrives either as the precomputed P rows of the
 // big GEMM (layers >= 1) or -- layer 0 -- straight from the look-up tables
-// EK[idx] + sum_n CtxK_n[ctx_n] + b (no P1 buffer at all).  The outputs are also written
-// transposed ([W][(T+1)B]) for the weight-gradient GEMMs.
+// EK[idx] + sum_n CtxK_n[ctx_n] + b (no P1 buffer at all).  On request (a.HT / a.HdT: the TN
+// weight-gradient GEMMs) the outputs are also written transposed ([W][(T+1)B]); by default they are not
+// (the weight-gradient GEMMs read the row-major outputs K-major).
 template <int KSTEPS, int MAXRB, bool SENT>
 __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide_kernel(const KlScanFwdWide a) {
   // Register budget: 1024 threads leave 128 VGPRs per lane and the resident weights take 64, so
