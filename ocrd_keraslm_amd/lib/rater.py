@@ -17,8 +17,8 @@ Differences that are deliberate:
     the reference's list-of-arrays states (rating.py:622-639).
   * context ids are clamped to the embedding range (the reference can index
     Embedding(200,10) out of range for years >= 1991, rating.py:111, 996).
-  * the stateless, non-incremental window modes (rating.py:93-99, 352-378) are
-    not built yet: configure() says so.
+  * the stateless, non-incremental window mode (rating.py:93-99, 352-378) runs through the
+    same engine with `set_window_mode(True)`: zero state per window, one target per window.
 """
 from __future__ import annotations
 
@@ -262,18 +262,18 @@ class Rater(object):
                 # works on the current one, and only then is the loss read back (a synchronisation).
                 # Streams that entered a new file while that batch was generated are reset right before
                 # it is trained, as ResetStatesCallback.on_batch_begin does.
-                pending = (next_batch(train_gens), sorted(reset_rows))
+                # (the dropout masks of the next step are drawn there too: 2 ms of host work per 1024 streams)
+                pending = (next_batch(train_gens), sorted(reset_rows), lm.draw_dropout_masks(B))
                 reset_rows.clear()
                 for step in range(steps_per_epoch):
-                    (x, z, y), rows = pending
+                    (x, z, y), rows, masks = pending
                     if rows:
                         lm.reset_states(B, rows=rows)
-                    masks = lm.draw_dropout_masks(B)
                     lm.train_window(x, z, y, masks)
                     sync.average(lm)
                     lm.adam_step()
                     if step + 1 < steps_per_epoch:
-                        pending = (next_batch(train_gens), sorted(reset_rows))
+                        pending = (next_batch(train_gens), sorted(reset_rows), lm.draw_dropout_masks(B))
                         reset_rows.clear()
                     ce, acc, reg = lm.read_loss(reset=True)
                     loss = ce + reg
