@@ -295,9 +295,12 @@ class Rater(object):
                 lm.reset_states(B)
                 lm.prepare(PREC_BF16)
                 v_loss = v_acc = 0.0
-                for _ in range(val_steps):
-                    x, z, y = next_batch(val_gens)
+                nxt = next_batch(val_gens) if val_steps else None
+                for k in range(val_steps):
+                    x, z, y = nxt
                     lm.forward_window(x, z, y, want_probs=False)
+                    if k + 1 < val_steps:      # (generated while the GPU works, as in training)
+                        nxt = next_batch(val_gens)
                     ce, acc, _ = lm.read_loss(reset=True)
                     v_loss += ce
                     v_acc += acc
