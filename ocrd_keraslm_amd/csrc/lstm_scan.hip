@@ -1523,7 +1523,7 @@ bool kl_scan_bwd_wide_applicable(int B, int T, int W) {
   int g = scan_cus() / col_groups;
   if (g < 1) return false;
   if (g > n_rb) g = n_rb;
-  if ((n_rb + g - 1) / g > 4) return false;
+  if ((n_rb + g - 1) / g > 8) return false;
   return (long)T * B * 4 * W * 2 <= 0xffffffffL;      // unsigned 32-bit buffer offsets
 }
 
@@ -1546,9 +1546,9 @@ int kl_launch_scan_bwd_wide(KlScanBwd a, hipStream_t stream) {
   if (g > a.n_rb) g = a.n_rb;
   a.n_rg = g;
   const int per_wg = (a.n_rb + g - 1) / g;
-  if (per_wg > 4) return KL_ERR_SHAPE;
+  if (per_wg > 8) return KL_ERR_SHAPE;
   dim3 grid(8 * col_groups * ((g + 7) / 8)), block(1024);     // 8 XCDs x column groups x row groups per XCD (surplus ones exit)
-  const size_t lds = (size_t)KL_BWD_WIDE_LDS(W / 32) + (per_wg > 1 ? 4 : 0) * 1024 * sizeof(float);
+  const size_t lds = (size_t)KL_BWD_WIDE_LDS(W / 32) + (per_wg > 4 ? 8 : (per_wg > 1 ? 4 : 0)) * 1024 * sizeof(float);
 #define KL_WIDE_CASE2(KS, RB, S)                                                                                     \
   do {                                                                                                               \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_bwd_wide_kernel<KS, RB, S>),                  \
@@ -1560,8 +1560,8 @@ int kl_launch_scan_bwd_wide(KlScanBwd a, hipStream_t stream) {
     if (a.sentinel) KL_WIDE_CASE2(KS, RB, true);      \
     else KL_WIDE_CASE2(KS, RB, false);                \
   } while (0)
-  if (W == 512) { if (per_wg == 1) KL_WIDE_CASE(16, 1); else if (per_wg == 2) KL_WIDE_CASE(16, 2); else KL_WIDE_CASE(16, 4); }
-  else { if (per_wg == 1) KL_WIDE_CASE(8, 1); else if (per_wg == 2) KL_WIDE_CASE(8, 2); else KL_WIDE_CASE(8, 4); }
+  if (W == 512) { if (per_wg == 1) KL_WIDE_CASE(16, 1); else if (per_wg == 2) KL_WIDE_CASE(16, 2); else if (per_wg <= 4) KL_WIDE_CASE(16, 4); else KL_WIDE_CASE(16, 8); }
+  else { if (per_wg == 1) KL_WIDE_CASE(8, 1); else if (per_wg == 2) KL_WIDE_CASE(8, 2); else if (per_wg <= 4) KL_WIDE_CASE(8, 4); else KL_WIDE_CASE(8, 8); }
 #undef KL_WIDE_CASE2
 #undef KL_WIDE_CASE
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
@@ -1574,7 +1574,7 @@ bool kl_scan_fwd_wide_applicable(int B, int T, int W) {
   int g = scan_cus() / col_groups;
   if (g < 1) return false;
   if (g > n_rb) g = n_rb;
-  if ((n_rb + g - 1) / g > 4) return false;
+  if ((n_rb + g - 1) / g > 8) return false;
   return (long)T * B * 4 * W * 2 <= 0xffffffffL;      // unsigned 32-bit buffer offsets (the gate rows are the largest)
 }
 
@@ -1591,9 +1591,9 @@ int kl_launch_scan_fwd_wide(KlScanFwdWide a, hipStream_t stream) {
   if (g > a.n_rb) g = a.n_rb;
   a.n_rg = g;
   const int per_wg = (a.n_rb + g - 1) / g;
-  if (per_wg > 4) return KL_ERR_SHAPE;
+  if (per_wg > 8) return KL_ERR_SHAPE;
   dim3 grid(8 * col_groups * ((g + 7) / 8)), block(1024);     // 8 XCDs x column groups x row groups per XCD (surplus ones exit)
-  const size_t lds = (size_t)KL_FWD_WIDE_LDS(W / 32) + (per_wg > 1 ? 4 : 0) * 1024 * sizeof(float);
+  const size_t lds = (size_t)KL_FWD_WIDE_LDS(W / 32) + (per_wg > 4 ? 8 : (per_wg > 1 ? 4 : 0)) * 1024 * sizeof(float);
   if ((long)a.T * a.B * 4 * W * 2 > 0xffffffffL) return KL_ERR_SHAPE;   // unsigned 32-bit buffer offsets (the gate rows are the largest)
 #define KL_WIDE_CASE2(KS, RB, S)                                                                                     \
   do {                                                                                                               \
@@ -1606,8 +1606,8 @@ int kl_launch_scan_fwd_wide(KlScanFwdWide a, hipStream_t stream) {
     if (a.sentinel) KL_WIDE_CASE2(KS, RB, true);      \
     else KL_WIDE_CASE2(KS, RB, false);                \
   } while (0)
-  if (W == 512) { if (per_wg == 1) KL_WIDE_CASE(16, 1); else if (per_wg == 2) KL_WIDE_CASE(16, 2); else KL_WIDE_CASE(16, 4); }
-  else { if (per_wg == 1) KL_WIDE_CASE(8, 1); else if (per_wg == 2) KL_WIDE_CASE(8, 2); else KL_WIDE_CASE(8, 4); }
+  if (W == 512) { if (per_wg == 1) KL_WIDE_CASE(16, 1); else if (per_wg == 2) KL_WIDE_CASE(16, 2); else if (per_wg <= 4) KL_WIDE_CASE(16, 4); else KL_WIDE_CASE(16, 8); }
+  else { if (per_wg == 1) KL_WIDE_CASE(8, 1); else if (per_wg == 2) KL_WIDE_CASE(8, 2); else if (per_wg <= 4) KL_WIDE_CASE(8, 4); else KL_WIDE_CASE(8, 8); }
 #undef KL_WIDE_CASE2
 #undef KL_WIDE_CASE
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;

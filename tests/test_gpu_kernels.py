@@ -255,7 +255,7 @@ def test_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks):
                                                                  # several row blocks per workgroup: sentinel backward, prefetched
                                                                  # tiles, late stores (even and uneven visits; width 256)
                                                                  (2, 512, 64, 1024, 3, 1, True), (2, 512, 64, 1040, 3, 1, True),
-                                                                 (2, 256, 40, 1056, 3, 1, True)])
+                                                                 (2, 256, 40, 1056, 3, 1, True), (2, 512, 64, 2560, 2, 1, True)])
 def test_train_window_wide_forward(monkeypatch, depth, width, voc, B, T, n_ctx, use_masks):
     """Layer-sequential forward with 64-unit workgroups (table look-ups fused into the
     layer-0 scan, transposed outputs written by the scans): forced on for small shapes."""
@@ -368,6 +368,7 @@ def test_train_consecutive_windows_reuse_buffers(depth, width, voc, B, T):
     (512, 10, {}), (1024, 4, {}), (264, 6, {}),
     (2048, 2, {}),                                       # four row blocks per workgroup: prefetched tiles, late stores
     (1040, 2, {}),                                       # 65 row blocks on 32 row groups: uneven visits
+    (2560, 1, {}),                                       # five row blocks per workgroup (the 8-block instantiation)
     (1032, 2, {}),                                       # a partial last tile: no prefetch
     (512, 4, {"KL_SENTINEL_BWD": "2"}),                  # sentinel backward with ONE block per workgroup (probe-first spin)
     (1024, 3, {"KL_XCD_LOCAL": "1", "KL_XCD_LOCAL_BWD": "1"}),   # XCD-local publishes (plain stores into the shared L2)
