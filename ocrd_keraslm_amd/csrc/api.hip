@@ -430,6 +430,48 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
   }
   if (!scanned)
     KL_TRY(kl_launch_p1_gather(d.EK, ctxk.data(), c.n_ctx, P + h->off_b[0], idx, ctx, B, T, 4 * W, w.P1, s));
+  // Width 1024 (the cfg5 topology): the recurrent weights of 16 units alone fill half of a 256-thread
+  // workgroup's registers, so neither the fused scans (U and K resident) nor the 64-unit wide scans apply.
+  // One layer per launch with the thin workgroups instead, the input side from one GEMM over all steps as
+  // in the wide path (layer 0: the table gather above).
+  if (!scanned && training && h->scan_enabled && W == 1024) {
+    bool all = true;
+    for (int l = 0; l < L && all; ++l) {
+      if (l > 0) {
+        const bool masked_in = masks != nullptr && (l - 1) > 0;
+        const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
+        KL_TRY(kl_launch_gemm_tn(X, d.KT_hi[l], w.P1, P + h->off_b[l], B * T, 4 * W, W, W, W, 4 * W, 0, 1, 1.f, s));
+      }
+      const bool masked = masks != nullptr && l > 0;
+      KlScanFwd a;
+      memset(&a, 0, sizeof(a));
+      a.B = B; a.T = T; a.W = W; a.L = 1;
+      a.UT[0] = d.UT_hi[l];
+      a.H[0] = (bf16_t*)w.H[l];
+      a.C[0] = w.C[l];
+      a.G[0] = w.G[l];
+      a.Hd[0] = masked ? w.Hd[l] : nullptr;
+      a.mask[0] = masked ? masks + (size_t)l * BW : nullptr;
+      a.P1 = w.P1;
+      a.counters = w.scan_cnt;
+      a.status = w.scan_status;
+      KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)((B + 15) / 16) * T, s));
+      if (l == L - 1) h->trace_begin(0, s);
+      const int e = kl_launch_scan_fwd(a, s);
+      if (e == KL_ERR_SHAPE && l == 0) {
+        all = false;          // (too many row blocks: the launch-per-step path below takes the window, P1 is in place)
+      } else if (e != 0) {
+        return e;
+      } else if (l == L - 1) {
+        h->trace_persistent[0] = true;
+        h->trace_name[0] = "lstm_scan_fwd_kernel";
+        h->trace_flops[0] = (double)B * T * (2.0 * W * 4.0 * W);
+        h->trace_end(0, s);
+      }
+    }
+    if (all) scanned = true;
+    else KL_TRY(kl_launch_p1_gather(d.EK, ctxk.data(), c.n_ctx, P + h->off_b[0], idx, ctx, B, T, 4 * W, w.P1, s));
+  }
   // rating windows in split precision: one persistent launch for all layers and steps
   if (!scanned && !training && split == KL_PREC_SPLIT && h->scan_enabled && L <= KL_SCAN_MAXL) {
     KlScanFwdSplit a;
@@ -832,8 +874,10 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   const int n_rb_all = (B + 15) / 16, nug = W / 16;
   const bool thin_fits = (n_rb_all + 512 / nug - 1) / (512 / nug) <= 4;
   const bool wide_fits = h->wide_bwd && kl_scan_bwd_wide_applicable(B, T, W) && BTp == BT && (B & 7) == 0;
-  const bool sequential = h->scan_enabled && h->seq_bwd && L > 1 && L <= KL_SCAN_MAXL && (W == 512 || W == 256 || W == 128) &&
-                          n_rb_all > 512 / (L * nug) && (thin_fits || wide_fits);
+  // (width 1024 has no fused scan at all: always layer by layer)
+  const bool sequential = h->scan_enabled && h->seq_bwd && L <= KL_SCAN_MAXL &&
+                          ((L > 1 && (W == 512 || W == 256 || W == 128) && n_rb_all > 512 / (L * nug)) || W == 1024) &&
+                          (thin_fits || wide_fits);
   if (sequential) {
     for (int l = L - 1; l >= 0; --l) {
       if (l < L - 1)   // dX_l = dZ_{l+1} . K_{l+1}^T  -> w.dH (free once the layer above has been scanned)

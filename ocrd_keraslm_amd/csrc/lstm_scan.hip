@@ -222,7 +222,9 @@ __device__ __forceinline__ bool poll_counter(const unsigned* cnt, unsigned targe
 // ---------------------------------------------------------------- forward scan
 // block = 256 threads; wave w contracts over K quarter w (KQ = W/128 k-steps of 32
 // per operand) for all 4 gates x 16 units.  MAXRB = row blocks served per step.
-template <int KSTEPS, int MAXRB>
+// IN = false: single-layer launches whose input side arrives precomputed in P1 (the layer-sequential path
+// for width 1024, where U alone takes 128 of the 256 registers): no input-weight registers at all.
+template <int KSTEPS, int MAXRB, bool IN = true>
 __global__ __launch_bounds__(256, 2) void lstm_scan_fwd_kernel(const KlScanFwd a) {
   constexpr int KQ = KSTEPS / 4;
   constexpr int W = KSTEPS * 32;
@@ -234,14 +236,14 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_fwd_kernel(const KlScanFwd a
   id -= l * NUG * n_rg;
   const int ug = id / n_rg, rg = id % n_rg;
   const int u0 = ug * 16;
-  const bool has_in = l > 0;
+  const bool has_in = IN && l > 0;
 
   __shared__ float zt[4][4][16][17];   // [wave][gate][row][unit] partial tiles
   __shared__ int ok_flag;
 
   // ---- resident weights as B fragments: gate g, this wave's K quarter
   const int kq = (lane >> 4) * 8;
-  uint4 bu[4][KQ], bk[4][KQ];
+  uint4 bu[4][KQ], bk[IN ? 4 : 1][IN ? KQ : 1];
   {
     const bf16_t* UT = a.UT[l];
     const bf16_t* KT = a.KT[l];
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_fwd_kernel(const KlScanFwd a
 #pragma unroll
       for (int j = 0; j < KQ; ++j) {
         bu[g][j] = *reinterpret_cast<const uint4*>(UT + wrow + j * 32);
-        bk[g][j] = has_in ? *reinterpret_cast<const uint4*>(KT + wrow + j * 32) : uint4{0, 0, 0, 0};
+        if (IN) bk[g][j] = has_in ? *reinterpret_cast<const uint4*>(KT + wrow + j * 32) : uint4{0, 0, 0, 0};
       }
     }
   }
@@ -319,24 +321,27 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_fwd_kernel(const KlScanFwd a
       // ---- this wave's fragments of the 16 x K state tile, write-through reads
       const int arow = min(r0 + (lane & 15), B - 1);
       const unsigned abase = (unsigned)((((long)t * B + arow) * W + (wave * KQ) * 32 + kq) * 2);
-      uint4 ah[KQ], ax[KQ];
+      uint4 ah[KQ], ax[IN ? KQ : 1];
       if (alive) {
 #pragma unroll
         for (int j = 0; j < KQ; ++j) {
-          ax[j] = has_in ? load16_sc1(rs_in, abase + j * 64) : uint4{0, 0, 0, 0};
+          if (IN) ax[j] = has_in ? load16_sc1(rs_in, abase + j * 64) : uint4{0, 0, 0, 0};
           ah[j] = load16_sc1(rs_h, abase + j * 64);
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < KQ; ++j) { ax[j] = uint4{0, 0, 0, 0}; ah[j] = uint4{0, 0, 0, 0}; }
+        for (int j = 0; j < KQ; ++j) {
+          if (IN) ax[j] = uint4{0, 0, 0, 0};
+          ah[j] = uint4{0, 0, 0, 0};
+        }
       }
       SSTAMP(3);
       f32x4 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (has_in) {
+      if (IN && has_in) {
 #pragma unroll
-        for (int j = 0; j < KQ; ++j) {
+        for (int j = 0; j < (IN ? KQ : 1); ++j) {
           frag16 fa;
           fa.u = ax[j];
 #pragma unroll
@@ -590,7 +595,8 @@ __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_kernel(const KlSca
 // over gate w's K range (W of the 4W columns) of dZ_l[t+1] . U_l^T and, below the
 // top layer, dZ_{l+1}[t] . K_{l+1}^T; the four partial tiles meet in LDS and the
 // gate derivatives run on the reduced tile.  dc lives in registers for all T steps.
-template <int KSTEPS, int MAXRB>
+// UP = false: single-layer launches (the from-above term arrives in dH from the big GEMM): no Kn registers.
+template <int KSTEPS, int MAXRB, bool UP = true>
 __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a) {
   constexpr int W = KSTEPS * 32;
   constexpr int NUG = W / 16;
@@ -601,18 +607,18 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
   id -= l * NUG * n_rg;
   const int ug = id / n_rg, rg = id % n_rg;
   const int u0 = ug * 16;
-  const bool has_up = l < a.L - 1;
+  const bool has_up = UP && l < a.L - 1;
 
   __shared__ float zt[4][16][17];
   __shared__ int ok_flag;
 
   const long wrow = (long)(u0 + (lane & 15)) * 4 * W + (long)wave * W;
   const int kq = (lane >> 4) * 8;
-  uint4 bu[KSTEPS], bk[KSTEPS];
+  uint4 bu[KSTEPS], bk[UP ? KSTEPS : 1];
 #pragma unroll
   for (int j = 0; j < KSTEPS; ++j) {
     bu[j] = *reinterpret_cast<const uint4*>(a.Un[l] + wrow + j * 32 + kq);
-    bk[j] = has_up ? *reinterpret_cast<const uint4*>(a.Kn[l + 1] + wrow + j * 32 + kq) : uint4{0, 0, 0, 0};
+    if (UP) bk[j] = has_up ? *reinterpret_cast<const uint4*>(a.Kn[l + 1] + wrow + j * 32 + kq) : uint4{0, 0, 0, 0};
   }
   const int er = tid >> 4, eu = tid & 15;
   float dc_reg[MAXRB];
@@ -670,13 +676,13 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
       alive = ok_flag != 0;
       const int arow = min(r0 + (lane & 15), B - 1);
       f32x4 acc_up = f32x4{0.f, 0.f, 0.f, 0.f}, acc = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (alive && has_up) {
-        uint4 av[KSTEPS];
+      if (UP && alive && has_up) {
+        uint4 av[UP ? KSTEPS : 1];
         const unsigned base = (unsigned)((((long)t * B + arow) * 4 * W + (long)wave * W + kq) * 2);
 #pragma unroll
-        for (int j = 0; j < KSTEPS; ++j) av[j] = load16_sc1(rs_up, base + j * 64);
+        for (int j = 0; j < (UP ? KSTEPS : 1); ++j) av[j] = load16_sc1(rs_up, base + j * 64);
 #pragma unroll
-        for (int j = 0; j < KSTEPS; ++j) {
+        for (int j = 0; j < (UP ? KSTEPS : 1); ++j) {
           frag16 fa, fb;
           fa.u = av[j];
           fb.u = bk[j];
@@ -684,16 +690,21 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
         }
       }
       if (alive && t < T - 1) {
-        uint4 av[KSTEPS];
+        // (at most 16 fragments in flight: width 1024 would otherwise need 128 registers for them)
+        constexpr int CH = KSTEPS < 16 ? KSTEPS : 16;
         const unsigned base = (unsigned)((((long)(t + 1) * B + arow) * 4 * W + (long)wave * W + kq) * 2);
 #pragma unroll
-        for (int j = 0; j < KSTEPS; ++j) av[j] = load16_sc1(rs_own, base + j * 64);
+        for (int c0 = 0; c0 < KSTEPS; c0 += CH) {
+          uint4 av[CH];
 #pragma unroll
-        for (int j = 0; j < KSTEPS; ++j) {
-          frag16 fa, fb;
-          fa.u = av[j];
-          fb.u = bu[j];
-          acc = mfma16(fa.v, fb.v, acc);
+          for (int j = 0; j < CH; ++j) av[j] = load16_sc1(rs_own, base + (c0 + j) * 64);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            frag16 fa, fb;
+            fa.u = av[j];
+            fb.u = bu[c0 + j];
+            acc = mfma16(fa.v, fb.v, acc);
+          }
         }
       }
 #pragma unroll
@@ -1450,7 +1461,7 @@ int scan_max_wgs() {
 
 // grid plan shared by both scans; false = this shape must use the launch-per-step path
 bool plan_scan(int W, int L, int B, int T, int* n_rb, int* n_rg, int* per_wg) {
-  if (W != 512 && W != 256 && W != 128) return false;
+  if (W != 512 && W != 256 && W != 128 && !(W == 1024 && L == 1)) return false;      // (width 1024: one layer per launch)
   if (L < 1 || L > KL_SCAN_MAXL || B < 1 || T < 1) return false;
   const int col_tasks = L * (W / 16);
   if (col_tasks > 256) return false;
@@ -1460,7 +1471,7 @@ bool plan_scan(int W, int L, int B, int T, int* n_rb, int* n_rg, int* per_wg) {
   if (g < 1) return false;
   *n_rg = g;
   *per_wg = (*n_rb + g - 1) / g;
-  return *per_wg <= (W == 512 ? 8 : 4);
+  return *per_wg <= (W == 512 ? 8 : 4);      // (the dispatch tables: 8 row blocks per workgroup at width 512, else 4)
 }
 
 }  // namespace
@@ -1491,6 +1502,13 @@ int kl_launch_scan_fwd(KlScanFwd a, hipStream_t stream) {
   if (!plan_scan(W, a.L, a.B, a.T, &a.n_rb, &a.n_rg, &per_wg)) return KL_ERR_SHAPE;
   // (the caller has zeroed a.counters -- L*ceil(B/16)*T words -- and a.status, write-through)
   dim3 grid(a.L * (W / 16) * a.n_rg), block(256);
+  if (W == 1024) {      // one layer per launch, input side precomputed in P1 (U alone takes 128 of the 256 registers)
+#define KL_SCAN_CASE3(KERNEL, KS, RB) hipLaunchKernelGGL((KERNEL<KS, RB, false>), grid, block, 0, stream, a)
+    if (per_wg == 1) KL_SCAN_CASE3(lstm_scan_fwd_kernel, 32, 1);
+    else if (per_wg == 2) KL_SCAN_CASE3(lstm_scan_fwd_kernel, 32, 2);
+    else KL_SCAN_CASE3(lstm_scan_fwd_kernel, 32, 4);
+    return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+  }
   KL_SCAN_DISPATCH(lstm_scan_fwd_kernel);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
@@ -1501,6 +1519,13 @@ int kl_launch_scan_bwd(KlScanBwd a, hipStream_t stream) {
   if (!plan_scan(W, a.L, a.B, a.T, &a.n_rb, &a.n_rg, &per_wg)) return KL_ERR_SHAPE;
   // (the caller has zeroed a.counters -- L*ceil(B/16)*T words -- and a.status, write-through)
   dim3 grid(a.L * (W / 16) * a.n_rg), block(256);
+  if (W == 1024) {      // one layer per launch (the caller's layer-sequential path)
+    if (per_wg == 1) KL_SCAN_CASE3(lstm_scan_bwd_kernel, 32, 1);
+    else if (per_wg == 2) KL_SCAN_CASE3(lstm_scan_bwd_kernel, 32, 2);
+    else KL_SCAN_CASE3(lstm_scan_bwd_kernel, 32, 4);
+#undef KL_SCAN_CASE3
+    return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+  }
   KL_SCAN_DISPATCH(lstm_scan_bwd_kernel);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }

@@ -242,7 +242,9 @@ def test_forward_window_parity(depth, width, voc, B, T, n_ctx):
                                                                  (2, 512, 64, 144, 6, 1, True), (2, 256, 40, 272, 4, 1, True),
                                                                  (3, 256, 30, 176, 5, 1, True),
                                                                  # cfg5 topology: depth 4, width 1024, two context variables
-                                                                 (4, 1024, 64, 4, 4, 2, True)])
+                                                                 (4, 1024, 64, 4, 4, 2, True),
+                                                                 # width 1024: one thin persistent scan per layer (several row blocks, ragged last one)
+                                                                 (4, 1024, 64, 48, 5, 2, True), (2, 1024, 40, 150, 3, 1, False)])
 def test_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks):
     check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks)
 
@@ -325,7 +327,7 @@ def test_adam_step_matches_oracle():
         assert np.abs(got[k] - wo[k]).max() < 1e-6, k
 
 
-@pytest.mark.parametrize("depth,width,voc,B,T", [(2, 128, 50, 20, 12), (2, 512, 64, 40, 8), (2, 512, 64, 144, 5)])
+@pytest.mark.parametrize("depth,width,voc,B,T", [(2, 128, 50, 20, 12), (2, 512, 64, 40, 8), (2, 512, 64, 144, 5), (3, 1024, 40, 40, 4)])
 def test_train_consecutive_windows_reuse_buffers(depth, width, voc, B, T):
     """The persistent scans hand data between workgroups through buffers that are
     re-used by every window: three consecutive windows (carried state, fresh inputs)
