@@ -1471,7 +1471,7 @@ bool plan_scan(int W, int L, int B, int T, int* n_rb, int* n_rg, int* per_wg) {
   if (g < 1) return false;
   *n_rg = g;
   *per_wg = (*n_rb + g - 1) / g;
-  return *per_wg <= (W == 512 ? 8 : 4);      // (the dispatch tables: 8 row blocks per workgroup at width 512, else 4)
+  return *per_wg <= ((W == 512 || W == 1024) ? 8 : 4);      // (the dispatch tables: 8 row blocks per workgroup at widths 512 and 1024, else 4)
 }
 
 }  // namespace
@@ -1506,7 +1506,8 @@ int kl_launch_scan_fwd(KlScanFwd a, hipStream_t stream) {
 #define KL_SCAN_CASE3(KERNEL, KS, RB) hipLaunchKernelGGL((KERNEL<KS, RB, false>), grid, block, 0, stream, a)
     if (per_wg == 1) KL_SCAN_CASE3(lstm_scan_fwd_kernel, 32, 1);
     else if (per_wg == 2) KL_SCAN_CASE3(lstm_scan_fwd_kernel, 32, 2);
-    else KL_SCAN_CASE3(lstm_scan_fwd_kernel, 32, 4);
+    else if (per_wg <= 4) KL_SCAN_CASE3(lstm_scan_fwd_kernel, 32, 4);
+    else KL_SCAN_CASE3(lstm_scan_fwd_kernel, 32, 8);
     return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
   }
   KL_SCAN_DISPATCH(lstm_scan_fwd_kernel);
@@ -1522,7 +1523,8 @@ int kl_launch_scan_bwd(KlScanBwd a, hipStream_t stream) {
   if (W == 1024) {      // one layer per launch (the caller's layer-sequential path)
     if (per_wg == 1) KL_SCAN_CASE3(lstm_scan_bwd_kernel, 32, 1);
     else if (per_wg == 2) KL_SCAN_CASE3(lstm_scan_bwd_kernel, 32, 2);
-    else KL_SCAN_CASE3(lstm_scan_bwd_kernel, 32, 4);
+    else if (per_wg <= 4) KL_SCAN_CASE3(lstm_scan_bwd_kernel, 32, 4);
+    else KL_SCAN_CASE3(lstm_scan_bwd_kernel, 32, 8);
 #undef KL_SCAN_CASE3
     return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
   }

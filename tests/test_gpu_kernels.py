@@ -244,7 +244,7 @@ def test_forward_window_parity(depth, width, voc, B, T, n_ctx):
                                                                  # cfg5 topology: depth 4, width 1024, two context variables
                                                                  (4, 1024, 64, 4, 4, 2, True),
                                                                  # width 1024: one thin persistent scan per layer (several row blocks, ragged last one)
-                                                                 (4, 1024, 64, 48, 5, 2, True), (2, 1024, 40, 150, 3, 1, False)])
+                                                                 (4, 1024, 64, 48, 5, 2, True), (2, 1024, 40, 150, 3, 1, False), (2, 1024, 40, 640, 2, 1, True)])
 def test_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks):
     check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks)
 
