@@ -2,7 +2,7 @@ import os, sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 from ocrd_keraslm_amd.lib import hipabi
 from ocrd_keraslm_amd.lib.engine import HipLM
-L,W,V,B,T = 2,512,256,int(sys.argv[1]) if len(sys.argv)>1 else 64,256
+L,W,V,B,T = int(os.environ.get("KL_PROBE_L", "2")),int(os.environ.get("KL_PROBE_W", "512")),256,int(sys.argv[1]) if len(sys.argv)>1 else 64,256
 lm = HipLM(L,W,V,1)
 lm.init_weights(seed=1)
 lm.prepare(hipabi.KL_PREC_BF16)
