@@ -226,10 +226,15 @@ __device__ __forceinline__ bool poll_counter(const unsigned* cnt, unsigned targe
 // for width 1024, where U alone takes 128 of the 256 registers): no input-weight registers at all.
 template <int KSTEPS, int MAXRB, bool IN = true>
 __global__ __launch_bounds__(256, 2) void lstm_scan_fwd_kernel(const KlScanFwd a) {
-  constexpr int KQ = KSTEPS / 4;
+  // K is split over KW waves (four; fewer for widths below 128, where the other waves contribute zero tiles)
+  constexpr int KW = KSTEPS < 4 ? KSTEPS : 4;
+  constexpr int KQ = KSTEPS / KW;
+  static_assert(KSTEPS % KW == 0, "K split");
   constexpr int W = KSTEPS * 32;
   constexpr int NUG = W / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool kactive = wave < KW;
+  const int kw = kactive ? wave : 0;       // (idle waves read wave 0's slice and discard the product)
   int id = blockIdx.x;
   const int n_rg = a.n_rg, n_rb = a.n_rb, B = a.B, T = a.T;
   const int l = id / (NUG * n_rg);
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_fwd_kernel(const KlScanFwd a
     const bf16_t* KT = a.KT[l];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const long wrow = ((long)g * W + u0 + (lane & 15)) * W + (wave * KQ) * 32 + kq;
+      const long wrow = ((long)g * W + u0 + (lane & 15)) * W + (kw * KQ) * 32 + kq;
 #pragma unroll
       for (int j = 0; j < KQ; ++j) {
         bu[g][j] = *reinterpret_cast<const uint4*>(UT + wrow + j * 32);
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_fwd_kernel(const KlScanFwd a
       alive = ok_flag != 0;
       // ---- this wave's fragments of the 16 x K state tile, write-through reads
       const int arow = min(r0 + (lane & 15), B - 1);
-      const unsigned abase = (unsigned)((((long)t * B + arow) * W + (wave * KQ) * 32 + kq) * 2);
+      const unsigned abase = (unsigned)((((long)t * B + arow) * W + (kw * KQ) * 32 + kq) * 2);
       uint4 ah[KQ], ax[IN ? KQ : 1];
       if (alive) {
 #pragma unroll
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_fwd_kernel(const KlScanFwd a
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) zt[wave][g][(lane >> 4) * 4 + r][lane & 15] = acc[g][r];
+        for (int r = 0; r < 4; ++r) zt[wave][g][(lane >> 4) * 4 + r][lane & 15] = kactive ? acc[g][r] : 0.f;
       SSTAMP(5);
       __syncthreads();
       SSTAMP(6);
@@ -423,7 +428,10 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_fwd_kernel(const KlScanFwd a
 // one 256-thread workgroup per CU.
 template <int KSTEPS, int MAXRB>
 __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_kernel(const KlScanFwdSplit a) {
-  constexpr int KQ = KSTEPS / 4;
+  // K is split over KW waves (four; fewer for widths below 128, where the other waves contribute zero tiles)
+  constexpr int KW = KSTEPS < 4 ? KSTEPS : 4;
+  constexpr int KQ = KSTEPS / KW;
+  static_assert(KSTEPS % KW == 0, "K split");
   constexpr int W = KSTEPS * 32;
   constexpr int NUG = W / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -434,6 +442,8 @@ __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_kernel(const KlSca
   const int ug = id / n_rg, rg = id % n_rg;
   const int u0 = ug * 16;
   const bool has_in = l > 0;
+  const bool kactive = wave < KW;
+  const int kw = kactive ? wave : 0;       // (idle waves read wave 0's slice and discard the product)
 
   __shared__ float zt[4][4][16][17];
   __shared__ int ok_flag;
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_kernel(const KlSca
   {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const long wrow = ((long)g * W + u0 + (lane & 15)) * W + (wave * KQ) * 32 + kq;
+      const long wrow = ((long)g * W + u0 + (lane & 15)) * W + (kw * KQ) * 32 + kq;
 #pragma unroll
       for (int j = 0; j < KQ; ++j) {
         bu[0][g][j] = *reinterpret_cast<const uint4*>(a.UT_hi[l] + wrow + j * 32);
@@ -507,7 +517,7 @@ __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_kernel(const KlSca
       __syncthreads();
       alive = ok_flag != 0;
       const int arow = min(r0 + (lane & 15), B - 1);
-      const unsigned abase = (unsigned)((((long)t * B + arow) * W + (wave * KQ) * 32 + kq) * 2);
+      const unsigned abase = (unsigned)((((long)t * B + arow) * W + (kw * KQ) * 32 + kq) * 2);
       f32x4 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -559,7 +569,7 @@ __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_kernel(const KlSca
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) zt[wave][g][(lane >> 4) * 4 + r][lane & 15] = acc[g][r];
+        for (int r = 0; r < 4; ++r) zt[wave][g][(lane >> 4) * 4 + r][lane & 15] = kactive ? acc[g][r] : 0.f;
       __syncthreads();
       float z[4];
 #pragma unroll
@@ -1461,7 +1471,7 @@ int scan_max_wgs() {
 
 // grid plan shared by both scans; false = this shape must use the launch-per-step path
 bool plan_scan(int W, int L, int B, int T, int* n_rb, int* n_rg, int* per_wg) {
-  if (W != 512 && W != 256 && W != 128 && !(W == 1024 && L == 1)) return false;      // (width 1024: one layer per launch)
+  if (W != 512 && W != 256 && W != 128 && W != 64 && !(W == 1024 && L == 1)) return false;      // (width 1024: one layer per launch)
   if (L < 1 || L > KL_SCAN_MAXL || B < 1 || T < 1) return false;
   const int col_tasks = L * (W / 16);
   if (col_tasks > 256) return false;
@@ -1488,10 +1498,14 @@ bool plan_scan(int W, int L, int B, int T, int* n_rb, int* n_rg, int* per_wg) {
       if (per_wg == 1) KL_SCAN_CASE(KERNEL, 8, 1);                                                    \
       else if (per_wg == 2) KL_SCAN_CASE(KERNEL, 8, 2);                                               \
       else KL_SCAN_CASE(KERNEL, 8, 4);                                                                \
-    } else {                                                                                          \
+    } else if (W == 128) {                                                                            \
       if (per_wg == 1) KL_SCAN_CASE(KERNEL, 4, 1);                                                    \
       else if (per_wg == 2) KL_SCAN_CASE(KERNEL, 4, 2);                                               \
       else KL_SCAN_CASE(KERNEL, 4, 4);                                                                \
+    } else {                                                                                          \
+      if (per_wg == 1) KL_SCAN_CASE(KERNEL, 2, 1);                                                    \
+      else if (per_wg == 2) KL_SCAN_CASE(KERNEL, 2, 2);                                               \
+      else KL_SCAN_CASE(KERNEL, 2, 4);                                                                \
     }                                                                                                 \
   } while (0)
 
@@ -1643,7 +1657,7 @@ int kl_launch_scan_fwd_wide(KlScanFwdWide a, hipStream_t stream) {
 // Split-precision inference scan (all layers fused).  KL_ERR_SHAPE = not applicable.
 int kl_launch_scan_fwd_split(KlScanFwdSplit a, hipStream_t stream) {
   const int W = a.W;
-  if (W != 512 && W != 256 && W != 128) return KL_ERR_SHAPE;
+  if (W != 512 && W != 256 && W != 128 && W != 64) return KL_ERR_SHAPE;
   if (a.L < 1 || a.L > KL_SCAN_MAXL || a.B < 1 || a.T < 1) return KL_ERR_SHAPE;
   const int col_tasks = a.L * (W / 16);
   if (col_tasks > 256) return KL_ERR_SHAPE;
