@@ -23,8 +23,23 @@ CTX_DIM = 10
 DROPOUT_RATE = 0.1  # rating.py:152
 
 
+FAST_WIDTHS = (64, 128, 256, 512, 1024)   # hidden sizes the persistent scans are instantiated for
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def physical_width(width):
+    """The width the kernels run at: the next one the persistent scans serve (else the next multiple of 32).
+    The extra hidden units are zero-padding -- all their weights and biases are zero, so their cell and
+    output stay exactly zero, nothing flows out of them, and their gradients are exactly zero (Adam leaves
+    them alone): a model of ANY width (the reference takes 1..9128, scripts/run.py:34) runs bit-identically to
+    its padded twin, on the fast kernels."""
+    for w in FAST_WIDTHS:
+        if width <= w:
+            return w
+    return (width + 31) // 32 * 32
 
 
 class HipLM:
@@ -36,9 +51,11 @@ class HipLM:
         self.lib = hipabi.load()
         self.device = torch.device(device)
         self.depth, self.width, self.voc_size, self.n_ctx = int(depth), int(width), int(voc_size), int(n_ctx)
-        if self.width % 32:
-            raise hipabi.KlError("width must be a multiple of 32 on the HIP path (got %d)" % self.width)
-        self.cfg = hipabi.KlConfig(self.depth, self.width, self.voc_size, self.n_ctx, CTX_VOCAB, CTX_DIM)
+        if self.width < 1:
+            raise hipabi.KlError("width must be positive (got %d)" % self.width)
+        self.pwidth = physical_width(self.width)       # what the kernels see (zero-padded hidden units)
+        self.padded = self.pwidth != self.width
+        self.cfg = hipabi.KlConfig(self.depth, self.pwidth, self.voc_size, self.n_ctx, CTX_VOCAB, CTX_DIM)
         self.handle = self.lib.kl_create(C.byref(self.cfg))
         if not self.handle:
             raise hipabi.KlError("kl_create rejected configuration depth=%d width=%d voc=%d"
@@ -101,25 +118,96 @@ class HipLM:
             yield
         cur.wait_stream(self.stream)
 
-    def get_weights(self):
-        """dict name -> float32 array in Keras shapes (E, Ctx0.., K0, U0, b0, ...)."""
-        flat = self.params.detach().cpu().numpy()
+    # `layout`, `params`, `grads`, `states`, `pool` are PHYSICAL (padded width); the accessors below speak the
+    # model's own shapes.  For the widths in FAST_WIDTHS (and multiples of 32 above 1024) both coincide.
+    def _logical_shape(self, name):
+        W = self.width
+        if name == "E":
+            return (self.voc_size, W)
+        if name.startswith("Ctx"):
+            return (CTX_VOCAB, CTX_DIM)
+        if name.startswith("b"):
+            return (4 * W,)
+        if name == "K0":
+            return (W + self.n_ctx * CTX_DIM, 4 * W)
+        return (W, 4 * W)
+
+    def _row_map(self, name, n_rows):
+        """physical row of every logical row (K0: the context rows sit behind the padded embedding rows)"""
+        r = np.arange(n_rows)
+        if name == "K0":
+            r = np.where(r < self.width, r, r + (self.pwidth - self.width))
+        return r
+
+    def _pad(self, name, a):
+        """logical array -> physical array (zeros in the padding)"""
+        a = np.asarray(a, dtype=np.float32).reshape(self._logical_shape(name))
+        if not self.padded or name.startswith("Ctx"):
+            return a
+        W, Wp = self.width, self.pwidth
+        if name == "E":
+            out = np.zeros((a.shape[0], Wp), dtype=np.float32)
+            out[:, :W] = a
+            return out
+        if name.startswith("b"):
+            out = np.zeros(4 * Wp, dtype=np.float32)
+            for g in range(4):
+                out[g * Wp:g * Wp + W] = a[g * W:(g + 1) * W]
+            return out
+        rows = self._row_map(name, a.shape[0])
+        out = np.zeros((a.shape[0] + (Wp - W), 4 * Wp), dtype=np.float32)
+        for g in range(4):
+            out[rows, g * Wp:g * Wp + W] = a[:, g * W:(g + 1) * W]
+        return out
+
+    def _unpad(self, name, a):
+        """physical array -> logical array"""
+        if not self.padded or name.startswith("Ctx"):
+            return a
+        W, Wp = self.width, self.pwidth
+        if name == "E":
+            return a[:, :W].copy()
+        if name.startswith("b"):
+            return np.concatenate([a[g * Wp:g * Wp + W] for g in range(4)])
+        rows = self._row_map(name, self._logical_shape(name)[0])
+        return np.concatenate([a[rows, g * Wp:g * Wp + W] for g in range(4)], axis=1)
+
+    def _unflatten(self, flat):
         out = {}
         for name, off, rows, cols in self.layout:
             a = flat[off:off + rows * cols]
-            out[name] = a.reshape(cols) .copy() if name.startswith("b") else a.reshape(rows, cols).copy()
+            a = a.reshape(cols).copy() if name.startswith("b") else a.reshape(rows, cols).copy()
+            out[name] = self._unpad(name, a)
         return out
+
+    def get_weights(self):
+        """dict name -> float32 array in Keras shapes (E, Ctx0.., K0, U0, b0, ...)."""
+        return self._unflatten(self.params.detach().cpu().numpy())
+
+    def get_grads(self):
+        """gradients of the last train_window, same names and shapes as get_weights()"""
+        return self._unflatten(self.grads.detach().cpu().numpy())
 
     def set_weights(self, weights, precision=None):
         flat = np.empty(self.n_params, dtype=np.float32)
         for name, off, rows, cols in self.layout:
             a = np.asarray(weights[name], dtype=np.float32)
-            if a.size != rows * cols:
-                raise ValueError("weight %s has %d elements, expected %d x %d" % (name, a.size, rows, cols))
-            flat[off:off + rows * cols] = a.reshape(-1)
+            if a.size != int(np.prod(self._logical_shape(name))):
+                raise ValueError("weight %s has %d elements, expected shape %s" % (name, a.size, self._logical_shape(name)))
+            flat[off:off + rows * cols] = self._pad(name, a).reshape(-1)
         with self._launch():
             self.params.copy_(self.torch.from_numpy(flat))
         self.prepare(precision or self.precision or hipabi.KL_PREC_SPLIT)
+
+    def get_states(self):
+        """implicit states of the stateful streams, numpy [B][2L][W]"""
+        return self.states[:, :, :self.width].cpu().numpy()
+
+    def set_states(self, values):
+        values = np.asarray(values, dtype=np.float32)
+        self.reset_states(values.shape[0])
+        with self._launch():
+            self.states[:, :, :self.width] = self.torch.from_numpy(np.ascontiguousarray(values)).to(self.device)
 
     def init_weights(self, seed=None, emb_std=0.001):
         """Keras initialisers of rating.py:104-114 + LSTM defaults (glorot_uniform kernel,
@@ -127,7 +215,9 @@ class HipLM:
         rng = np.random.default_rng(seed)
         W = self.width
         w = {}
-        for name, off, rows, cols in self.layout:
+        for name, _off, _rows, _cols in self.layout:
+            shape = self._logical_shape(name)
+            rows, cols = (1, shape[0]) if len(shape) == 1 else shape
             if name == "E" or name.startswith("Ctx"):
                 w[name] = (rng.standard_normal((rows, cols)) * emb_std).astype(np.float32)
             elif name.startswith("K"):
@@ -169,7 +259,7 @@ class HipLM:
     def reset_states(self, B=None, rows=None):
         """Keras reset_states (rating.py:475, 555; callbacks.py:58, 69)."""
         if self.states is None or (B is not None and self.states.shape[0] != B):
-            self.states = self.torch.zeros((B or 1, 2 * self.depth, self.width), dtype=self.torch.float32,
+            self.states = self.torch.zeros((B or 1, 2 * self.depth, self.pwidth), dtype=self.torch.float32,
                                            device=self.device)
         elif rows is None:
             self.states.zero_()
@@ -236,6 +326,8 @@ class HipLM:
             if masks is not None:
                 masks_d = masks if isinstance(masks, torch.Tensor) else torch.from_numpy(
                     np.ascontiguousarray(masks, dtype=np.float32)).to(self.device)
+                if self.padded and masks_d.shape[-1] == self.width:      # (whatever the padded units get is multiplied by zero)
+                    masks_d = torch.nn.functional.pad(masks_d, (0, self.pwidth - self.width), value=1.0).contiguous()
             ws = self._workspace(B, T, True)
             hipabi.check(self.lib.kl_train_window(self.handle, B, T, _ptr(idx_d), _ptr(ctx_d), _ptr(tgt_d),
                                                   _ptr(self.states), _ptr(masks_d), _ptr(self.grads),
@@ -262,7 +354,7 @@ class HipLM:
     def ensure_pool(self, n_slots):
         torch = self.torch
         if self.pool is None or self.pool.shape[0] < n_slots:
-            new = torch.zeros((n_slots, 2 * self.depth, self.width), dtype=torch.float32, device=self.device)
+            new = torch.zeros((n_slots, 2 * self.depth, self.pwidth), dtype=torch.float32, device=self.device)
             if self.pool is not None:
                 new[:self.pool.shape[0]] = self.pool
             self.pool = new
@@ -308,7 +400,7 @@ class HipLM:
     def pool_heads(self, slots, k):
         """first k state vectors of the given slots, [n][k][W] on the host"""
         idx = self.torch.as_tensor(np.asarray(slots), device=self.device, dtype=self.torch.long)
-        return self.pool[idx, :k].cpu().numpy()
+        return self.pool[idx, :k, :self.width].cpu().numpy()
 
     def state_dist2(self, a, b, k):
         torch = self.torch
@@ -327,10 +419,12 @@ class HipLM:
     def pool_read(self, slots):
         """states of the given slots as a numpy array [n][2L][W]"""
         with self._launch():
-            out = self.pool[self.torch.as_tensor(list(slots), device=self.device, dtype=self.torch.long)]
+            out = self.pool[self.torch.as_tensor(list(slots), device=self.device, dtype=self.torch.long)][:, :, :self.width]
         return out.cpu().numpy()
 
     def pool_write(self, slots, values):
         with self._launch():
             v = self.torch.from_numpy(np.ascontiguousarray(values, dtype=np.float32)).to(self.device)
+            if self.padded and v.shape[-1] == self.width:
+                v = self.torch.nn.functional.pad(v, (0, self.pwidth - self.width))
             self.pool[self.torch.as_tensor(list(slots), device=self.device, dtype=self.torch.long)] = v

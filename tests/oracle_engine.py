@@ -83,6 +83,10 @@ class OracleLM(object):
             self.loss[1] += acc
         return probs if want_probs else None
 
+    def get_grads(self):
+        flat = self.grads.numpy()
+        return {name: flat[off:off + rows * cols].reshape(self.w[name].shape).copy() for name, off, rows, cols in self.layout}
+
     def draw_dropout_masks(self, B):
         keep = self._rng.random((self.depth, B, self.width)) >= O.DROPOUT_RATE
         m = (keep / (1.0 - O.DROPOUT_RATE)).astype(np.float32)

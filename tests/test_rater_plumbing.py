@@ -39,7 +39,8 @@ def hip_factory(*args):
 
 @pytest.mark.parametrize("factory,width,length,size", [
     pytest.param(OracleLM, 32, 16, 400, id="oracle-cpu"),
-    pytest.param(hip_factory, 128, 64, 1500, id="hip", marks=pytest.mark.gpu)])
+    pytest.param(hip_factory, 128, 64, 1500, id="hip", marks=pytest.mark.gpu),
+    pytest.param(hip_factory, 100, 64, 1500, id="hip-width-100-zero-padded", marks=pytest.mark.gpu)])
 def test_train_save_load_rate(factory, width, length, size):
     random.seed(3)
     with tempfile.TemporaryDirectory() as tmp:

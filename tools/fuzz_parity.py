@@ -17,7 +17,7 @@ def run(n_cases, seed, verbose=True):
   bad = 0
   for case in range(n_cases):
       depth = int(rng.integers(1, 5))
-      width = int(rng.choice([32, 64, 96, 128, 160, 256, 512]))
+      width = int(rng.choice([32, 64, 96, 128, 160, 256, 512, 100, 50, 200, 333]))
       voc = int(rng.integers(5, 300))
       n_ctx = int(rng.integers(0, 3))
       B = int(rng.choice([1, 2, 3, 7, 8, 15, 16, 17, 24, 40, 100, 144, 200, 264, 512, 768, 1024, 1040, 1536]))
@@ -36,7 +36,7 @@ def run(n_cases, seed, verbose=True):
       tgt = rng.integers(0, voc, (B, T))
       tgt[rng.random((B, T)) < 0.1] = -1
       st0 = [rng.standard_normal((B, width)) * 0.1 for _ in range(2 * depth)]
-      lm.states.copy_(torch.from_numpy(np.stack(st0, axis=1).astype(np.float32)))
+      lm.set_states(np.stack(st0, axis=1).astype(np.float32))
       masks = lm.draw_dropout_masks(B) if use_masks else None
       om = ([None] + [masks[l].astype(np.float64) for l in range(1, depth)]) if use_masks else None
       ref_p, ref_st, cache = O.forward_window(cfg, w64, idx, ctx, [s.astype(np.float64) for s in st0], om, keep_cache=True)
@@ -45,16 +45,16 @@ def run(n_cases, seed, verbose=True):
       lm.loss_acc.zero_()
       lm.train_window(idx, ctx, tgt, masks)
       l, a, r = lm.read_loss()
-      flat = lm.grads.cpu().numpy()
+      grads = lm.get_grads()
       worst = 0.0
       for name, off, rows, cols in lm.layout:
-          got = flat[off:off + rows * cols].reshape(g_ref[name].shape)
+          got = grads[name].reshape(g_ref[name].shape)
           worst = max(worst, np.abs(got - g_ref[name]).max() / (np.abs(g_ref[name]).max() + 1e-12))
-      st = lm.states.cpu().numpy()
+      st = lm.get_states()
       sterr = max(np.abs(st[:, k] - ref_st[k]).max() for k in range(2 * depth))
       # rating window in split precision from the same start
       lm.prepare(hipabi.KL_PREC_SPLIT)
-      lm.states.copy_(torch.from_numpy(np.stack(st0, axis=1).astype(np.float32)))
+      lm.set_states(np.stack(st0, axis=1).astype(np.float32))
       ref_i, _, _ = O.forward_window(cfg, w64, idx, ctx, [s.astype(np.float64) for s in st0])
       perr = np.abs(lm.forward_window(idx, ctx).cpu().numpy() - ref_i).max()
       ok = worst < 3e-2 and abs(l - ce) < 2e-2 * max(1, ce) and sterr < 3e-2 and perr < 3e-5
