@@ -434,7 +434,9 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
   // workgroup's registers, so neither the fused scans (U and K resident) nor the 64-unit wide scans apply.
   // One layer per launch with the thin workgroups instead, the input side from one GEMM over all steps as
   // in the wide path (layer 0: the table gather above).
-  if (!scanned && training && h->scan_enabled && W == 1024) {
+  // The same layer-by-layer launches serve models deeper than the fused scans' four layers (the reference takes up to
+  // ten, scripts/run.py:35).
+  if (!scanned && training && h->scan_enabled && (W == 1024 || L > KL_SCAN_MAXL)) {
     bool all = true;
     for (int l = 0; l < L && all; ++l) {
       if (l > 0) {
@@ -529,7 +531,7 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
     }
   }
   for (int dgl = 0; !scanned && dgl < T + L - 1; ++dgl) {
-    KlFwdStep steps[4];
+    KlFwdStep steps[16];     // one per layer (config_ok: depth <= 16); launched in packs of 4 below
     int ns = 0;
     for (int l = 0; l < L; ++l) {
       const int t = dgl - l;
@@ -875,8 +877,10 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   const bool thin_fits = (n_rb_all + 512 / nug - 1) / (512 / nug) <= (W == 1024 ? 8 : 4);
   const bool wide_fits = h->wide_bwd && kl_scan_bwd_wide_applicable(B, T, W) && BTp == BT && (B & 7) == 0;
   // (width 1024 has no fused scan at all: always layer by layer)
-  const bool sequential = h->scan_enabled && h->seq_bwd && L <= KL_SCAN_MAXL &&
-                          ((L > 1 && (W == 512 || W == 256 || W == 128) && n_rb_all > 512 / (L * nug)) || W == 1024) &&
+  // (... and deeper than four layers: the fused scan's limit)
+  const bool sequential = h->scan_enabled && h->seq_bwd &&
+                          ((L > 1 && L <= KL_SCAN_MAXL && (W == 512 || W == 256 || W == 128) && n_rb_all > 512 / (L * nug)) ||
+                           W == 1024 || (L > KL_SCAN_MAXL && (W == 512 || W == 256 || W == 128 || W == 64))) &&
                           (thin_fits || wide_fits);
   if (sequential) {
     for (int l = L - 1; l >= 0; --l) {
@@ -962,7 +966,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
     }
   }
   for (int dgl = 0; !bscanned && dgl < T + L - 1; ++dgl) {
-    KlBwdStep steps[4];
+    KlBwdStep steps[16];     // one per layer (config_ok: depth <= 16); launched in packs of 4 below
     int ns = 0;
     for (int j = 0; j < L; ++j) {
       const int l = L - 1 - j;

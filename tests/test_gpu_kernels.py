@@ -151,7 +151,9 @@ def make_model(depth, width, voc, n_ctx=1, seed=4, emb_std=0.5):
                                                      # wide vocabulary (V >= 1024): output projection through the big GEMM too
                                                      (2, 128, 1100, 300, 1), (1, 64, 1500, 40, 0),
                                                      # zero-padded widths (small and big-n paths)
-                                                     (2, 100, 50, 30, 1), (2, 200, 50, 260, 1)])
+                                                     (2, 100, 50, 30, 1), (2, 200, 50, 260, 1),
+                                                     # deeper than four layers
+                                                     (6, 128, 30, 12, 1), (6, 128, 30, 260, 1)])
 def test_step_batch_parity(depth, width, voc, n, n_ctx):
     """S1 (rating.py:578-639): chained incremental steps through pool slots."""
     torch = _torch()
@@ -207,7 +209,9 @@ def test_step_batch_bf16_within_1e3():
                                                        # cfg5 topology
                                                        (4, 1024, 64, 2, 6, 2),
                                                        # zero-padded widths
-                                                       (2, 100, 50, 3, 12, 1), (1, 33, 20, 20, 5, 0)])
+                                                       (2, 100, 50, 3, 12, 1), (1, 33, 20, 20, 5, 0),
+                                                       # deeper than four layers (launch-per-step kernels, packs of four layers)
+                                                       (6, 128, 30, 5, 9, 1), (9, 64, 20, 2, 6, 2)])
 def test_forward_window_parity(depth, width, voc, B, T, n_ctx):
     """F1-F6 stateful windows (rating.py:490, 516): two consecutive windows carry state."""
     from ocrd_keraslm_amd.lib import hipabi
@@ -251,7 +255,9 @@ def test_forward_window_parity(depth, width, voc, B, T, n_ctx):
                                                                  (4, 1024, 64, 48, 5, 2, True), (2, 1024, 40, 150, 3, 1, False), (2, 1024, 40, 640, 2, 1, True),
                                                                  # any width: hidden units zero-padded to the next width the persistent scans serve
                                                                  (2, 100, 50, 24, 9, 1, True), (3, 40, 30, 5, 7, 2, True), (2, 300, 64, 144, 4, 1, True),
-                                                                 (1, 7, 20, 3, 6, 1, False)])
+                                                                 (1, 7, 20, 3, 6, 1, False),
+                                                                 # deeper than the fused scans' four layers: one persistent scan per layer
+                                                                 (6, 128, 30, 24, 5, 1, True), (5, 512, 40, 144, 3, 1, True), (7, 64, 20, 3, 4, 2, False)])
 def test_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks):
     check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks)
 
@@ -270,6 +276,14 @@ def test_train_window_wide_forward(monkeypatch, depth, width, voc, B, T, n_ctx, 
     layer-0 scan, transposed outputs written by the scans): forced on for small shapes."""
     monkeypatch.setenv("KL_WIDE_FWD_MIN", "1")
     check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks)
+
+
+@pytest.mark.parametrize("depth,width,voc,B,T,n_ctx", [(6, 128, 30, 5, 7, 1), (2, 128, 40, 20, 9, 1)])
+def test_train_window_launch_per_step_path(monkeypatch, depth, width, voc, B, T, n_ctx):
+    """KL_SCAN=0: the launch-per-step kernels (the fallback of every shape the scans do not cover), incl. more
+    layers than one launch packs"""
+    monkeypatch.setenv("KL_SCAN", "0")
+    check_train_window_gradients(depth, width, voc, B, T, n_ctx, True)
 
 
 def check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks):
