@@ -257,7 +257,9 @@ def test_forward_window_parity(depth, width, voc, B, T, n_ctx):
                                                                  (2, 100, 50, 24, 9, 1, True), (3, 40, 30, 5, 7, 2, True), (2, 300, 64, 144, 4, 1, True),
                                                                  (1, 7, 20, 3, 6, 1, False),
                                                                  # deeper than the fused scans' four layers: one persistent scan per layer
-                                                                 (6, 128, 30, 24, 5, 1, True), (5, 512, 40, 144, 3, 1, True), (7, 64, 20, 3, 4, 2, False)])
+                                                                 (6, 128, 30, 24, 5, 1, True), (5, 512, 40, 144, 3, 1, True), (7, 64, 20, 3, 4, 2, False),
+                                                                 # wider than 1024: padded to a multiple of 32, launch-per-step kernels
+                                                                 (2, 1100, 30, 4, 3, 1, True)])
 def test_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks):
     check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks)
 
