@@ -874,7 +874,8 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   // twice the row groups fit -- and take the from-above term dZ_{l+1} . K_{l+1}^T for all
   // steps at once from the big GEMM.
   const int n_rb_all = (B + 15) / 16, nug = W / 16;
-  const bool thin_fits = (n_rb_all + 512 / nug - 1) / (512 / nug) <= (W == 1024 ? 8 : 4);
+  const bool thin_fits = (n_rb_all + 512 / nug - 1) / (512 / nug) <= (W == 1024 ? 8 : 4) &&
+                         (long)T * B * 4 * W * 2 <= 0xfffffff0L;      // (the scans address dZ with unsigned 32-bit offsets)
   const bool wide_fits = h->wide_bwd && kl_scan_bwd_wide_applicable(B, T, W) && BTp == BT && (B & 7) == 0;
   // (width 1024 has no fused scan at all: always layer by layer)
   // (... and deeper than four layers: the fused scan's limit)

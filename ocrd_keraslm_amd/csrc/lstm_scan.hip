@@ -1514,6 +1514,7 @@ int kl_launch_scan_fwd(KlScanFwd a, hipStream_t stream) {
   const int W = a.W;
   int per_wg = 0;
   if (!plan_scan(W, a.L, a.B, a.T, &a.n_rb, &a.n_rg, &per_wg)) return KL_ERR_SHAPE;
+  if ((long)(a.T + 1) * a.B * W * 2 > 0xfffffff0L) return KL_ERR_SHAPE;      // unsigned 32-bit buffer offsets into H
   // (the caller has zeroed a.counters -- L*ceil(B/16)*T words -- and a.status, write-through)
   dim3 grid(a.L * (W / 16) * a.n_rg), block(256);
   if (W == 1024) {      // one layer per launch, input side precomputed in P1 (U alone takes 128 of the 256 registers)
@@ -1532,6 +1533,7 @@ int kl_launch_scan_bwd(KlScanBwd a, hipStream_t stream) {
   const int W = a.W;
   int per_wg = 0;
   if (!plan_scan(W, a.L, a.B, a.T, &a.n_rb, &a.n_rg, &per_wg)) return KL_ERR_SHAPE;
+  if ((long)a.T * a.B * 4 * W * 2 > 0xfffffff0L) return KL_ERR_SHAPE;        // unsigned 32-bit buffer offsets into dZ
   // (the caller has zeroed a.counters -- L*ceil(B/16)*T words -- and a.status, write-through)
   dim3 grid(a.L * (W / 16) * a.n_rg), block(256);
   if (W == 1024) {      // one layer per launch (the caller's layer-sequential path)
@@ -1565,7 +1567,7 @@ bool kl_scan_bwd_wide_applicable(int B, int T, int W) {
   if (g < 1) return false;
   if (g > n_rb) g = n_rb;
   if ((n_rb + g - 1) / g > 8) return false;
-  return (long)T * B * 4 * W * 2 <= 0xffffffffL;      // unsigned 32-bit buffer offsets
+  return (long)T * B * 4 * W * 2 <= 0xfffffff0L;      // unsigned 32-bit buffer offsets
 }
 
 // row blocks each workgroup of a wide scan serves per step (both wide scans use the same grid plan)
@@ -1616,7 +1618,7 @@ bool kl_scan_fwd_wide_applicable(int B, int T, int W) {
   if (g < 1) return false;
   if (g > n_rb) g = n_rb;
   if ((n_rb + g - 1) / g > 8) return false;
-  return (long)T * B * 4 * W * 2 <= 0xffffffffL;      // unsigned 32-bit buffer offsets (the gate rows are the largest)
+  return (long)T * B * 4 * W * 2 <= 0xfffffff0L;      // unsigned 32-bit buffer offsets (the gate rows are the largest)
 }
 
 // One-layer forward scan with 64-unit workgroups.  KL_ERR_SHAPE = not applicable.
@@ -1635,7 +1637,7 @@ int kl_launch_scan_fwd_wide(KlScanFwdWide a, hipStream_t stream) {
   if (per_wg > 8) return KL_ERR_SHAPE;
   dim3 grid(8 * col_groups * ((g + 7) / 8)), block(1024);     // 8 XCDs x column groups x row groups per XCD (surplus ones exit)
   const size_t lds = (size_t)KL_FWD_WIDE_LDS(W / 32) + (per_wg > 4 ? 8 : (per_wg > 1 ? 4 : 0)) * 1024 * sizeof(float);
-  if ((long)a.T * a.B * 4 * W * 2 > 0xffffffffL) return KL_ERR_SHAPE;   // unsigned 32-bit buffer offsets (the gate rows are the largest)
+  if ((long)a.T * a.B * 4 * W * 2 > 0xfffffff0L) return KL_ERR_SHAPE;   // unsigned 32-bit buffer offsets (the gate rows are the largest)
 #define KL_WIDE_CASE2(KS, RB, S)                                                                                     \
   do {                                                                                                               \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_fwd_wide_kernel<KS, RB, S>),                  \
