@@ -243,7 +243,7 @@ size_t carve_window(const kl_handle* h, void* base, int B, int T, int training, 
   o.s_ctx = cv.take<int>(BT * (size_t)(c.n_ctx > 0 ? c.n_ctx : 1));
   o.s_tgt = cv.take<int>(BT);
   o.s_masks = cv.take<float>(training ? L * (size_t)B * W : 1);
-  o.s_probs = cv.take<float>(training ? 1 : BT * V);
+  o.s_probs = cv.take<float>(BT * V);      // (training layout too: validation windows run on it, kl_forward_window)
   o.scan_cnt = cv.take<unsigned>(L * ((size_t)(B + 15) / 16) * T);
   o.scan_status = cv.take<unsigned>(4 + 256);   // status words [4] + XCC posts of the wide scans' workgroups [256]
   o.reg_scratch = cv.take<float>(3 * (W > (size_t)c.ctx_dim ? W : (size_t)c.ctx_dim) + (V > (size_t)c.ctx_vocab ? V : (size_t)c.ctx_vocab) + 8);
@@ -738,8 +738,28 @@ static int forward_window_body(kl_handle* h, int B, int T, const int32_t* idx, c
   if (!h->precision) return KL_ERR_STATE;
   hipStream_t s = (hipStream_t)stream;
   WindowWs w;
-  if (ws_bytes < carve_window(h, ws, B, T, 0, &w)) return KL_ERR_WORKSPACE;
   const int W = h->cfg.width, V = h->cfg.voc_size, L = h->cfg.depth;
+  // Windows in bf16 precision (validation after each epoch, rating.py:300-306: a fifth of every epoch's data) with
+  // a training-size workspace take the TRAINING forward -- persistent wide / fused scans and the big GEMMs -- without
+  // the backward, instead of the launch-per-step inference kernels (1024 x 256 characters: 41 ms -> 4.6 ms).
+  if (h->precision == KL_PREC_BF16 && ws_bytes >= carve_window(h, nullptr, B, T, 1, nullptr)) {
+    carve_window(h, ws, B, T, 1, &w);
+    const int BT = B * T;
+    KL_TRY(kl_zero_async(w.scan_status, (4 + 256) * sizeof(unsigned), s));
+    w.km_plan = true;                  // (no transposed outputs: nothing is going to contract over the rows)
+    KL_TRY(forward_impl(h, B, T, idx, ctx, states, nullptr, 1, w, s));
+    const bf16_t* Htop = (const bf16_t*)w.H[L - 1] + (size_t)B * W;
+    KL_TRY(kl_launch_gemm_tn(Htop, h->d.E_hi, w.logits, nullptr, BT, V, W, W, W, V, 0, 1, 1.f, s));
+    KL_TRY(kl_launch_softmax_ce(w.logits, V, BT, V, tgt, B, T, 1.0f / (h->last_only ? (float)B : (float)BT), nullptr, 0,
+                                tgt ? loss_acc : nullptr, w.rowstat, 1, s, h->last_only));
+    if (probs) {
+      if (B == 1) KL_TRY(hip_ok(hipMemcpyAsync(probs, w.logits, (size_t)T * V * sizeof(float), hipMemcpyDeviceToDevice, s)));
+      else KL_TRY(kl_launch_rows_tm_to_bm(w.logits, V, probs, B, T, V, s));
+    }
+    if (loss_acc) hipLaunchKernelGGL(scan_status_kernel, dim3(1), dim3(64), 0, s, w.scan_status, loss_acc);
+    return hip_ok(hipGetLastError());
+  }
+  if (ws_bytes < carve_window(h, ws, B, T, 0, &w)) return KL_ERR_WORKSPACE;
   KL_TRY(kl_zero_async(w.scan_status, (4 + 256) * sizeof(unsigned), s));
   KL_TRY(forward_impl(h, B, T, idx, ctx, states, nullptr, 0, w, s));
   KlOperand op;
@@ -1285,7 +1305,10 @@ extern "C" int kl_forward_window(kl_handle* h, int B, int T, const int32_t* idx,
   if (!h->precision) return KL_ERR_STATE;
   hipStream_t s = (hipStream_t)stream;
   WindowWs w;
-  if (ws_bytes < carve_window(h, ws, B, T, 0, &w)) return KL_ERR_WORKSPACE;
+  // (bf16 windows on a training-size workspace run the training forward: the staging slots must come from the
+  // same layout the body is going to carve -- see forward_window_body)
+  const int layout = (h->precision == KL_PREC_BF16 && ws_bytes >= carve_window(h, nullptr, B, T, 1, nullptr)) ? 1 : 0;
+  if (ws_bytes < carve_window(h, ws, B, T, layout, &w)) return KL_ERR_WORKSPACE;
   const size_t BT = (size_t)B * T;
   KL_TRY(hip_ok(hipMemcpyAsync(w.s_idx, idx, BT * sizeof(int), hipMemcpyDeviceToDevice, s)));
   if (h->cfg.n_ctx > 0)

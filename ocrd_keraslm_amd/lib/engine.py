@@ -284,7 +284,9 @@ class HipLM:
             tgt_d = self._dev_i32(tgt) if tgt is not None else None
             if self.states is None or self.states.shape[0] != B:
                 self.reset_states(B)
-            ws = self._workspace(B, T, False)
+            # (bf16 precision = validation windows: a training-size workspace lets the library take the training
+            # forward, i.e. the persistent scans; it is the buffer train_window uses anyway)
+            ws = self._workspace(B, T, self.precision == hipabi.KL_PREC_BF16)
             probs = torch.empty((B, T, self.voc_size), dtype=torch.float32, device=self.device) if want_probs else None
             hipabi.check(self.lib.kl_forward_window(self.handle, B, T, _ptr(idx_d), _ptr(ctx_d), _ptr(tgt_d),
                                                     _ptr(self.states), _ptr(probs), _ptr(self.loss_acc), _ptr(ws),

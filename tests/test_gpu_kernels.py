@@ -239,6 +239,38 @@ def test_forward_window_parity(depth, width, voc, B, T, n_ctx):
         assert np.abs(states[:, k] - st[k]).max() < 1e-4
 
 
+@pytest.mark.parametrize("depth,width,voc,B,T,n_ctx", [(2, 128, 40, 20, 9, 1), (2, 512, 64, 512, 4, 1), (2, 512, 64, 1024, 3, 1),
+                                                       (3, 100, 30, 5, 7, 2), (2, 1024, 40, 48, 4, 1), (6, 128, 30, 24, 5, 1)])
+def test_validation_windows_bf16(depth, width, voc, B, T, n_ctx):
+    """forward_window in bf16 precision (validation after each epoch, rating.py:300-306) takes the training forward --
+    the persistent scans -- without the backward: loss, accuracy, probabilities and carried state against the oracle,
+    over two consecutive windows."""
+    from ocrd_keraslm_amd.lib import hipabi
+    cfg, w, lm = make_model(depth, width, voc, n_ctx, emb_std=0.3)
+    lm.set_weights(w, hipabi.KL_PREC_BF16)
+    lm.reset_states(B)
+    rng = np.random.default_rng(5)
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    st = O.zero_states(cfg, B, np.float64)
+    for win in range(2):
+        idx = rng.integers(0, voc, (B, T))
+        ctx = rng.integers(0, 200, (B, 1, n_ctx)).repeat(T, axis=1)
+        tgt = rng.integers(0, voc, (B, T))
+        tgt[:, -1:] = -1
+        ref, st, _ = O.forward_window(cfg, w64, idx, ctx, st)
+        lm.loss_acc.zero_()
+        probs = lm.forward_window(idx, ctx, tgt).cpu().numpy()
+        assert np.abs(probs - ref).max() < 1e-2, np.abs(probs - ref).max()
+        ce, acc, _ = O.crossentropy(ref, tgt)
+        l, a, _ = lm.read_loss()
+        assert abs(l - ce) < 2e-2 * max(1, ce), (l, ce)
+        assert abs(a - acc) < 2e-2, (a, acc)
+        got = lm.get_states()
+        for k in range(2 * depth):
+            assert np.abs(got[:, k] - st[k]).max() < 3e-2
+        st = [got[:, k].astype(np.float64) for k in range(2 * depth)]      # (carry the engine's bf16-rounded state on)
+
+
 @pytest.mark.parametrize("depth,width,voc,B,T,n_ctx,use_masks", [(1, 64, 40, 2, 8, 1, False), (2, 64, 50, 4, 16, 1, True),
                                                                  (2, 128, 70, 8, 32, 1, True), (3, 64, 30, 3, 8, 2, True),
                                                                  (2, 64, 50, 1, 5, 1, False),
