@@ -1009,7 +1009,7 @@ class Rater(object):
         '''Load weights into the configured model (rating.py:966-974).'''
         assert self.status > 0
         weights = modelio.load_weights(filename, self.depth, self.width, self.n_ctx)
-        self.model.set_weights(weights, PREC_SPLIT if (self.incremental or True) else PREC_BF16)
+        self.model.set_weights(weights, PREC_SPLIT)      # (rating needs the f32-accurate mode; train() re-prepares in bf16)
         self.status = 2
 
     # ---- offline views of the embeddings (rating.py:1169-1237; matplotlib / scikit-learn are imported on use)
