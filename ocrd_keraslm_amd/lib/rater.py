@@ -456,13 +456,16 @@ class Rater(object):
         for epoch in range(self.max_epochs):
             lm.read_loss(reset=True)
             loss_sum = acc_sum = 0.0
+            nxt = next(train_gen)
             for step in range(steps_per_epoch):
-                x, z, y = next(train_gen)
+                x, z, y = nxt
                 b = x.shape[0]
                 lm.reset_states(b)
                 one = lm.draw_dropout_masks(1)      # noise_shape (1, W): one mask for the whole batch (rating.py:150)
                 lm.train_window(x, z, self._last_targets(x, y), np.repeat(one, b, axis=1))
                 lm.adam_step()
+                if step + 1 < steps_per_epoch:      # the next batch is generated while the GPU works (as in train)
+                    nxt = next(train_gen)
                 ce, acc, reg = lm.read_loss(reset=True)
                 loss = ce + reg
                 loss_sum += loss
@@ -478,11 +481,14 @@ class Rater(object):
             lm.prepare(PREC_BF16)
             v_loss = v_acc = 0.0
             n_rows = 0
-            for _ in range(val_steps):
-                x, z, y = next(val_gen)
+            nxt = next(val_gen)
+            for k in range(val_steps):
+                x, z, y = nxt
                 b = x.shape[0]
                 lm.reset_states(b)
                 lm.forward_window(x, z, self._last_targets(x, y), want_probs=False)
+                if k + 1 < val_steps:
+                    nxt = next(val_gen)
                 ce, acc, _ = lm.read_loss(reset=True)
                 v_loss += ce * b
                 v_acc += acc * b
