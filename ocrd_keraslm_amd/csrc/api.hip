@@ -140,7 +140,7 @@ struct kl_handle {
     ++trace_used[kind];
   }
   void drop_graphs() {
-    for (auto& g : graphs) hipGraphExecDestroy(g.second);
+    for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
     graphs.clear();
   }
 };
@@ -1271,14 +1271,14 @@ int run_graphed(kl_handle* h, const kl_handle::GraphKey& key, hipStream_t s, con
   hipGraph_t graph = nullptr;
   const hipError_t ce = hipStreamEndCapture(s, &graph);
   if (e != 0 || ce != hipSuccess || graph == nullptr) {
-    if (graph) hipGraphDestroy(graph);
+    if (graph) (void)hipGraphDestroy(graph);
     (void)hipGetLastError();
     h->graphs_enabled = false;
     return e != 0 ? e : body();
   }
   hipGraphExec_t exec = nullptr;
   const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
+  (void)hipGraphDestroy(graph);
   if (ie != hipSuccess || exec == nullptr) {
     (void)hipGetLastError();
     h->graphs_enabled = false;

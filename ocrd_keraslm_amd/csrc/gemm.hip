@@ -173,8 +173,7 @@ void launch_bm(int out_mode, dim3 grid, hipStream_t stream, const bf16_t* A, con
 #ifndef KL_GEMM_PRIO
 #define KL_GEMM_PRIO 1
 #endif
-constexpr int LBM = 256, LBN = 128, LTHREADS = 512, LSTAGES = 3;
-constexpr int LSTAGE_BYTES = (LBM + LBN) * 128;
+constexpr int LBM = 256, LBN = 128, LSTAGES = 3;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4g;
@@ -527,7 +526,7 @@ __device__ __forceinline__ void quad_transpose(f32x4& m, int k) {
 __global__ __launch_bounds__(512, 1) void gemm_tn_pers_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* __restrict__ C, const float* __restrict__ bias,
     int M, int N, int K, long lda, long ldb, long ldc, float alpha, int tiles_n, int total) {
-  constexpr int RF = 4, WM = 4, WN = 2, NW = 8;
+  constexpr int RF = 4, WN = 2;               // 8 waves as 4 x 2, each 64 x 64
   constexpr int WROWS = 64, TBM = 256, WCOLS = 64, NT = 4;
   constexpr int PA = 4, PB = 2, NP = 6, NP0 = 3;
   constexpr int STAGE_BYTES = (TBM + LBN) * 128;
