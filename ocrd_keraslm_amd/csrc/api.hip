@@ -52,6 +52,11 @@ struct Derived {
   bf16_t* Ecat = nullptr;        // [Vp][3W]
   float* EK = nullptr;
   std::vector<float*> CtxK;
+  // gate-interleaved copies for the second-generation wide scans (lstm_scan2.hip): column / row u*4+g <- g*W+u
+  std::vector<bf16_t*> KTp;      // [4W][W], l >= 1
+  std::vector<float*> bp;        // [4W], l >= 1 (layer 0's bias is folded into EKp)
+  float* EKp = nullptr;          // [V][4W] = EK + b_0
+  float* CtxKp = nullptr;        // [ctx_vocab][4W] of context variable 0
 };
 
 struct WindowWs {
@@ -61,6 +66,9 @@ struct WindowWs {
   float* logits;               // [BT][V]
   float* rowstat;              // [BT][2] per-row (loss, hit)
   int *s_idx, *s_ctx, *s_tgt;  // staged inputs (fixed addresses for graph replay)
+  int* ids_tm = nullptr;       // training: [T+1][B][2] table-row byte offsets, time-major (second-generation wide scans)
+  int scan2_rows = 0;          // second-generation wide scans planned for this window: rows per forward phase (0: first generation)
+  bool scan2_bwd = false;      // ... and the backward scan reads gate-interleaved G
   float *s_masks, *s_probs;
   unsigned *scan_cnt, *scan_status;   // persistent-scan hand-off counters [L][ceil(B/16)][T], status words [2]
   float* reg_scratch;                 // statistics of the embedding regularisers
@@ -113,6 +121,10 @@ struct kl_handle {
   bool sentinel_bwd_all = false; // KL_SENTINEL_BWD=2: also with one row block per workgroup
   bool xcd_local_bwd = false;    // KL_XCD_LOCAL_BWD=1     // the same for the wide backward scan (KL_SENTINEL_BWD=0, or KL_SENTINEL=0: counters)
   bool fused_step = true;       // incremental step, n >= 256: cell fused into the GEMM epilogue (KL_FUSED_STEP=0: separate kernels)
+  bool scan2 = true;            // second-generation wide scans where their grid plan applies (KL_SCAN2=0: first generation)
+  int scan2_rows = 0;           // KL_SCAN2_ROWS = 16 / 32: rows per forward phase (0: chosen by shape)
+  int scan2_pf = -1;            // KL_SCAN2_PF: where the forward scan requests its next tile (0: top of a phase, 1: behind the MFMA phase, 2: two phases ahead; -1: by shape)
+  int scan2_pfb = -1;           // KL_SCAN2_PFB: the same for the backward scan (-1: by shape)
   int wide_fwd_min = 96;        // layer-sequential wide forward scans from this many 64-unit workgroups (KL_WIDE_FWD_MIN; 0 = never)
   double trace_flops[2] = {0.0, 0.0};   // algorithmic FLOPs of ONE timed launch
   // optional per-launch timing of the cell-step kernels with HIP events (bench.py's
@@ -213,6 +225,14 @@ size_t carve_derived(const kl_handle* h, void* base, Derived* d) {
   o.Ecat = cv.take<bf16_t>(Vp * 3 * W);
   o.CtxK.assign(c.n_ctx, nullptr);
   for (int n = 0; n < c.n_ctx; ++n) o.CtxK[n] = cv.take<float>((size_t)c.ctx_vocab * 4 * W);
+  o.KTp.assign(c.depth, nullptr);
+  o.bp.assign(c.depth, nullptr);
+  for (int l = 1; l < c.depth; ++l) {
+    o.KTp[l] = cv.take<bf16_t>(4 * W * W);
+    o.bp[l] = cv.take<float>(4 * W);
+  }
+  o.EKp = cv.take<float>(V * 4 * W);
+  o.CtxKp = c.n_ctx > 0 ? cv.take<float>((size_t)c.ctx_vocab * 4 * W) : nullptr;
   return align_up(cv.off, 256);
 }
 
@@ -259,6 +279,7 @@ size_t carve_window(const kl_handle* h, void* base, int B, int T, int training, 
     }
     o.dZT = cv.take<bf16_t>(4 * W * BTp);
     o.HT = cv.take<bf16_t>(W * BTp);
+    o.ids_tm = cv.take<int>((BT + B) * 2);
     o.HTf.assign(L, nullptr); o.HdT.assign(L, nullptr);
     if ((B & 7) == 0) {
       for (size_t l = 0; l < L; ++l) {
@@ -321,6 +342,15 @@ int prepare_impl(kl_handle* h, int precision, hipStream_t s) {
     const float* Kc = P + h->off_K[0] + (size_t)(W + n * c.ctx_dim) * 4 * W;
     KL_TRY(kl_launch_small_table(P + h->off_Ctx[n], c.ctx_vocab, c.ctx_dim, Kc, 4 * W, 4 * W, d.CtxK[n], 4 * W, s));
   }
+  if (precision == KL_PREC_BF16 && h->scan2 && (W == 512 || W == 256)) {
+    // gate-interleaved copies for the second-generation wide scans
+    for (int l = 1; l < c.depth; ++l) {
+      KL_TRY(kl_launch_permute_gate_rows_bf16(d.KT_hi[l], d.KTp[l], W, W, s));
+      KL_TRY(kl_launch_permute_gate_cols_f32(P + h->off_b[l], nullptr, d.bp[l], 1, W, s));
+    }
+    KL_TRY(kl_launch_permute_gate_cols_f32(d.EK, P + h->off_b[0], d.EKp, V, W, s));
+    if (c.n_ctx > 0) KL_TRY(kl_launch_permute_gate_cols_f32(d.CtxK[0], nullptr, d.CtxKp, c.ctx_vocab, W, s));
+  }
   h->precision = precision;
   h->inc_ready = false;      // the big-n incremental operands are rebuilt on their first use (prepare_incremental)
   return 0;
@@ -358,6 +388,24 @@ int prepare_incremental(kl_handle* h, hipStream_t s) {
   return 0;
 }
 
+// Second-generation wide scans (lstm_scan2.hip) for this window?  Returns the rows per forward phase (16 / 32) or 0.
+// need_bwd: the window is a training window, i.e. the backward scan must be able to read the gate-interleaved G.
+int plan_scan2(const kl_handle* h, int B, int T, bool km_plan, bool need_bwd) {
+  const kl_config& c = h->cfg;
+  const int W = c.width;
+  if (!h->scan2 || !h->scan_enabled || !h->sentinel || !km_plan || c.n_ctx > 1 || T < 3) return 0;
+  if (W != 512) return 0;      // (one tile row = one 1 KiB DMA piece)
+  if (h->wide_fwd_min <= 0 || !kl_scan_fwd_wide_applicable(B, T, W) || ((B + 15) / 16) * (W / 64) < h->wide_fwd_min) return 0;
+  if (need_bwd && (!h->wide_bwd || !h->seq_bwd || !h->sentinel_bwd || !h->sentinel_roll || !kl_scan_wide2_phases(B, T, W, 16, 6))) return 0;
+  const int p16 = kl_scan_wide2_phases(B, T, W, 16, 4), p32 = kl_scan_wide2_phases(B, T, W, 32, 4);
+  if (h->scan2_rows == 16) return p16 ? 16 : 0;
+  if (h->scan2_rows == 32) return p32 ? 32 : 0;
+  // (by shape: 32-row phases once three of them keep a workgroup busy while a publish travels, else 16-row phases)
+  if (p32 >= 3) return 32;
+  if (p16) return 16;
+  return p32 ? 32 : 0;
+}
+
 // forward over one window; fills ws (activations) and states
 int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, float* states, const float* masks,
                  int training, WindowWs& w, hipStream_t s) {
@@ -390,11 +438,19 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       memset(&a, 0, sizeof(a));
       a.B = B; a.T = T; a.W = W;
       a.UT = d.UT_hi[l];
+      const bool v2 = w.scan2_rows != 0;
       if (l > 0) {
         const bool masked_in = masks != nullptr && (l - 1) > 0;
         const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
-        KL_TRY(kl_launch_gemm_tn(X, d.KT_hi[l], w.P1, P + h->off_b[l], B * T, 4 * W, W, W, W, 4 * W, 0, 1, 1.f, s));
+        KL_TRY(kl_launch_gemm_tn(X, v2 ? d.KTp[l] : d.KT_hi[l], w.P1, v2 ? d.bp[l] : P + h->off_b[l], B * T, 4 * W, W, W, W, 4 * W, 0, 1, 1.f, s));
         a.P = w.P1;
+      } else if (v2) {
+        KL_TRY(kl_launch_ids_tm(idx, ctx, c.n_ctx, B, T, W, c.voc_size, c.ctx_vocab, w.ids_tm, s));
+        a.EK = d.EKp;
+        a.CtxK[0] = d.CtxKp;
+        a.n_ctx = c.n_ctx;
+        a.ids_tm = w.ids_tm;
+        a.V = c.voc_size; a.ctx_vocab = c.ctx_vocab;
       } else {
         a.EK = d.EK;
         for (int n = 0; n < c.n_ctx; ++n) a.CtxK[n] = d.CtxK[n];
@@ -416,11 +472,14 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
         KL_TRY(kl_fill_u32_async((bf16_t*)w.H[l] + BW, (size_t)T * BW * sizeof(bf16_t), 0xFFFFFFFFu, s));
       else
         KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)n_rb * T, s));
+      // (two phases ahead needs the rows to have been published a phase before the request: three or more phases per workgroup)
+      a.pf_mode = h->scan2_pf >= 0 ? h->scan2_pf : (v2 && kl_scan_wide2_phases(B, T, W, w.scan2_rows, 4) >= 3 ? 2 : 1);
       if (l == L - 1) h->trace_begin(0, s);
-      KL_TRY(kl_launch_scan_fwd_wide(a, s));
+      if (v2) KL_TRY(kl_launch_scan_fwd_wide2(a, w.scan2_rows, s));
+      else KL_TRY(kl_launch_scan_fwd_wide(a, s));
       if (l == L - 1) {
         h->trace_persistent[0] = true;
-        h->trace_name[0] = "lstm_scan_fwd_wide_kernel";
+        h->trace_name[0] = v2 ? "lstm_scan_fwd_wide2_kernel" : "lstm_scan_fwd_wide_kernel";
         h->trace_flops[0] = (double)B * T * (2.0 * W * 4.0 * W);   // one layer's recurrent contraction
         h->trace_end(0, s);
       }
@@ -714,6 +773,14 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->xcd_local_bwd = h->xcd_local && env7d && env7d[0] == '1';
   const char* env6 = getenv("KL_FUSED_STEP");
   h->fused_step = !(env6 && env6[0] == '0');
+  const char* env8 = getenv("KL_SCAN2");
+  if (env8) h->scan2 = atoi(env8) != 0;
+  const char* env8b = getenv("KL_SCAN2_ROWS");
+  if (env8b) h->scan2_rows = atoi(env8b);
+  const char* env8c = getenv("KL_SCAN2_PF");
+  if (env8c) h->scan2_pf = atoi(env8c);
+  const char* env8d = getenv("KL_SCAN2_PFB");
+  if (env8d) h->scan2_pfb = atoi(env8d);
   const char* env5 = getenv("KL_WIDE_FWD_MIN");
   if (env5) h->wide_fwd_min = atoi(env5);
   return kl_zero_page_ready();
@@ -747,6 +814,7 @@ static int forward_window_body(kl_handle* h, int B, int T, const int32_t* idx, c
     const int BT = B * T;
     KL_TRY(kl_zero_async(w.scan_status, (4 + 256) * sizeof(unsigned), s));
     w.km_plan = true;                  // (no transposed outputs: nothing is going to contract over the rows)
+    w.scan2_rows = plan_scan2(h, B, T, true, false);
     KL_TRY(forward_impl(h, B, T, idx, ctx, states, nullptr, 1, w, s));
     const bf16_t* Htop = (const bf16_t*)w.H[L - 1] + (size_t)B * W;
     KL_TRY(kl_launch_gemm_tn(Htop, h->d.E_hi, w.logits, nullptr, BT, V, W, W, W, V, 0, 1, 1.f, s));
@@ -799,6 +867,8 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   KL_TRY(kl_zero_async(w.scan_status, (4 + 256) * sizeof(unsigned), s));
   // (M = 4W rows of dZ as the K-major A operand: W % 64 == 0, T*B % 64 == 0)
   w.km_plan = h->gemm_an && BTp == BT && kl_gemm_an_applicable(4 * W, W, BT, 4 * W);
+  w.scan2_rows = plan_scan2(h, B, T, w.km_plan, true);
+  w.scan2_bwd = w.scan2_rows != 0;
   KL_TRY(forward_impl(h, B, T, idx, ctx, states, masks, 1, w, s));
 
   // F5/F6: logits over the (masked) top-layer outputs, softmax, CE, dlogits
@@ -903,7 +973,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
                           ((L > 1 && L <= KL_SCAN_MAXL && (W == 512 || W == 256 || W == 128) && n_rb_all > 512 / (L * nug)) ||
                            W == 1024 || (L > KL_SCAN_MAXL && (W == 512 || W == 256 || W == 128 || W == 64))) &&
                           (thin_fits || wide_fits);
-  if (sequential) {
+  if (sequential || w.scan2_bwd) {
     for (int l = L - 1; l >= 0; --l) {
       if (l < L - 1)   // dX_l = dZ_{l+1} . K_{l+1}^T  -> w.dH (free once the layer above has been scanned)
         KL_TRY(kl_launch_gemm_tn(w.dZ[l + 1], d.Kn[l + 1], w.dH, nullptr, BT, W, 4 * W, 4 * W, 4 * W, W, 0, 1, 1.f, s));
@@ -920,7 +990,9 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       a.status = w.scan_status + 1;
       // (sentinels pay with several row blocks per workgroup, where the next tile is prefetched; with one
       // block the cheap counter poll beats re-fetching 64 KiB tiles; XCD-local publishes measured slower here)
-      a.sentinel = (h->sentinel_bwd && wide_fits && (kl_scan_wide_blocks_per_wg(B, W) > 1 || h->sentinel_bwd_all)) ? 1 : 0;
+      a.sentinel = (w.scan2_bwd || (h->sentinel_bwd && wide_fits && (kl_scan_wide_blocks_per_wg(B, W) > 1 || h->sentinel_bwd_all))) ? 1 : 0;
+      // (measured: with two blocks per workgroup a request at the top of a block comes too early and is re-fetched)
+      a.pf_mode = h->scan2_pfb >= 0 ? h->scan2_pfb : (kl_scan_wide2_phases(B, T, W, 16, 6) >= 3 ? 0 : 1);
       a.xcc_slots = (a.sentinel && h->xcd_local_bwd) ? w.scan_status + 4 : nullptr;
       a.gen = (unsigned)(1 + L + l);
       if (a.sentinel && h->sentinel_roll && T >= 3) {
@@ -937,8 +1009,9 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       a.dZT = (!w.km_plan && BTp == BT && (B & 7) == 0) ? w.dZT : nullptr;
       a.ldt = BTp;
       a.db = grads + h->off_b[l];
-      int e = h->wide_bwd ? kl_launch_scan_bwd_wide(a, s) : KL_ERR_SHAPE;
+      int e = w.scan2_bwd ? kl_launch_scan_bwd_wide2(a, s) : (h->wide_bwd ? kl_launch_scan_bwd_wide(a, s) : KL_ERR_SHAPE);
       const bool wide = e == 0;
+      if (e == KL_ERR_SHAPE && w.scan2_bwd) return KL_ERR_SHAPE;      // (the forward scans wrote gate-interleaved G: planned together, plan_scan2)
       if (e == KL_ERR_SHAPE) {
         a.dZT = nullptr;
         a.db = nullptr;
@@ -948,7 +1021,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       if (e != 0) return e;
       if (l == L - 1) {
         h->trace_persistent[1] = true;
-        h->trace_name[1] = wide ? "lstm_scan_bwd_wide_kernel" : "lstm_scan_bwd_kernel";
+        h->trace_name[1] = w.scan2_bwd ? "lstm_scan_bwd_wide2_kernel" : (wide ? "lstm_scan_bwd_wide_kernel" : "lstm_scan_bwd_kernel");
         h->trace_flops[1] = (double)B * T * (2.0 * W * 4.0 * W);   // one layer's recurrent contraction
         h->trace_end(1, s);
       }

@@ -142,9 +142,21 @@ struct KlScanFwdWide {
   unsigned* status;
   int sentinel;                        // 1: hand-off by data -- H blocks 1..T pre-filled with 0xFFFF halfwords, no counters
   unsigned* xcc_slots; unsigned gen;   // [256] + launch token: XCD-local hand-off if the workgroups of a row group share an XCD (null: off)
+  // second generation (lstm_scan2.hip): P, EK (+ bias), CtxK[0] and G are gate-interleaved ([row][unit][4 gates])
+  const int* ids_tm;                   // [T+1][B][2] byte offsets of the EK / CtxK[0] rows, time-major (kl_launch_ids_tm)
+  int V, ctx_vocab;                    // rows of EK / CtxK[0]
+  int pf_mode;                         // where the next phase's tile is requested: 0 = top of a phase, 1 = behind the MFMA phase
 };
 bool kl_scan_fwd_wide_applicable(int B, int T, int W);
 int kl_launch_scan_fwd_wide(KlScanFwdWide args, hipStream_t stream);
+// second generation: every workgroup serves NP = 2..max_np phases of `rows` (16 or 32) rows per step; 0 = not applicable
+// (forward scans: max_np 4; backward scan, always 16-row blocks: 6)
+int kl_scan_wide2_phases(int B, int T, int W, int rows, int max_np);
+int kl_launch_scan_fwd_wide2(KlScanFwdWide args, int rows, hipStream_t stream);
+int kl_launch_permute_gate_cols_f32(const float* in, const float* bias, float* out, long rows, int W, hipStream_t stream);
+int kl_launch_permute_gate_rows_bf16(const bf16_t* in, bf16_t* out, int W, int K, hipStream_t stream);
+int kl_launch_ids_tm(const int* idx, const int* ctx, int n_ctx, int B, int T, int W, int V, int ctx_vocab, int* out,
+                     hipStream_t stream);
 
 struct KlScanBwd {
   int B, T, W, L;
@@ -162,11 +174,13 @@ struct KlScanBwd {
   float* db;                           // wide one-layer kernel only: += column sums of dZ (bias gradient; null: no)
   int sentinel;                        // wide one-layer kernel only: 1 = hand-off by data sentinels (dZ pre-filled with 0xFFFF halfwords)
   unsigned* xcc_slots; unsigned gen;   // as KlScanFwdWide (sentinel hand-off only)
+  int pf_mode;                         // second generation: as KlScanFwdWide
 };
 int kl_launch_scan_bwd(KlScanBwd args, hipStream_t stream);
 bool kl_scan_bwd_wide_applicable(int B, int T, int W);
 int kl_scan_wide_blocks_per_wg(int B, int W);
 int kl_launch_scan_bwd_wide(KlScanBwd args, hipStream_t stream);   // one layer per launch, 64-unit workgroups
+int kl_launch_scan_bwd_wide2(KlScanBwd args, hipStream_t stream);  // second generation (lstm_scan2.hip): a.G gate-interleaved, rolling sentinels
 
 // thin split-precision contraction C[M,N] = A[M,K] . WT[N,K]^T (+bias) for
 // small M (tables, inference logits)

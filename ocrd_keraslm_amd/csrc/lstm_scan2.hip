@@ -1,0 +1,1048 @@
+// Second generation of the layer-sequential WIDE scans (many streams: two or more row phases per
+// workgroup and step).  Same decomposition as lstm_scan.hip's wide kernels -- one layer per launch,
+// 1024-thread workgroups of 64 hidden units with the recurrent weights resident in registers, the
+// state tile fetched once per workgroup by LDS-DMA and shared, hand-off by data sentinels -- but
+// re-cut around what the stamps of the first generation showed: a 16-row block
+// cost 6600 (forward) / 9500 (backward) cycles of which the MFMA pipe was busy for 1000, the rest
+// being three workgroup barriers, an f32 partial-tile round trip through LDS (the K split over the
+// waves), the wait for a tile that was only requested after the previous block's MFMA phase, and
+// 7-8 small global loads per thread.
+//
+// Forward (lstm_scan_fwd_wide2_kernel):
+//  * no K split: wave w owns ALL of K for the 4 gates x 4 hidden units 4w..4w+3 (16 MFMA columns in
+//    the order unit-major, gate-minor), so a finished accumulator tile holds complete gate
+//    pre-activations; a 4 x 4 transpose inside each lane quad (DPP) turns "4 rows x 1 gate" per
+//    lane into "1 row x 4 gates" and the cell update runs straight on the accumulator registers:
+//    no partial tiles in LDS, one barrier less;
+//  * 32 rows (two row blocks) per phase against the same register-resident weights: barriers, waits
+//    and stores are paid once per 32 rows;
+//  * the state tile is double-buffered in LDS and the next phase's tile is requested at the TOP of a
+//    phase (it was published a whole phase earlier), so it lands behind MFMA phase and epilogue;
+//  * every asynchronous vector-memory operation (tile DMA, gate-input rows, table-row ids) is issued
+//    through inline asm and waited for by COUNT (s_waitcnt vmcnt(n) with n = operations issued
+//    since): nothing ever waits for a younger operation, in particular not for the write-through
+//    publish of the phase before;
+//  * gate-interleaved layouts ([row][unit][4 gates]) for the gate-input rows P, the layer-0 tables
+//    and the stored gate activations G: one 16-byte load / one 8-byte LDS write per cell.
+// Backward (lstm_scan_bwd_wide2_kernel): the K split stays (K = 4W: the partial tiles are small), but the
+// dZ tile is double-buffered and requested a whole block ahead, the cell state is carried in a
+// register from step to step (one load of C per step instead of two), the gates arrive as one
+// 8-byte load, and all loads are counted the same way.
+//
+// Hand-off protocol, sentinel re-arming and the bounded spins are those of lstm_scan.hip.
+#include <stdlib.h>
+#include <string.h>
+
+#include "kl_common.h"
+#include "kl_kernels.h"
+
+namespace {
+
+#define KL_STAMP_ARRAY kl_scan2_stamps
+#include "kl_scan_common.h"
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// ---- asynchronous loads the compiler does not know about (waited for by count, wait_vm) ----
+// The destination registers count as written at the end of the asm statement; every consumer sits
+// behind a wait + "+v" fence (use_regs) so that nothing reads them before the data has landed.
+// The destinations are read-write operands: the caller sets them to all-ones first, which no valid datum is, so
+// that "has landed" can be CHECKED after an optimistic counted wait (a register with a load in flight reads
+// as its old value).
+__device__ __forceinline__ void aload16_glb(u32x4& d, const void* sbase, unsigned voff) {
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void aload8_glb(u32x2& d, const void* sbase, unsigned voff) {
+  asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "+v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void aload4_glb(unsigned& d, const void* sbase, unsigned voff) {
+  asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void aload16_buf(u32x4& d, __amdgpu_buffer_rsrc_t r, unsigned voff) {
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(d) : "v"(voff), "s"(r) : "memory");
+}
+__device__ __forceinline__ void use_regs(u32x4& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void use_regs(u32x2& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void use_regs(unsigned& a) { asm volatile("" : "+v"(a)); }
+
+// LDS-DMA of one 1 KiB tile piece: lane l lands at lds_addr + 16 l; source = lane offset + scalar offset
+__device__ __forceinline__ void glds16_sc1_s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+      : "memory");
+}
+
+// ... as a streaming ("nt") load: served by the XCD's L2 without the coherence actions of an sc1 load -- for partners
+// that were verified to share that L2 (XCD-local hand-off, kl_scan_common.h)
+__device__ __forceinline__ void glds16_nt_s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+      : "memory");
+}
+
+__device__ __forceinline__ float dpp_x1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_x2(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+}
+// lane k of a quad holds m[r] = M[k][r]; afterwards m[r] = M[r][k]
+__device__ __forceinline__ void quad_transpose(f32x4& m, int k) {
+  const bool odd = k & 1, hi = k & 2;
+  {
+    const float s0 = odd ? m[0] : m[1], s1 = odd ? m[2] : m[3];
+    const float r0 = dpp_x1(s0), r1 = dpp_x1(s1);
+    if (odd) { m[0] = r0; m[2] = r1; } else { m[1] = r0; m[3] = r1; }
+  }
+  {
+    const float s0 = hi ? m[0] : m[2], s1 = hi ? m[1] : m[3];
+    const float r0 = dpp_x2(s0), r1 = dpp_x2(s1);
+    if (hi) { m[0] = r0; m[1] = r1; } else { m[2] = r0; m[3] = r1; }
+  }
+}
+
+__device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
+
+// Every LDS landing zone of a DMA is ARMED with 0xFFFFFFFF words before the DMA is issued and checked after the
+// counted wait: the count is a good estimate of "landed", not a proof -- with stores among the younger operations the
+// wait was observed to pass before an older load's data had arrived (B = 1536: a few lanes of the gate-input pieces
+// still held the previous phase's values), and a tile buffer still holds the VALID-looking tile of two phases ago.
+// 0xFFFFFFFF is neither a finite float, nor a pair of finite bf16, nor a table-row offset.
+__device__ __forceinline__ void arm16(unsigned char* p) {
+  *reinterpret_cast<uint4*>(p) = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+}
+// a 16-byte piece of a tile is there once none of its four dwords is all-ones (armed LDS, or the sentinel the
+// producers' buffer was pre-filled with): dword writes are atomic and two finite bf16 never make 0xFFFFFFFF
+__device__ __forceinline__ bool piece_there(const unsigned char* p) {
+  const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+  return max(max(v.x, v.y), max(v.z, v.w)) != 0xFFFFFFFFu;
+}
+__device__ __forceinline__ bool landed16(const unsigned char* p) {      // (re-read on every call)
+  asm volatile("" ::: "memory");
+  const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+  return v.x != 0xFFFFFFFFu && v.y != 0xFFFFFFFFu && v.z != 0xFFFFFFFFu && v.w != 0xFFFFFFFFu;
+}
+
+// ---------------------------------------------------------------- forward
+// LDS map (bytes): tile [2][NB*KSTEPS][1024] | zin [16 waves][NZ][1024] | st_g [ROWS][544] | st_c [ROWS][272] |
+// pub [ROWS][144] | st_hd [ROWS][144] (P mode only) | ids [2][256] (table mode only) | flags.
+// The row strides of the staging buffers are padded so that the epilogue's writes (lane = row-in-4 fastest,
+// then unit) fall on distinct banks.
+constexpr int F2_G_LD = 544, F2_C_LD = 272, F2_H_LD = 144;
+constexpr int fwd2_lds_bytes(int ksteps, int nb, bool tab) {
+  return 2 * nb * ksteps * 1024 + 16 * (tab ? 2 * nb : nb) * 1024 + 16 * nb * (F2_G_LD + F2_C_LD + F2_H_LD) +
+         (tab ? 512 : 16 * nb * F2_H_LD) + 16;
+}
+
+// plain LDS-DMA of one 1 KiB piece (lane l lands at lds_addr + 16 l); source = lane offset into the buffer
+__device__ __forceinline__ void glds16_plain(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(lds_addr)
+      : "memory");
+}
+// ... of 256 bytes (lane l lands at lds_addr + 4 l); source = lane offset + scalar offset
+__device__ __forceinline__ void glds4_plain_s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dword %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+      : "memory");
+}
+
+// NB: row blocks of 16 per phase; NP: phases per workgroup and step (>= 2: while one phase computes, the other's
+// publish travels); TAB: layer 0, gate inputs from the look-up tables instead of P rows.
+// Nothing asynchronous ever lands in a register: tiles, gate-input pieces and table-row ids are all brought in by
+// LDS-DMA and read from LDS behind a counted wait (the compiler is free to move or copy registers it believes to
+// hold data, which it did with asm loads whose data had not landed yet).
+template <int KSTEPS, int NB, int NP, bool TAB>
+__global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide2_kernel(const KlScanFwdWide a) {
+  constexpr int W = KSTEPS * 32;
+  constexpr int NWG_RB = W / 64;
+  constexpr int ROWS = 16 * NB;
+  constexpr int NPIECE = NB * KSTEPS;            // 1 KiB pieces of a phase's tile
+  constexpr int NPC = (NPIECE + 15) / 16;        // ... fetched per wave (at most)
+  constexpr int NZ = TAB ? 2 * NB : NB;          // gate-input pieces per phase and wave
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_rg = a.n_rg, B = a.B, T = a.T;
+  // placement as in the first generation: XCD x = blockIdx % 8 hosts whole row groups (all their column groups)
+  const int xcd = blockIdx.x & 7, yy = blockIdx.x >> 3;
+  const int cg = yy % NWG_RB, rq = yy / NWG_RB, rg = xcd * ((n_rg + 7) >> 3) + rq;
+  if (rg >= n_rg) return;
+  const int u0 = cg * 64;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const zin_l = smem + 2 * NPIECE * 1024;
+  unsigned char* const st_g = zin_l + 16 * NZ * 1024;
+  unsigned char* const st_c = st_g + ROWS * F2_G_LD;
+  unsigned char* const pub = st_c + ROWS * F2_C_LD;
+  unsigned char* const st_hd = pub + ROWS * F2_H_LD;                       // (P mode)
+  unsigned char* const ids_l = pub + ROWS * F2_H_LD;                       // (table mode: [2][256])
+  int& ok_flag = *reinterpret_cast<int*>(pub + ROWS * F2_H_LD + (TAB ? 512 : ROWS * F2_H_LD));
+  const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)smem;
+  const unsigned lds_zin = lds_base + (unsigned)(2 * NPIECE * 1024 + wave * NZ * 1024);      // this wave's landing slots
+  const unsigned lds_ids = lds_base + (unsigned)(ids_l - smem);
+  const unsigned char* const my_zin = zin_l + wave * NZ * 1024 + lane * 16;
+
+  // cell of this lane inside a 16-row block: row 4 (lane >> 4) + (lane & 3), unit 4 wave + ((lane >> 2) & 3)
+  const int jr = lane & 3, a4 = (lane >> 2) & 3, q4 = lane >> 4;
+  const int crow = 4 * q4 + jr, cunit = 4 * wave + a4;
+
+  // ---- resident weights: B fragments of the 16 columns (unit-major, gate-minor), all of K
+  u32x4 bu[KSTEPS];
+  {
+    const int col = lane & 15;
+    const long wrow = ((long)(col & 3) * W + u0 + 4 * wave + (col >> 2)) * W + (lane >> 4) * 8;
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j) bu[j] = *reinterpret_cast<const u32x4*>(a.UT + wrow + j * 32);
+  }
+  // cell state and dropout keep-mask of this lane's cells, per phase and block (phase 0 = the current one: rotated)
+  float cst[NP][NB];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+      const long row = (long)(rg + p * n_rg) * ROWS + s * 16 + crow;
+      cst[p][s] = a.C[row * W + u0 + cunit];
+    }
+  const long BW = (long)B * W;
+  const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(a.H, (long)(T + 1) * BW * 2);
+  const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(a.C, (long)(T + 1) * BW * 4);
+  const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.G, (long)T * BW * 4 * 2);
+  const __amdgpu_buffer_rsrc_t rs_hd = make_rsrc(a.Hd, a.Hd ? (long)T * BW * 2 : 0);          // zero records: stores dropped
+  const __amdgpu_buffer_rsrc_t rs_ek = make_rsrc(a.EK, TAB ? (long)a.V * 4 * W * 4 : 0);
+  const __amdgpu_buffer_rsrc_t rs_ck = make_rsrc(a.CtxK[0], (TAB && a.n_ctx > 0) ? (long)a.ctx_vocab * 4 * W * 4 : 0);   // (no context: zeros land)
+  const __amdgpu_buffer_rsrc_t rs_id = make_rsrc(a.ids_tm, TAB ? (long)(T + 1) * B * 8 : 0);
+  const bool has_ctx = TAB && a.n_ctx > 0;
+  unsigned* status = a.status;
+  bool alive = true;
+  if (tid == 0) ok_flag = 1;
+  // the compiler's own loads end here: everything it knows about has landed before the first asm operation
+  // is issued, so it never places a wait of its own inside the loop
+#pragma unroll
+  for (int j = 0; j < KSTEPS; ++j) asm volatile("" : "+v"(bu[j]));
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int s = 0; s < NB; ++s) asm volatile("" : "+v"(cst[p][s]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // XCD-local hand-off (opt-in): plain publishes that stay in the shared L2 + streaming tile loads, if all column groups
+  // of this row group were verified to sit on this workgroup's XCD
+  bool local = false;
+  if (a.xcc_slots)
+    local = __builtin_amdgcn_readfirstlane(
+                xcd_local_group(a.xcc_slots, a.gen, NWG_RB, [&](int j) { return xcd + 8 * (rq * NWG_RB + j); }, &ok_flag + 1, status) ? 1 : 0) != 0;
+  SSTAMP_INIT(0);
+
+  // vector-memory queue of this wave: vq counts the operations issued so far, seq_x = vq right after x was
+  // issued; "x has landed" = s_waitcnt vmcnt(vq - seq_x)
+  int vq = 0, seq_tile[2] = {0, 0}, seq_z = 0, seq_id = 0;
+  // Tile image in LDS: one 1 KiB piece = one ROW of the tile (W = 512 bf16), fetched by ONE fully coalesced DMA
+  // instruction (8 whole cache lines; the fragment-order image of the first generation asked the address unit for
+  // 64 different lines of which it used 16 bytes each, and the scans ran at ~10 bytes per clock and CU).  The
+  // MFMA fragment reads (lane = row l & 15, k group l >> 4) would then meet on one bank group, so the 16-byte
+  // chunks of row r are XOR-swizzled AT THE SOURCE: lane l fetches chunk l ^ (r & 15) and lands at position l,
+  // i.e. chunk c sits at position c ^ r -- conflict-free for every 16-lane group the LDS serves together.
+  static_assert(KSTEPS == 16, "one tile row = one 1 KiB DMA piece");
+  const unsigned dma_lane = (unsigned)(((lane ^ (wave & 15)) * 16));
+  auto issue_tile = [&](int t, int r0, int buf) {      // tile = H block t (the state before step t), rows r0 .. r0 + ROWS
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) {
+      const int p = wave + 16 * k;
+      if (p < NPIECE) arm16(smem + (buf * NPIECE + p) * 1024 + lane * 16);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) {
+      const int p = wave + 16 * k;                     // row p of the phase (p & 15 == wave)
+      if (p < NPIECE) {
+        const unsigned soff = (unsigned)((((long)t * B + r0 + p) * W) * 2);
+        if (local) glds16_nt_s(rs_h, dma_lane, soff, lds_base + (unsigned)((buf * NPIECE + p) * 1024));
+        else glds16_sc1_s(rs_h, dma_lane, soff, lds_base + (unsigned)((buf * NPIECE + p) * 1024));
+        ++vq;
+      }
+    }
+    seq_tile[buf] = vq;
+  };
+  // lane part of the fragment address of k-step j: chunk 4 j + g of row r at position chunk ^ r, i.e.
+  // frag_lane ^ (64 (j & 3)) + 256 (j >> 2) with frag_lane = 1024 r + 16 (g ^ (r & 3)) + 64 ((r >> 2) & 3)
+  const unsigned frag_lane = (unsigned)((lane & 15) * 1024 + (((lane >> 4) ^ (lane & 3)) * 16) + 64 * ((lane >> 2) & 3));
+  // gate-input pieces of a phase: P mode = this lane's 16 bytes (4 gates) of each block's P rows; table mode = EK row +
+  // context row pieces, addressed through the ids in LDS
+  const unsigned z_lane = (unsigned)((crow * 4 * W + (u0 + cunit) * 4) * 4);
+  const unsigned tab_lane = (unsigned)((u0 + cunit) * 16);
+  auto issue_ids = [&](int t, int r0, int slot) {       // (wave 0: the 256 bytes of (EK, context) row offsets from row r0 of block t on)
+    if (wave == 0) {
+      *reinterpret_cast<unsigned*>(ids_l + slot * 256 + lane * 4) = 0xFFFFFFFFu;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      glds4_plain_s(rs_id, (unsigned)(lane * 4), (unsigned)(((long)t * B + r0) * 8), lds_ids + (unsigned)(slot * 256));
+      ++vq;
+      seq_id = vq;
+    }
+  };
+  auto issue_zin = [&](int t, int r0, int slot) {
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) arm16(const_cast<unsigned char*>(my_zin) + i * 1024);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (TAB) {
+#pragma unroll
+      for (int s = 0; s < NB; ++s) {
+        const uint2 idv = *reinterpret_cast<const uint2*>(ids_l + slot * 256 + (s * 16 + crow) * 8);
+        glds16_plain(rs_ek, idv.x + tab_lane, lds_zin + (unsigned)((2 * s) * 1024));
+        ++vq;
+        if (has_ctx) {      // (an out-of-range LDS-DMA writes nothing: without a context variable there is no second piece)
+          glds16_plain(rs_ck, idv.y + tab_lane, lds_zin + (unsigned)((2 * s + 1) * 1024));
+          ++vq;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < NB; ++s) {
+        const __amdgpu_buffer_rsrc_t rs_p = make_rsrc(a.P + ((long)t * B + r0 + s * 16) * 4 * W, (long)16 * 4 * W * 4);
+        glds16_plain(rs_p, z_lane, lds_zin + (unsigned)(s * 1024));
+        ++vq;
+      }
+    }
+    seq_z = vq;
+  };
+
+  // all pieces of this wave's gate inputs have landed (checked, not assumed: see arm16)
+  auto zin_landed = [&]() {
+    bool ok = false;
+    for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
+      bool v = true;
+#pragma unroll
+      for (int i = 0; i < NZ; ++i)
+        if (!TAB || (i & 1) == 0 || has_ctx) v = v && landed16(my_zin + i * 1024);
+      if (__all(v)) { ok = true; break; }
+#ifdef KL_STAMP
+      if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[13] += 1;
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (!ok) { __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok_flag = 0; }
+  };
+
+  // ---- prologue: tile and gate inputs of the first phase; (tables) ids of the first two phases
+  {
+    const int r0 = rg * ROWS;
+    issue_tile(0, r0, 0);
+    if (a.pf_mode == 2) issue_tile(0, (rg + n_rg) * ROWS, 1);      // (NP >= 2: the second phase is another row group of step 0)
+    if (TAB) {
+      issue_ids(0, r0, 0);
+      issue_ids(0, (rg + n_rg) * ROWS, 1);      // (NP >= 2: the second phase is another row group of step 0)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    issue_zin(0, r0, 0);
+  }
+
+  int n = 0;
+  for (int t = 0; t < T; ++t) {
+#pragma unroll 1
+    for (int ip = 0; ip < NP; ++ip, ++n) {
+      const int buf = n & 1;
+      const int r0 = (rg + ip * n_rg) * ROWS;
+      // the phase after this one, and the one after that
+      int t1 = t, ip1 = ip + 1;
+      if (ip1 >= NP) { ip1 = 0; t1 = t + 1; }
+      int t2 = t1, ip2 = ip1 + 1;
+      if (ip2 >= NP) { ip2 = 0; t2 = t1 + 1; }
+      const int r1 = (rg + ip1 * n_rg) * ROWS, r2 = (rg + ip2 * n_rg) * ROWS;
+      SSTAMP(0);
+      // dropout keep-masks of this phase's cells (constant over the steps, served by L2): asm loads of this iteration,
+      // consumed in the epilogue (no younger stores between: the count is exact)
+      unsigned mkin[NB];
+      int seq_mk = 0;
+#pragma unroll
+      for (int s = 0; s < NB; ++s) mkin[s] = 0x3f800000u;      // (1.0f)
+      if (!TAB && a.mask) {
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+          aload4_glb(mkin[s], a.mask + ((long)r0 + s * 16) * W, (unsigned)((crow * W + u0 + cunit) * 4));
+          ++vq;
+        }
+        seq_mk = vq;
+      }
+      // ---- request the next phase's tile (its rows were published a whole phase ago), then wait for this one's
+      // Where the next tile is requested (a.pf_mode): 0 = here, a phase ahead; 1 = behind this phase's MFMAs; 2 = TWO
+      // phases ahead, behind the barrier after the MFMAs of the phase that last read its buffer (NP >= 3: the rows were
+      // published at least a phase before) -- the request then also sits in front of this phase's stores in the queue.
+      if (a.pf_mode == 0 && alive && t1 < T) issue_tile(t1, r1, buf ^ 1);
+      if (alive) {
+        wait_vm(vq - seq_tile[buf]);
+        SSTAMP(8);
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NPC; ++k) {
+          const int p = wave + 16 * k;
+          if (p < NPIECE) ok = ok && piece_there(smem + (buf * NPIECE + p) * 1024 + lane * 16);
+        }
+        ok = __all(ok);
+        if (!ok) {
+          // a producer was late: re-fetch this wave's pieces until all their granules are there (bounded)
+#ifdef KL_STAMP
+          if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[12] += 1;
+#endif
+          for (unsigned spin = 0; spin < SPIN_LIMIT && !ok; ++spin) {
+#pragma unroll
+            for (int k = 0; k < NPC; ++k) {
+              const int p = wave + 16 * k;
+              if (p < NPIECE && spin > 0) {       // (first round: only wait until everything issued has landed)
+                const unsigned soff = (unsigned)((((long)t * B + r0 + p) * W) * 2);
+                if (local) glds16_nt_s(rs_h, dma_lane, soff, lds_base + (unsigned)((buf * NPIECE + p) * 1024));
+                else glds16_sc1_s(rs_h, dma_lane, soff, lds_base + (unsigned)((buf * NPIECE + p) * 1024));
+                ++vq;
+              }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ok = true;
+#pragma unroll
+            for (int k = 0; k < NPC; ++k) {
+              const int p = wave + 16 * k;
+              if (p < NPIECE) ok = ok && piece_there(smem + (buf * NPIECE + p) * 1024 + lane * 16);
+            }
+            ok = __all(ok);
+            if (!ok) {
+              if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+              __builtin_amdgcn_s_sleep(2);
+            }
+          }
+          if (!ok) {
+            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok_flag = 0;
+          }
+        }
+      }
+      if (TAB && wave == 0) {      // the ids the waves will read behind the next barrier have landed (slot of phase n + 1)
+        wait_vm(vq - seq_id);
+        if (t1 < T) {
+          bool ok = false;
+          for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
+            asm volatile("" ::: "memory");
+            const unsigned v = *reinterpret_cast<const unsigned*>(ids_l + ((n + 1) & 1) * 256 + lane * 4);
+            if (__all(v != 0xFFFFFFFFu || lane * 4 >= ROWS * 8)) { ok = true; break; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          if (!ok) { __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok_flag = 0; }
+        }
+      }
+      SSTAMP(1);
+      __syncthreads();
+      SSTAMP(2);
+      alive = __builtin_amdgcn_readfirstlane(ok_flag) != 0;
+      // ---- MFMA phase: NB row blocks against the resident weights, all of K
+      // The gate inputs of this phase (requested a whole phase ago) start the accumulators, in the MFMA's own layout (the
+      // quad transpose is its own inverse); their landing slots are free again at once, so the next phase's pieces are
+      // requested here, a whole phase ahead (table mode: through the ids in LDS; wave 0 then fetches the ids of the
+      // phase after that)
+      f32x4 acc[NB];
+      wait_vm(vq - seq_z);
+      zin_landed();
+#pragma unroll
+      for (int s = 0; s < NB; ++s) {
+        if (TAB) {
+          acc[s] = *reinterpret_cast<const f32x4*>(my_zin + (2 * s) * 1024);
+          if (has_ctx) acc[s] += *reinterpret_cast<const f32x4*>(my_zin + (2 * s + 1) * 1024);
+        } else {
+          acc[s] = *reinterpret_cast<const f32x4*>(my_zin + s * 1024);
+        }
+        quad_transpose(acc[s], jr);
+      }
+      asm volatile("" : "+v"(acc[0]));
+      if (NB > 1) asm volatile("" : "+v"(acc[NB - 1]));
+      if (t1 < T) issue_zin(t1, r1, (n + 1) & 1);
+      if (TAB && t2 < T) issue_ids(t2, r2, n & 1);      // (slot of this phase's ids: every wave read them a phase ago)
+      {
+        // k-steps in the order j = 4 (q & 3) + (q >> 2), q = 0..15: one lane address per group of four; the fragments of
+        // step q + 1 are requested before the MFMAs of step q (pinned: left alone, the compiler serialised read -> wait ->
+        // MFMA on a single fragment buffer)
+        const unsigned char* tb = smem + buf * NPIECE * 1024;
+        u32x4 fr[2][NB];
+#pragma unroll
+        for (int s = 0; s < NB; ++s) fr[0][s] = *reinterpret_cast<const u32x4*>(tb + frag_lane + s * 16 * 1024);
+#pragma unroll
+        for (int q = 0; q < KSTEPS; ++q) {
+          if (q + 1 < KSTEPS) {
+            const int q1 = q + 1;
+            const unsigned char* ap = tb + (frag_lane ^ (unsigned)(64 * (q1 >> 2))) + 256 * (q1 & 3);
+#pragma unroll
+            for (int s = 0; s < NB; ++s) fr[q1 & 1][s] = *reinterpret_cast<const u32x4*>(ap + s * 16 * 1024);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8 fb = __builtin_bit_cast(bf16x8, bu[4 * (q & 3) + (q >> 2)]);
+#pragma unroll
+          for (int s = 0; s < NB; ++s) acc[s] = mfma16(__builtin_bit_cast(bf16x8, fr[q & 1][s]), fb, acc[s]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      SSTAMP(3);
+      if (a.pf_mode == 1 && alive && t1 < T) issue_tile(t1, r1, buf ^ 1);     // (its buffer was last read a phase ago)
+      // ---- epilogue on the accumulators: lane = (row, unit), registers = gates
+#pragma unroll
+      for (int s = 0; s < NB; ++s) quad_transpose(acc[s], jr);
+      float z[NB][4];
+#pragma unroll
+      for (int s = 0; s < NB; ++s)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) z[s][g] = acc[s][g];
+      SSTAMP(4);
+      if (!TAB && a.mask) {
+        wait_vm(vq - seq_mk);
+#pragma unroll
+        for (int s = 0; s < NB; ++s) use_regs(mkin[s]);
+      }
+#pragma unroll
+      for (int s = 0; s < NB; ++s) {
+        const float gi = fast_sigmoid(z[s][0]), gf = fast_sigmoid(z[s][1]), gg = fast_tanh(z[s][2]), go = fast_sigmoid(z[s][3]);
+        const float c = gf * cst[0][s] + gi * gg;
+        cst[0][s] = c;
+        const float h = go * fast_tanh(c);
+        const int row = s * 16 + crow;
+        *reinterpret_cast<bf16_t*>(pub + row * F2_H_LD + cunit * 2) = f2bf(h);
+        if (!TAB) *reinterpret_cast<bf16_t*>(st_hd + row * F2_H_LD + cunit * 2) = f2bf(h * u2f(mkin[s]));
+        *reinterpret_cast<float*>(st_c + row * F2_C_LD + cunit * 4) = c;
+        uint2 gp;
+        gp.x = (unsigned)f2bf(gi) | ((unsigned)f2bf(gf) << 16);
+        gp.y = (unsigned)f2bf(gg) | ((unsigned)f2bf(go) << 16);
+        *reinterpret_cast<uint2*>(st_g + row * F2_G_LD + cunit * 8) = gp;
+      }
+      SSTAMP(5);
+      __syncthreads();
+      SSTAMP(6);
+      if (a.pf_mode == 2 && alive && t2 < T) issue_tile(t2, r2, buf);       // (every wave has finished this phase's MFMAs)
+      // ---- stores: the publish first (write-through, whole 128-byte lines per row), then what only later launches read
+      {
+        int stid = tid;
+        asm volatile("" : "+v"(stid));
+        const unsigned trow = (unsigned)(t * B + r0);          // first time-major row of this phase
+        if (wave < 2 * NB) {       // h[t] -> H block t + 1: ROWS x 8 pieces of 8 units
+          const int prow = stid >> 3, seg = stid & 7;
+          const uint4 v = *reinterpret_cast<const uint4*>(pub + prow * F2_H_LD + seg * 16);
+          const unsigned off = (unsigned)((prow * W + seg * 8) * 2) + ((trow + B) * W + u0) * 2u;
+          if (!alive) store16(make_rsrc(a.H, 0), 0u, 0u, v);
+          else if (local) store16(rs_h, off, 0u, v);        // stays in this XCD's L2, where all its readers are
+          else store16_sc1(rs_h, off, v);
+          ++vq;
+        }
+        if (NB == 2 || wave >= 2) {
+          // gates: ROWS x 32 pieces (2 units x 4 gates); NB == 1: waves 2..9
+          const int q = NB == 2 ? stid : stid - 128;
+          if (NB == 2 || q < 512) {
+            const int prow = q >> 5, seg = q & 31;
+            store16(rs_g, (unsigned)((prow * W * 4 + seg * 8) * 2), (trow * W + u0) * 8u,
+                    *reinterpret_cast<const uint4*>(st_g + prow * F2_G_LD + seg * 16));
+            ++vq;
+          }
+        }
+        {
+          // cell state (ROWS x 16 pieces of 4 units) and masked outputs (ROWS x 8 pieces of 8 units)
+          const int cq = NB == 2 ? stid - 256 : stid - 640;          // NB == 2: waves 4..11, NB == 1: waves 10..13
+          const int hq = NB == 2 ? stid - 768 : stid - 896;          // NB == 2: waves 12..15, NB == 1: waves 14..15
+          const int wv_c0 = NB == 2 ? 4 : 10, wv_c1 = NB == 2 ? 12 : 14;
+          if (wave >= wv_c0 && wave < wv_c1) {
+            const int prow = cq >> 4, seg = cq & 15;
+            store16(rs_c, (unsigned)((prow * W + seg * 4) * 4), ((trow + B) * W + u0) * 4u,
+                    *reinterpret_cast<const uint4*>(st_c + prow * F2_C_LD + seg * 16));
+            ++vq;
+          } else if (!TAB && wave >= wv_c1) {
+            const int prow = hq >> 3, seg = hq & 7;
+            store16(rs_hd, (unsigned)((prow * W + seg * 8) * 2), (trow * W + u0) * 2u,
+                    *reinterpret_cast<const uint4*>(st_hd + prow * F2_H_LD + seg * 16));
+            ++vq;
+          }
+        }
+      }
+      SSTAMP(7);
+      // the next phase's cells move to slot 0
+      if (NP > 1) {
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+          const float c0 = cst[0][s];
+#pragma unroll
+          for (int p = 0; p + 1 < NP; ++p) cst[p][s] = cst[p + 1][s];
+          cst[NP - 1][s] = c0;
+        }
+      }
+    }
+  }
+  SSTAMP_FLUSH();
+}
+
+}  // namespace
+
+namespace {
+
+// ---------------------------------------------------------------- backward
+// LDS map (bytes): tile [2][4*KSTEPS][1024] | zt [16 waves][16][17] f32 | pub [4 gates][16 rows][64 units] bf16 | flags
+constexpr int bwd2_lds_bytes(int ksteps) { return 2 * 4 * ksteps * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16; }
+
+// One layer, 16-row blocks, NP blocks per workgroup and step (2..4).  Wave = (K quarter = gate kq4, unit group ug):
+// dh_rec[16 x 16] = dZ[t+1][16 x W(gate kq4)] . Un[W(gate kq4) x 16 units]; the four gate partials meet in LDS.
+// a.G is gate-interleaved ([row][unit][4]); dZ leaves gate-major as before (the GEMMs behind it are unchanged).
+// Rolling sentinels (a.sentinel == 2) as in the first generation: the publishing lanes re-arm step t - 2 while they store
+// step t.  The re-arming store has completed before the same lanes publish step t - 1: a whole step of NP >= 2 blocks
+// lies between them, and the counted tile wait at the top of the block after next covers every store of this one.
+// Registers v124..v127 are kept out of the compiler's hands (amdgpu_num_vgpr(120) asks for it, tools/audit_async_regs.py
+// checks the generated code -- the attribute alone did not stop hipcc from using v120/v121 in the six-block variant): the epilogue inputs of the NEXT block (gates 8
+// bytes, c_{t-1} and dh 4 bytes each) land there, requested half a block ahead -- an HBM round trip
+// under this load takes ~3500 cycles -- and are moved into compiler registers behind the counted wait.  (As ordinary
+// asm outputs carried around the loop they were copied by the compiler at the loop head before the data had landed.)
+#define KL_B2_IN_REGS "v124", "v125", "v126", "v127"
+template <int KSTEPS, int NP>
+__global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(120))) void lstm_scan_bwd_wide2_kernel(const KlScanBwd a) {
+  constexpr int W = KSTEPS * 32;
+  constexpr int NWG_RB = W / 64;
+  constexpr int JW = KSTEPS / 4;          // tile pieces per wave
+  constexpr int NPIECE = 4 * KSTEPS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq4 = wave & 3, ug = wave >> 2;
+  const int n_rg = a.n_rg, B = a.B, T = a.T;
+  const int xcd = blockIdx.x & 7, yy = blockIdx.x >> 3;
+  const int cg = yy % NWG_RB, rq = yy / NWG_RB, rg = xcd * ((n_rg + 7) >> 3) + rq;
+  if (rg >= n_rg) return;
+  const int u0 = cg * 64;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float (*zt)[16][17] = reinterpret_cast<float (*)[16][17]>(smem + 2 * NPIECE * 1024);
+  bf16_t* pub = reinterpret_cast<bf16_t*>(smem + 2 * NPIECE * 1024 + 16 * 16 * 17 * 4);
+  int& ok_flag = *reinterpret_cast<int*>(smem + 2 * NPIECE * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2);
+  const unsigned lds_tile = (unsigned)(size_t)(lds_void_t*)smem;
+
+  u32x4 bu[KSTEPS];
+  {
+    const long wrow = (long)(u0 + ug * 16 + (lane & 15)) * 4 * W + (long)kq4 * W + (lane >> 4) * 8;
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j) bu[j] = *reinterpret_cast<const u32x4*>(a.Un[0] + wrow + j * 32);
+  }
+  const int er = wave, eu = lane;                  // epilogue thread = (row = wave: scalar, unit of 64)
+  const long BW = (long)B * W;
+  const bf16_t* Gl = a.G[0];
+  const float* Cl = a.C[0];
+  bf16_t* dZl = a.dZ[0];
+  const float* dH = a.dH;
+  const float* maskl = a.mask[0];
+  unsigned* status = a.status;
+  // per block of this workgroup (slot 0 = the current one: rotated): running dc, the cell state c_t of the step
+  // being processed (the c_{t-1} loaded for step t is the c_t of step t-1), the dropout mask on dH
+  float dcr[NP], ccur[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const long row = (long)(rg + p * n_rg) * 16 + er;
+    dcr[p] = 0.f;
+    ccur[p] = Cl[(long)T * BW + row * W + u0 + eu];
+  }
+  float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+  const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(dZl, (long)T * BW * 4 * 2);
+  const __amdgpu_buffer_rsrc_t rs_null = make_rsrc(dZl, 0);
+  bool alive = true;
+  if (tid == 0) ok_flag = 1;
+#pragma unroll
+  for (int j = 0; j < KSTEPS; ++j) asm volatile("" : "+v"(bu[j]));
+#pragma unroll
+  for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(ccur[p]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  bool local = false;      // XCD-local hand-off (opt-in), as in the forward scan
+  if (a.xcc_slots)
+    local = __builtin_amdgcn_readfirstlane(
+                xcd_local_group(a.xcc_slots, a.gen, NWG_RB, [&](int j) { return xcd + 8 * (rq * NWG_RB + j); }, &ok_flag + 1, status) ? 1 : 0) != 0;
+  SSTAMP_INIT(0);
+
+  int vq = 0, seq_tile[2] = {0, 0}, seq_in = 0;
+  // Tile image in LDS: piece (gate quarter q, row r) = the 1 KiB of row r's quarter q, one fully coalesced DMA
+  // instruction each, its 16-byte chunks XOR-swizzled at the source (chunk c at position c ^ r: see the forward
+  // scan).  Wave w fetches the four quarters of row w: 4 KiB contiguous.
+  static_assert(KSTEPS == 16, "one quarter of a tile row = one 1 KiB DMA piece");
+  const unsigned dma_lane = (unsigned)((lane ^ wave) * 16);
+  const unsigned frag_lane = (unsigned)((lane & 15) * 1024 + (((lane >> 4) ^ (lane & 3)) * 16) + 64 * ((lane >> 2) & 3));
+  auto issue_tile = [&](int t, int r0, int buf) {      // tile = dZ[t + 1], rows r0 .. r0 + 16, this wave's row
+#pragma unroll
+    for (int j = 0; j < JW; ++j) arm16(smem + (buf * NPIECE + j * 16 + wave) * 1024 + lane * 16);      // (see arm16)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < JW; ++j) {
+      const int p = j * 16 + wave;                      // (quarter j, row wave)
+      const unsigned soff = (unsigned)((((long)(t + 1) * B + r0 + wave) * 4 * W + (long)j * W) * 2);
+      if (local) glds16_nt_s(rs_own, dma_lane, soff, lds_tile + (unsigned)((buf * NPIECE + p) * 1024));
+      else glds16_sc1_s(rs_own, dma_lane, soff, lds_tile + (unsigned)((buf * NPIECE + p) * 1024));
+      ++vq;
+    }
+    seq_tile[buf] = vq;
+  };
+  // epilogue inputs of a block (gates 8 bytes, c_{t-1} and dh 4 bytes each): asm loads into registers, issued at
+  // the top of the block they belong to and consumed behind its MFMA phase.  They are NOT carried around the loop:
+  // a loop-carried asm destination was copied by the compiler at the loop head before its data had landed.
+  const unsigned in_lane4 = (unsigned)((u0 + eu) * 4);
+  auto issue_inputs = [&](int t, int r0) {
+    const long trow = (long)t * B + r0 + er;
+    asm volatile("v_mov_b32 v124, -1\n\tv_mov_b32 v125, -1\n\tv_mov_b32 v126, -1\n\tv_mov_b32 v127, -1\n\t"
+                 "s_nop 4\n\tglobal_load_dwordx2 v[124:125], %0, %1"
+                 :: "v"(in_lane4 * 2), "s"(Gl + trow * W * 4) : "memory", KL_B2_IN_REGS);
+    asm volatile("s_nop 4\n\tglobal_load_dword v126, %0, %1" :: "v"(in_lane4), "s"(Cl + trow * W) : "memory", KL_B2_IN_REGS);
+    asm volatile("s_nop 4\n\tglobal_load_dword v127, %0, %1" :: "v"(in_lane4), "s"(dH + trow * W) : "memory", KL_B2_IN_REGS);
+    vq += 3;
+    seq_in = vq;
+  };
+  issue_inputs(T - 1, rg * 16);
+
+  int n = 0;
+  for (int t = T - 1; t >= 0; --t) {
+#pragma unroll 1
+    for (int ip = 0; ip < NP; ++ip, ++n) {
+      const int buf = n & 1;
+      const int r0 = (rg + ip * n_rg) * 16;
+      int t1 = t, ip1 = ip + 1;
+      if (ip1 >= NP) { ip1 = 0; t1 = t - 1; }
+      int t2 = t1, ip2 = ip1 + 1;
+      if (ip2 >= NP) { ip2 = 0; t2 = t1 - 1; }
+      const int r1 = (rg + ip1 * n_rg) * 16, r2 = (rg + ip2 * n_rg) * 16;
+      SSTAMP(16);
+      // dropout keep-mask on dH (top layer; constant over the steps, served by L2): an asm load of THIS iteration into an
+      // armed compiler register, consumed behind the MFMA phase
+      unsigned mkin = maskl ? 0xFFFFFFFFu : 0x3f800000u;      // (no mask: 1.0f)
+      int seq_mk = 0;
+      if (maskl) {
+        aload4_glb(mkin, maskl + (long)(r0 + er) * W, in_lane4);
+        ++vq;
+        seq_mk = vq;
+      }
+      if (a.pf_mode == 0 && alive && t1 >= 0 && t1 < T - 1) issue_tile(t1, r1, buf ^ 1);       // (a.pf_mode: see the forward scan)
+      if (alive && t < T - 1) {
+        wait_vm(vq - seq_tile[buf]);
+        SSTAMP(25);
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < JW; ++j)
+          ok = ok && piece_there(smem + (buf * NPIECE + j * 16 + wave) * 1024 + lane * 16);
+        ok = __all(ok);
+        if (!ok) {
+#ifdef KL_STAMP
+          if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[28] += 1;
+#endif
+          for (unsigned spin = 0; spin < SPIN_LIMIT && !ok; ++spin) {
+#pragma unroll
+            for (int j = 0; j < JW; ++j) {
+              if (spin == 0) break;                 // (first round: only wait until everything issued has landed)
+              const int p = j * 16 + wave;
+              const unsigned soff = (unsigned)((((long)(t + 1) * B + r0 + wave) * 4 * W + (long)j * W) * 2);
+              if (local) glds16_nt_s(rs_own, dma_lane, soff, lds_tile + (unsigned)((buf * NPIECE + p) * 1024));
+              else glds16_sc1_s(rs_own, dma_lane, soff, lds_tile + (unsigned)((buf * NPIECE + p) * 1024));
+              ++vq;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ok = true;
+#pragma unroll
+            for (int j = 0; j < JW; ++j)
+              ok = ok && piece_there(smem + (buf * NPIECE + j * 16 + wave) * 1024 + lane * 16);
+            ok = __all(ok);
+            if (!ok) {
+              if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+              __builtin_amdgcn_s_sleep(2);
+            }
+          }
+          if (!ok) {
+            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok_flag = 0;
+          }
+        }
+      }
+      SSTAMP(17);
+      __syncthreads();
+      SSTAMP(18);
+      alive = __builtin_amdgcn_readfirstlane(ok_flag) != 0;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < T - 1) {
+        // (k-step order and read-ahead as in the forward scan)
+        const unsigned char* tb = smem + (buf * NPIECE + kq4 * 16) * 1024;
+        u32x4 fr[2];
+        fr[0] = *reinterpret_cast<const u32x4*>(tb + frag_lane);
+#pragma unroll
+        for (int q = 0; q < KSTEPS; ++q) {
+          if (q + 1 < KSTEPS) {
+            const int q1 = q + 1;
+            fr[q1 & 1] = *reinterpret_cast<const u32x4*>(tb + (frag_lane ^ (unsigned)(64 * (q1 >> 2))) + 256 * (q1 & 3));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc = mfma16(__builtin_bit_cast(bf16x8, fr[q & 1]), __builtin_bit_cast(bf16x8, bu[4 * (q & 3) + (q >> 2)]), acc);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zt[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+      SSTAMP(19);
+      __syncthreads();
+      SSTAMP(20);
+      if (a.pf_mode == 1 && alive && t1 >= 0 && t1 < T - 1) issue_tile(t1, r1, buf ^ 1);     // (its buffer was last read a block ago)
+      if (a.pf_mode == 2 && alive && t2 >= 0 && t2 < T - 1) issue_tile(t2, r2, buf);         // (every wave has finished this block's MFMAs)
+      // ---- epilogue: thread = (row er, unit eu)
+      // this block's inputs (requested behind the epilogue of the block before); loads and stores retire independently,
+      // so the count is an estimate: the registers were armed with all-ones, which no valid datum is, and are checked
+      wait_vm(vq - seq_in);
+      u32x2 gin;
+      unsigned cpin, dhin;
+      asm volatile("v_mov_b32 %0, v124\n\tv_mov_b32 %1, v125\n\tv_mov_b32 %2, v126\n\tv_mov_b32 %3, v127"
+                   : "=v"(gin.x), "=v"(gin.y), "=v"(cpin), "=v"(dhin));
+      if (maskl) {
+        wait_vm(vq - seq_mk);
+        use_regs(mkin);
+      }
+      if (__any(max(max(gin.x, gin.y), max(cpin, max(dhin, mkin))) == 0xFFFFFFFFu)) {
+#ifdef KL_STAMP
+        if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[29] += 1;
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("v_mov_b32 %0, v124\n\tv_mov_b32 %1, v125\n\tv_mov_b32 %2, v126\n\tv_mov_b32 %3, v127"
+                     : "=v"(gin.x), "=v"(gin.y), "=v"(cpin), "=v"(dhin));
+        use_regs(mkin);
+      }
+      if (t1 >= 0) issue_inputs(t1, r1);       // (v124..v127 are free again)
+      const float gi = bf2f((bf16_t)(gin.x & 0xffffu)), gf = bf2f((bf16_t)(gin.x >> 16));
+      const float gg = bf2f((bf16_t)(gin.y & 0xffffu)), go = bf2f((bf16_t)(gin.y >> 16));
+      const float cp = u2f(cpin);
+      float dh = u2f(dhin);
+      SSTAMP(21);
+      const int wz = (eu >> 4) * 4;      // the four K-quarter waves of this unit group
+      dh = dh * u2f(mkin) + (zt[wz][er][eu & 15] + zt[wz + 1][er][eu & 15] + zt[wz + 2][er][eu & 15] + zt[wz + 3][er][eu & 15]);
+      const float tc = fast_tanh(ccur[0]);
+      const float dc = dh * go * (1.f - tc * tc) + dcr[0];
+      dcr[0] = dc * gf;
+      ccur[0] = cp;
+      const float d_o = dh * tc, d_i = dc * gg, d_g = dc * gi, d_f = dc * cp;
+      const unsigned z0 = f2bf(d_i * gi * (1.f - gi)), z1 = f2bf(d_f * gf * (1.f - gf));
+      const unsigned z2 = f2bf(d_g * (1.f - gg * gg)), z3 = f2bf(d_o * go * (1.f - go));
+      if (alive) {
+        dbacc[0] += bf2f((bf16_t)z0); dbacc[1] += bf2f((bf16_t)z1); dbacc[2] += bf2f((bf16_t)z2); dbacc[3] += bf2f((bf16_t)z3);
+      }
+      pub[(0 * 16 + er) * 64 + eu] = (bf16_t)z0;
+      pub[(1 * 16 + er) * 64 + eu] = (bf16_t)z1;
+      pub[(2 * 16 + er) * 64 + eu] = (bf16_t)z2;
+      pub[(3 * 16 + er) * 64 + eu] = (bf16_t)z3;
+      SSTAMP(22);
+      __syncthreads();
+      SSTAMP(23);
+      // ---- publish dZ[t] (eight waves, one 16-byte write-through store per lane) and re-arm step t - 2
+      if (wave < 8) {
+        int stid = tid;
+        asm volatile("" : "+v"(stid));
+        const int g = stid >> 7, prow = (stid >> 3) & 15, seg = stid & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(pub + (g * 16 + prow) * 64 + seg * 8);
+        const unsigned off = (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2);
+        const unsigned soff = off - (unsigned)((long)2 * B * 4 * W * 2);
+        const uint4 ones = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (local) {      // plain stores: they stay in this XCD's L2, where all their readers are
+          store16(alive ? rs_own : rs_null, off, 0u, v);
+          store16((alive && t >= 2) ? rs_own : rs_null, soff, 0u, ones);
+        } else {
+          store16_sc1(alive ? rs_own : rs_null, off, v);
+          store16_sc1((alive && t >= 2) ? rs_own : rs_null, soff, ones);      // (a null buffer drops the store, the count stays)
+        }
+        vq += 2;
+      }
+      SSTAMP(24);
+      if (NP > 1) {
+        const float d0 = dcr[0], c0 = ccur[0];
+#pragma unroll
+        for (int p = 0; p + 1 < NP; ++p) { dcr[p] = dcr[p + 1]; ccur[p] = ccur[p + 1]; }
+        dcr[NP - 1] = d0;
+        ccur[NP - 1] = c0;
+      }
+    }
+  }
+  SSTAMP_FLUSH();
+  // db[g*W + u] += sum over this workgroup's rows and all steps (16 partials per column meet in LDS)
+  if (a.db) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);     // [4 gates][16 rows][64 units]
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[(g * 16 + er) * 64 + eu] = dbacc[g];
+    __syncthreads();
+    if (tid < 256) {
+      const int g = tid >> 6, u = tid & 63;
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += red[(g * 16 + r) * 64 + u];
+      atomicAdd(a.db + (long)g * W + u0 + u, sum);
+    }
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- helpers of the gate-interleaved layouts
+namespace {
+
+// out[r][u*4 + g] = in[r][g*W + u] (+ bias[g*W + u]); f32 rows of 4W columns
+__global__ void permute_gate_cols_f32_kernel(const float* __restrict__ in, const float* __restrict__ bias, float* __restrict__ out, long rows, int W) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one output quad (row, unit)
+  if (i >= rows * W) return;
+  const long r = i / W;
+  const int u = (int)(i % W);
+  const float* p = in + r * 4 * W + u;
+  float4 v = float4{p[0], p[W], p[2 * W], p[3 * W]};
+  if (bias) { v.x += bias[u]; v.y += bias[W + u]; v.z += bias[2 * W + u]; v.w += bias[3 * W + u]; }
+  *reinterpret_cast<float4*>(out + i * 4) = v;
+}
+
+// out[(u*4 + g)][k] = in[(g*W + u)][k]; bf16 rows of K elements (16-byte pieces)
+__global__ void permute_gate_rows_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int W, int K) {
+  const int pieces = K / 8;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)4 * W * pieces) return;
+  const int orow = (int)(i / pieces), pc = (int)(i % pieces);
+  const int u = orow >> 2, g = orow & 3;
+  *reinterpret_cast<uint4*>(out + (long)orow * K + pc * 8) = *reinterpret_cast<const uint4*>(in + ((long)g * W + u) * K + pc * 8);
+}
+
+// ids_tm[t][b] = (idx[b][t] * 4W * 4, ctx[b][t][0] * 4W * 4): table-row byte offsets, time-major; block T repeats block T-1
+__global__ void ids_tm_kernel(const int* __restrict__ idx, const int* __restrict__ ctx, int n_ctx, int B, int T, unsigned row_bytes,
+                              int V, int ctx_vocab, int* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)(T + 1) * B) return;
+  int t = (int)(i / B);
+  const int b = (int)(i % B);
+  if (t >= T) t = T - 1;
+  int id = idx[(long)b * T + t];
+  id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+  int c = n_ctx > 0 ? ctx[((long)b * T + t) * n_ctx] : 0;
+  c = c < 0 ? 0 : (c >= ctx_vocab ? ctx_vocab - 1 : c);
+  out[i * 2] = (int)((unsigned)id * row_bytes);
+  out[i * 2 + 1] = (int)((unsigned)c * row_bytes);
+}
+
+}  // namespace
+
+int kl_launch_permute_gate_cols_f32(const float* in, const float* bias, float* out, long rows, int W, hipStream_t stream) {
+  const long n = rows * W;
+  hipLaunchKernelGGL(permute_gate_cols_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, bias, out, rows, W);
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+int kl_launch_permute_gate_rows_bf16(const bf16_t* in, bf16_t* out, int W, int K, hipStream_t stream) {
+  if (K & 7) return KL_ERR_SHAPE;
+  const long n = (long)4 * W * (K / 8);
+  hipLaunchKernelGGL(permute_gate_rows_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, out, W, K);
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+int kl_launch_ids_tm(const int* idx, const int* ctx, int n_ctx, int B, int T, int W, int V, int ctx_vocab, int* out, hipStream_t stream) {
+  const long n = (long)(T + 1) * B;
+  hipLaunchKernelGGL(ids_tm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, idx, ctx, n_ctx, B, T,
+                     (unsigned)(4 * W * 4), V, ctx_vocab, out);
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------- launchers
+// Grid plan of the second-generation wide scans: every workgroup serves exactly NP phases of `rows` rows per step.
+// Returns NP (2..4) or 0 = not applicable (the first generation takes the shape).
+int kl_scan_wide2_phases(int B, int T, int W, int rows, int max_np) {
+  if (W != 512 || B < 1 || T < 1 || (B % rows)) return 0;      // (one tile row = one 1 KiB DMA piece: width 512)
+  int cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount > 256 ? 256 : prop.multiProcessorCount;
+  }
+  const int n_ph = B / rows, col_groups = W / 64;
+  int g = cus / col_groups;
+  if (g < 1) return 0;
+  if (g > n_ph) g = n_ph;
+  if (n_ph % g) return 0;
+  const int np = n_ph / g;
+  if (np < 2 || np > max_np) return 0;
+  if ((long)T * B * 4 * W * 2 > 0xfffffff0L) return 0;      // unsigned 32-bit buffer offsets (gate rows / dZ)
+  return np;
+}
+
+int kl_launch_scan_fwd_wide2(KlScanFwdWide a, int rows, hipStream_t stream) {
+  const int W = a.W;
+  const int np = kl_scan_wide2_phases(a.B, a.T, W, rows, 4);
+  if (!np || (rows != 16 && rows != 32)) return KL_ERR_SHAPE;
+  if (!a.sentinel || a.HT || a.HdT) return KL_ERR_SHAPE;
+  const bool tab = a.P == nullptr;
+  if (tab && (!a.EK || !a.ids_tm || a.n_ctx > 1)) return KL_ERR_ARG;
+  a.n_rb = a.B / rows;                 // (phases)
+  a.n_rg = a.n_rb / np;
+  const int col_groups = W / 64;
+  dim3 grid(8 * col_groups * ((a.n_rg + 7) / 8)), block(1024);
+  const int nb = rows / 16;
+  const size_t lds = (size_t)fwd2_lds_bytes(W / 32, nb, tab);
+#define KL_F2_CASE(KS, NB_, NP_, TAB_)                                                                                      \
+  do {                                                                                                                      \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_fwd_wide2_kernel<KS, NB_, NP_, TAB_>),                \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;     \
+    hipLaunchKernelGGL((lstm_scan_fwd_wide2_kernel<KS, NB_, NP_, TAB_>), grid, block, lds, stream, a);                      \
+  } while (0)
+#define KL_F2_NP(KS, NB_, TAB_)                                                    \
+  do {                                                                             \
+    if (np == 2) KL_F2_CASE(KS, NB_, 2, TAB_);                                     \
+    else if (np == 3) KL_F2_CASE(KS, NB_, 3, TAB_);                                \
+    else KL_F2_CASE(KS, NB_, 4, TAB_);                                             \
+  } while (0)
+#define KL_F2_TAB(KS, NB_)                          \
+  do {                                              \
+    if (tab) KL_F2_NP(KS, NB_, true);               \
+    else KL_F2_NP(KS, NB_, false);                  \
+  } while (0)
+  if (nb == 2) KL_F2_TAB(16, 2);
+  else KL_F2_TAB(16, 1);
+#undef KL_F2_TAB
+#undef KL_F2_NP
+#undef KL_F2_CASE
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+
+int kl_launch_scan_bwd_wide2(KlScanBwd a, hipStream_t stream) {
+  const int W = a.W;
+  const int np = kl_scan_wide2_phases(a.B, a.T, W, 16, 6);
+  if (!np || a.L != 1 || a.sentinel != 2 || a.dZT || a.T < 3) return KL_ERR_SHAPE;
+  a.n_rb = a.B / 16;
+  a.n_rg = a.n_rb / np;
+  const int col_groups = W / 64;
+  dim3 grid(8 * col_groups * ((a.n_rg + 7) / 8)), block(1024);
+  const size_t lds = (size_t)bwd2_lds_bytes(W / 32);
+#define KL_B2_CASE(KS, NP_)                                                                                                \
+  do {                                                                                                                      \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_bwd_wide2_kernel<KS, NP_>),                           \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;     \
+    hipLaunchKernelGGL((lstm_scan_bwd_wide2_kernel<KS, NP_>), grid, block, lds, stream, a);                                 \
+  } while (0)
+#define KL_B2_NP(KS)                                                                             \
+  do {                                                                                          \
+    switch (np) {                                                                               \
+      case 2: KL_B2_CASE(KS, 2); break;                                                         \
+      case 3: KL_B2_CASE(KS, 3); break;                                                         \
+      case 4: KL_B2_CASE(KS, 4); break;                                                         \
+      case 5: KL_B2_CASE(KS, 5); break;                                                         \
+      default: KL_B2_CASE(KS, 6); break;                                                        \
+    }                                                                                           \
+  } while (0)
+  KL_B2_NP(16);
+#undef KL_B2_NP
+#undef KL_B2_CASE
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+#ifdef KL_STAMP
+extern "C" int kl_test_scan2_stamps(unsigned long long* out, int reset) {
+  if (reset) {
+    unsigned long long z[32] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(kl_scan2_stamps), z, sizeof(z)) == hipSuccess ? 0 : KL_ERR_LAUNCH;
+  }
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(kl_scan2_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+#endif

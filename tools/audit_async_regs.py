@@ -1,0 +1,99 @@
+"""Audit of the inline-asm register loads in lstm_scan2.hip (the backward scan's epilogue inputs): between an asm
+`global_load_*` and the next hand-written `s_waitcnt vmcnt`, no instruction may read or write its destination
+registers -- the compiler believes they hold data from the end of the asm statement on and is free to copy or
+re-use them (cdna_hip_programming.md 5.7).  Usage: python tools/audit_async_regs.py <file.s>
+(hipcc ... -save-temps -c ocrd_keraslm_amd/csrc/lstm_scan2.hip writes the .s)"""
+import re
+import sys
+
+
+def regs_of(tok):
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def all_regs(line):
+    out = set()
+    for tok in re.findall(r"v\[\d+:\d+\]|v\d+", line):
+        out |= regs_of(tok)
+    return out
+
+
+def audit(path):
+    lines = open(path).read().split("\n")
+    bad = 0
+    kernel = None
+    in_asm = False
+    pending = {}          # register -> line number of the asm load
+    checked = 0
+    for i, ln in enumerate(lines):
+        s = ln.strip()
+        m = re.match(r"^(_Z\w+):", s)
+        if m:
+            kernel = m.group(1)
+            pending = {}
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if s.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not s or s.startswith(";") or s.startswith("."):
+            continue
+        if in_asm and s.startswith("global_load_dword") and " lds" not in s:
+            dst = s.split()[1].rstrip(",")
+            for r in regs_of(dst):
+                pending[r] = i + 1
+            checked += 1
+            continue
+        if in_asm and s.startswith("s_waitcnt vmcnt"):
+            pending = {}          # (the counted waits cover every asm load issued before them in this kernel's scheme)
+            continue
+        if s.startswith("s_endpgm") or s.startswith("s_branch"):
+            pending = {}          # (what follows an unconditional branch in the text is another path)
+            continue
+        hit = all_regs(s) & set(pending)
+        if hit:
+            bad += 1
+            print(f"{kernel}: line {i + 1} touches v{sorted(hit)} loaded by asm at line {pending[min(hit)]}: {s}")
+            for r in hit:
+                pending.pop(r, None)
+    print(f"{checked} asm register loads checked, {bad} premature uses")
+    return bad
+
+
+def audit_reserved(path, kernel_substr="bwd_wide2", reserved=range(124, 128)):
+    """The backward scan keeps v124..v127 for loads that land while the compiler's code runs: no compiler-generated
+    instruction of those kernels may name them."""
+    lines = open(path).read().split("\n")
+    kernel = None
+    in_asm = False
+    bad = checked = 0
+    res = set(reserved)
+    for i, ln in enumerate(lines):
+        s = ln.strip()
+        m = re.match(r"^(_Z\w+):", s)
+        if m:
+            kernel = m.group(1)
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if s.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not kernel or kernel_substr not in kernel or in_asm or not s or s[0] in ";.":
+            continue
+        checked += 1
+        hit = all_regs(s) & res
+        if hit:
+            bad += 1
+            print(f"{kernel}: line {i + 1} uses reserved v{sorted(hit)}: {s}")
+    print(f"{checked} compiler instructions of *{kernel_substr}* kernels checked, {bad} use v{min(res)}..v{max(res)}")
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if (audit(sys.argv[1]) + audit_reserved(sys.argv[1])) else 0)

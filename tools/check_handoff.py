@@ -3,6 +3,8 @@ engines that differ only in the hand-off (data sentinels vs counters, KL_SENTINE
 by the launch-per-step path (KL_SCAN=0).  The forward recurrence has no atomics, so the carried states of
 the two scan engines must agree BITWISE after every window; the step path (different summation order)
 must agree to bf16 accuracy.  Gradients are compared too (split-K atomics: to 1e-3 of their max-norm).
+The second-generation wide scans (KL_SCAN2=1 among the switches) sum in another order (no K split) and
+use bf16 tanh(c) nowhere else, so with them the states are compared to bf16 accuracy instead of bitwise.
 
   python tools/check_handoff.py [B] [windows] [KEY=VALUE ...]   (switches of the sentinel engine)"""
 import os
@@ -37,8 +39,9 @@ def engine(B, env):
 def run(B, N, verbose=True, env_a=None):
     """returns (mismatches, max rel gradient difference, max abs state difference to the step path);
     env_a: further switches of the sentinel engine (KL_SENTINEL_BWD=2, KL_XCD_LOCAL=1, ...)"""
-    a = engine(B, dict({"KL_SENTINEL": "1"}, **(env_a or {})))
+    a = engine(B, dict({"KL_SENTINEL": "1", "KL_SCAN2": "0"}, **(env_a or {})))
     b = engine(B, {"KL_SENTINEL": "0"})
+    gen2 = (env_a or {}).get("KL_SCAN2", "0") != "0"
     c = engine(B, {"KL_SCAN": "0"})
     rng = np.random.default_rng(0)
     gen = torch.Generator(device='cuda')
@@ -60,7 +63,13 @@ def run(B, N, verbose=True, env_a=None):
             if float(lm.loss_acc[3].item()) != 0.0:
                 print(f"window {w}: hand-off timed out")
                 bad += 1
-        if not torch.equal(a.states, b.states):
+        if gen2:
+            d = (a.states - b.states).abs().max().item()
+            if not d < 3e-2:
+                print(f"window {w}: carried states of the second-generation scans differ from the counter hand-off's (max {d:.3e})")
+                bad += 1
+            b.states.copy_(a.states)
+        elif not torch.equal(a.states, b.states):
             d = (a.states - b.states).abs().max().item()
             print(f"window {w}: carried states differ between sentinel and counter hand-off (max {d:.3e})")
             bad += 1
@@ -85,4 +94,4 @@ if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     bad, g, c = run(B, N, env_a=dict(kv.split("=", 1) for kv in sys.argv[3:]))
-    sys.exit(1 if bad or g > 1e-3 or c > 5e-2 else 0)
+    sys.exit(1 if bad or g > (3e-2 if any(kv == 'KL_SCAN2=1' for kv in sys.argv[3:]) else 1e-3) or c > 5e-2 else 0)
