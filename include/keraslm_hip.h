@@ -128,6 +128,11 @@ int kl_train_window(kl_handle* h, int B, int T, const int32_t* idx, const int32_
  * re-derives the bf16 weights (as kl_prepare).  t starts at 1. */
 int kl_adam_step(kl_handle* h, const float* grads, float* m, float* v, int t, float lr, float b1, float b2,
                  float eps, float clip, void* stream);
+/* The same with the gradients read as grads[i] * grad_scale (before the clip).  Data-parallel training (not a
+ * reference feature: rating.py:295 trains with workers=1) all-reduces the flat gradient vector with SUM and passes
+ * 1 / world size here, so the mean over the ranks costs no pass of its own. */
+int kl_adam_step_scaled(kl_handle* h, const float* grads, float grad_scale, float* m, float* v, int t, float lr,
+                        float b1, float b2, float eps, float clip, void* stream);
 
 /* Incremental step for n hypotheses with explicit states (rating.py:578-639):
  * row i reads its state from pool slot slot_in[i] and writes the new state to

@@ -101,9 +101,10 @@ struct kl_handle {
   struct GraphKey {
     int kind, B, T, flags, precision;
     const void *states, *loss_acc, *ws, *grads;
+    int layout = 0;               // workspace layout the body was captured with (kl_forward_window picks it from ws_bytes)
     bool operator==(const GraphKey& o) const {
       return kind == o.kind && B == o.B && T == o.T && flags == o.flags && precision == o.precision &&
-             states == o.states && loss_acc == o.loss_acc && ws == o.ws && grads == o.grads;
+             states == o.states && loss_acc == o.loss_acc && ws == o.ws && grads == o.grads && layout == o.layout;
     }
   };
   std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;
@@ -1118,14 +1119,19 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   return hip_ok(hipGetLastError());
 }
 
-int kl_adam_step(kl_handle* h, const float* grads, float* m, float* v, int t, float lr, float b1, float b2,
-                 float eps, float clip, void* stream) {
+int kl_adam_step_scaled(kl_handle* h, const float* grads, float grad_scale, float* m, float* v, int t, float lr, float b1,
+                        float b2, float eps, float clip, void* stream) {
   if (!h || !grads || !m || !v || t < 1) return KL_ERR_ARG;
   if (!h->params) return KL_ERR_STATE;
   hipStream_t s = (hipStream_t)stream;
   const double lr_t = (double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
-  KL_TRY(kl_launch_adam(h->params, grads, m, v, h->n_params, (float)lr_t, b1, b2, eps, clip, s));
+  KL_TRY(kl_launch_adam(h->params, grads, m, v, h->n_params, (float)lr_t, b1, b2, eps, clip, grad_scale, s));
   return prepare_impl(h, h->precision ? h->precision : KL_PREC_BF16, s);
+}
+
+int kl_adam_step(kl_handle* h, const float* grads, float* m, float* v, int t, float lr, float b1, float b2,
+                 float eps, float clip, void* stream) {
+  return kl_adam_step_scaled(h, grads, 1.0f, m, v, t, lr, b1, b2, eps, clip, stream);
 }
 
 size_t kl_step_workspace_bytes(const kl_handle* h, int n) {
@@ -1387,7 +1393,7 @@ extern "C" int kl_forward_window(kl_handle* h, int B, int T, const int32_t* idx,
   if (h->cfg.n_ctx > 0)
     KL_TRY(hip_ok(hipMemcpyAsync(w.s_ctx, ctx, BT * h->cfg.n_ctx * sizeof(int), hipMemcpyDeviceToDevice, s)));
   if (tgt) KL_TRY(hip_ok(hipMemcpyAsync(w.s_tgt, tgt, BT * sizeof(int), hipMemcpyDeviceToDevice, s)));
-  kl_handle::GraphKey key{0, B, T, (tgt ? 1 : 0) | (probs ? 2 : 0) | (h->last_only ? 4 : 0), h->precision, states, loss_acc, ws, nullptr};
+  kl_handle::GraphKey key{0, B, T, (tgt ? 1 : 0) | (probs ? 2 : 0) | (h->last_only ? 4 : 0), h->precision, states, loss_acc, ws, nullptr, layout};
   KL_TRY(run_graphed(h, key, s, [&]() {
     return forward_window_body(h, B, T, w.s_idx, w.s_ctx, tgt ? w.s_tgt : nullptr, states, probs ? w.s_probs : nullptr,
                                loss_acc, ws, ws_bytes, stream);

@@ -251,9 +251,10 @@ __global__ void rowstat_reduce_kernel(const float* __restrict__ rowstat, int row
 
 // ---- clip + Adam (Keras 2.3.1 formula; lr_t carries the bias correction) ---------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps, float clip) {
+                            float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps, float clip,
+                            float grad_scale) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    float gi = g[i];
+    float gi = g[i] * grad_scale;      // (1 / world size after a summing all-reduce: the mean over the ranks, no extra pass)
     gi = fminf(fmaxf(gi, -clip), clip);
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -451,9 +452,9 @@ int kl_launch_softmax_ce(float* logits, long ld, int rows, int V, const int* tgt
 }
 
 int kl_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
-                   float eps, float clip, hipStream_t stream) {
+                   float eps, float clip, float grad_scale, hipStream_t stream) {
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for((long)n, 256)), dim3(256), 0, stream, p, g, m, v, n, lr_t, b1, b2,
-                     eps, clip);
+                     eps, clip, grad_scale);
   return ok();
 }
 

@@ -199,7 +199,7 @@ int kl_launch_softmax_ce(float* logits, long ld, int rows, int V, const int* tgt
                          bf16_t* dlogits, long ld_dl, float* loss_acc, float* rowstat, int time_major,
                          hipStream_t stream, int last_only = 0);
 int kl_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
-                   float eps, float clip, hipStream_t stream);
+                   float eps, float clip, float grad_scale, hipStream_t stream);
 int kl_launch_onehot_t(const int* ids, int B, int T, int n_classes, int col, int n_cols, bf16_t* out, long ld,
                        hipStream_t stream);
 int kl_launch_regulariser_grads(const float* E, int V, int W, const float* const* ctx_tabs, int n_ctx, int ctx_vocab,

@@ -114,9 +114,11 @@ class HipLM:
         torch = self.torch
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
-        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
-            yield
-        cur.wait_stream(self.stream)
+        try:
+            with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+                yield
+        finally:
+            cur.wait_stream(self.stream)      # (also when the body raised: the streams stay joined)
 
     # `layout`, `params`, `grads`, `states`, `pool` are PHYSICAL (padded width); the accessors below speak the
     # model's own shapes.  For the widths in FAST_WIDTHS (and multiples of 32 above 1024) both coincide.
@@ -293,6 +295,7 @@ class HipLM:
                                                     ws.numel(), self._stream()), "kl_forward_window")
             if want_probs and float(self.loss_acc[3].item()) != 0.0:
                 # (the caller reads the probabilities next, so this sync is not an extra one)
+                self.loss_acc[3] = 0.0        # one timed-out window must not fail every later call
                 raise hipabi.KlError("persistent scan hand-off timed out (kl_forward_window)")
         return probs
 
@@ -336,12 +339,14 @@ class HipLM:
                                                   _ptr(self.loss_acc), _ptr(ws), ws.numel(), self._stream()),
                          "kl_train_window")
 
-    def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7, clip=1.0):
-        """Keras-2.3 Adam(clipvalue=1.0) (rating.py:178)."""
+    def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7, clip=1.0, grad_scale=1.0):
+        """Keras-2.3 Adam(clipvalue=1.0) (rating.py:178).  grad_scale: the gradients are read as grads * grad_scale
+        (1 / world size behind a summing all-reduce, distributed.GradSync.reduce)."""
         self.adam_t += 1
         with self._launch():
-            hipabi.check(self.lib.kl_adam_step(self.handle, _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
-                                               self.adam_t, lr, b1, b2, eps, clip, self._stream()), "kl_adam_step")
+            hipabi.check(self.lib.kl_adam_step_scaled(self.handle, _ptr(self.grads), float(grad_scale), _ptr(self.adam_m),
+                                                      _ptr(self.adam_v), self.adam_t, lr, b1, b2, eps, clip, self._stream()),
+                         "kl_adam_step_scaled")
 
     def read_loss(self, reset=True):
         """(CE mean, accuracy, regulariser) accumulated since the last reset."""

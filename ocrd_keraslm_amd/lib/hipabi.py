@@ -45,6 +45,8 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "kl_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "kl_adam_step_scaled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                     C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "kl_step_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "kl_step_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -202,6 +202,7 @@ class Rater(object):
             lm.prepare(PREC_BF16)
         sync = self._grad_sync()
         rank, world = sync.rank, sync.world
+        sync.broadcast_params(lm)      # every rank initialised or loaded its own weights: rank 0's count
         B = max(1, int(self.streams))
         n_streams = B * world
         if len(training_data) < n_streams or len(validation_data) < 1:
@@ -270,22 +271,31 @@ class Rater(object):
                     if rows:
                         lm.reset_states(B, rows=rows)
                     lm.train_window(x, z, y, masks)
-                    sync.average(lm)
-                    lm.adam_step()
+                    lm.adam_step(grad_scale=sync.reduce(lm))
                     if step + 1 < steps_per_epoch:
                         pending = (next_batch(train_gens), sorted(reset_rows), lm.draw_dropout_masks(B))
                         reset_rows.clear()
-                    ce, acc, reg = lm.read_loss(reset=True)
+                    failure = None
+                    try:
+                        ce, acc, reg = lm.read_loss(reset=True)
+                    except Exception as err:      # (a failed hand-off on this rank: every rank must leave together)
+                        failure, ce, acc, reg = err, float('nan'), 0.0, 0.0
                     loss = ce + reg
                     loss_sum += loss
                     acc_sum += acc
                     if loss > 25:
                         self.logger.warning('huge loss at batch %d', step)
-                    if not np.isfinite(loss):    # TerminateOnNaN
+                    # what ends the loop is decided by ALL ranks together: a rank that left on its own would leave
+                    # the others waiting in the next all-reduce
+                    is_nan, stop, failed = sync.any_flag(not np.isfinite(loss), self._stop, failure is not None)
+                    if failed:
+                        raise failure if failure is not None else RuntimeError('training failed on another rank')
+                    if is_nan:    # TerminateOnNaN
                         self.logger.critical('NaN loss at batch %d', step)
                         nan_abort = True
                         break
-                    if self._stop:
+                    if stop:
+                        self._stop = True
                         break
                 history['loss'].append(loss_sum / (step + 1))
                 history['accuracy'].append(acc_sum / (step + 1))
@@ -355,7 +365,12 @@ class Rater(object):
         '''Read text files, split into training vs validation, count batches and update
         the character mapping (stateful branch of rating.py:317-385).'''
         assert self.status >= 1
-        shuffle(data)
+        # (the reference shuffles in place with the global `random`; a shuffled index list takes the same swaps, and
+        # under data-parallel training every rank must see rank 0's order -- distributed.GradSync)
+        order = list(range(len(data)))
+        shuffle(order)
+        order = self._grad_sync().broadcast_object(order)
+        data[:] = [data[i] for i in order]
         if not self.stateful:
             return self._split_data_stateless(data, val_data)
         total_size = 0
@@ -413,7 +428,7 @@ class Rater(object):
             training_epoch_size = ceil(epoch_size * (1 - self.validation_split))
             validation_epoch_size = ceil(epoch_size * self.validation_split)
             validation_data, training_data = data, data
-            split = np.random.uniform(0, 1, (ceil(max_size / steps),))
+            split = self._grad_sync().broadcast_object(np.random.uniform(0, 1, (ceil(max_size / steps),)))
         if self.first_window:
             training_epoch_size *= 1.0 + self.first_window
         chars = sorted(list(chars))

@@ -124,8 +124,8 @@ class OracleLM(object):
             flat[off:off + rows * cols] = g[name].reshape(-1)
         self.grads = torch.from_numpy(flat)     # a CPU tensor: what GradSync all-reduces over gloo
 
-    def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7, clip=1.0):
-        flat = self.grads.numpy()
+    def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7, clip=1.0, grad_scale=1.0):
+        flat = self.grads.numpy() * np.float32(grad_scale)
         g = {name: flat[off:off + rows * cols].reshape(self.w[name].shape) for name, off, rows, cols in self.layout}
         self.opt.step(self.w, g)
 

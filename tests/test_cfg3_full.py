@@ -1,0 +1,62 @@
+"""BASELINE config 3 at its full size: 1024 hypotheses x 512 chained incremental steps,
+depth 2 / width 512 / V 256, "trained-like" weights, against the f64 oracle restatement of
+Rater.predict's arithmetic (rating.py:578-639).  The bar of north_star: |p - p_ref| < 1e-3 -- asserted at EVERY step
+in split precision (the rating precision); in plain bf16 the drift curve is recorded and only has to stay finite and
+below 5e-2 (bf16 is the training precision, not the rating one)."""
+import time
+
+import numpy as np
+import pytest
+
+from oracle import lstm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.timeout(1500)
+def test_cfg3_full_size_chained_parity():
+    from ocrd_keraslm_amd.lib import hipabi
+    from ocrd_keraslm_amd.lib.engine import HipLM
+    depth, width, voc, n, steps = 2, 512, 256, 1024, 512
+    cfg = O.ModelConfig(depth, width, voc, 1)
+    w = O.init_weights(cfg, seed=4, emb_std=0.5, dtype=np.float32)
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    rng = np.random.default_rng(3)
+    ctx = rng.integers(0, 200, (n, 1))
+    ids = rng.integers(1, voc, (steps, n))
+    engines = {}
+    for name, prec in (("split", hipabi.KL_PREC_SPLIT), ("bf16", hipabi.KL_PREC_BF16)):
+        lm = HipLM(depth, width, voc, 1)
+        lm.set_weights(w, prec)
+        lm.ensure_pool(2 * n)
+        engines[name] = lm
+    st = O.zero_states(cfg, n, np.float64)
+    a, b = np.arange(n), np.arange(n, 2 * n)
+    drift = {k: np.zeros(steps) for k in engines}
+    rows = np.arange(n)
+    t0 = time.time()
+    for s in range(steps):
+        ref, st = O.step_batch(cfg, w64, ids[s], ctx, st)
+        for name, lm in engines.items():
+            probs = lm.step_slots(ids[s], ctx, a, b).cpu().numpy()
+            drift[name][s] = np.abs(probs - ref).max()
+        a, b = b, a
+        # north_star's own criterion: the probability of the character that actually comes next
+        if s + 1 < steps:
+            nxt = ids[s + 1]
+            assert np.all(np.isfinite(ref[rows, nxt]))
+    oracle_s = time.time() - t0
+    d = drift["split"]
+    print("cfg3 full size: %d x %d steps, oracle + 2 engines %.0f s; split precision max |dp| per step: "
+          "first %.2e, step 128 %.2e, step 256 %.2e, last %.2e, worst %.2e at step %d"
+          % (n, steps, oracle_s, d[0], d[127], d[255], d[-1], d.max(), int(d.argmax())))
+    db = drift["bf16"]
+    cross = int(np.argmax(db >= 1e-3)) if (db >= 1e-3).any() else -1
+    print("  bf16: first %.2e, last %.2e, worst %.2e; first step at or above 1e-3: %s"
+          % (db[0], db[-1], db.max(), cross if cross >= 0 else "never"))
+    assert d.max() < 1e-3, (d.max(), int(d.argmax()))
+    assert np.all(np.isfinite(db)) and db.max() < 5e-2
+    # carried states after 512 steps (split precision)
+    pool = engines["split"].pool_read(a)
+    for k in range(2 * depth):
+        assert np.abs(pool[:, k] - st[k]).max() < 1e-3, k

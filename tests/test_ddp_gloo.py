@@ -35,14 +35,15 @@ def write_corpus(tmp, n_files=4, size=150, seed=0):
     return names
 
 
-def train_once(names, streams, epochs=2):
-    random.seed(0)
+def train_once(names, streams, epochs=2, seed=0):
+    if seed is not None:
+        random.seed(seed)
     r = Rater(engine_factory=OracleLM)
     r.width, r.depth, r.length = 16, 1, 8
     r.stateful = True
     r.streams = streams
     r.max_epochs = epochs
-    r.seed = 0
+    r.seed = seed
     r.char_degradation = 0.0
     r.context_degradation = 0.0
     r.configure()
@@ -72,6 +73,10 @@ def _worker(rank, world, port, names, out):
         assert torch.allclose(G.grads, torch.full((5,), 1.5))
         a, b = sync.mean_scalars(float(rank), 2.0 * rank)
         assert abs(a - 0.5) < 1e-12 and abs(b - 1.0) < 1e-12
+        G.grads = torch.full((5,), float(rank + 1))
+        assert sync.reduce(G) == 0.5 and torch.allclose(G.grads, torch.full((5,), 3.0))      # the sum; the scale goes to Adam
+        assert sync.any_flag(rank == 1, False, rank == 0) == (True, False, True)
+        assert sync.broadcast_object(["order", rank]) == ["order", 0]
         # 2) the training loop, one stream per rank
         w, hist = train_once(names, streams=1)
         np.savez(os.path.join(out, "rank%d.npz" % rank), **w)
@@ -86,6 +91,37 @@ def _free_port():
     port = s.getsockname()[1]
     s.close()
     return port
+
+
+def _worker_unseeded(rank, world, port, names, out):
+    """What a user gets from `torchrun ... keraslm-rate train`: Rater.seed is None and the global `random` is
+    seeded differently in every process -- initial weights, file order and dropout masks differ per rank unless
+    the training loop makes them agree."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        random.seed(1000 + rank)
+        np.random.seed(2000 + rank)
+        w, hist = train_once(names, streams=1, seed=None)
+        np.savez(os.path.join(out, "urank%d.npz" % rank), **w)
+        np.save(os.path.join(out, "uval%d.npy" % rank), np.array(hist["val_loss"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_unseeded_ranks_end_with_identical_weights():
+    """without a shared seed the ranks must still train ONE model -- rank 0's initial weights and
+    file order are broadcast, so weights and validation losses are identical on both ranks afterwards."""
+    with tempfile.TemporaryDirectory() as tmp:
+        names = write_corpus(tmp)
+        mp.spawn(_worker_unseeded, args=(2, _free_port(), names, tmp), nprocs=2, join=True)
+        w0 = dict(np.load(os.path.join(tmp, "urank0.npz")))
+        w1 = dict(np.load(os.path.join(tmp, "urank1.npz")))
+        for k in w0:
+            assert np.array_equal(w0[k], w1[k]), "ranks diverged on %s" % k
+        assert np.array_equal(np.load(os.path.join(tmp, "uval0.npy")), np.load(os.path.join(tmp, "uval1.npy")))
 
 
 @pytest.mark.timeout(600)
