@@ -17,13 +17,21 @@ synthetic corpus) are resident in HBM before the timed region.
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline      the dominant kernel (the persistent backward scan of one layer) against the
                 dense bf16 MFMA peak: algorithmic FLOPs per launch / mean launch time,
-                timed with HIP events on the engine's stream in an extra traced step
+                timed with HIP events on the engine's stream in an extra traced step.
+                `traffic` (HBM bytes per launch) is NOT measured by this run: it is read from the
+                committed rocprofv3 --pmc summary of the same command and stream count named in
+                `traffic_source`, and is null when no such file matches
   cpu_baseline  the CPU restatement (oracle/, numpy f32) of the same training step
                 with the reference's own batching (1 stream x 256 chars, stateful),
                 timed on this box's host cores on a bounded sample
   cpu_baseline_torch  informative second CPU figure: the same step with torch.nn.LSTM (oneDNN) + autograd
-  incremental   hypotheses*chars/s of the batched incremental step (cfg3:
-                1024 hypotheses x 512 chars), split-bf16 precision (parity mode)
+  incremental   hypotheses*chars/s of the batched incremental step, split-bf16 precision (the rating
+                precision): cfg3 (1024 hypotheses x 512 chars) and the reference's own batch cap
+                (128 hypotheses, rating.py:49, 809); wall and GPU-only time per step, algorithmic
+                HBM bytes per step; under N > 1 every rank runs it and the values are summed
+  end_to_end    chars/s of Rater.train itself (file reading, window generation, vocabulary look-up,
+                dropout masks, loss read-backs, one validation pass) over synthetic text files of the
+                same topology and stream count, rank 0 only -- what the host side costs
 """
 import argparse
 import json
@@ -138,13 +146,60 @@ def cpu_baseline_torch(seconds=8.0):
             "sample": "%d stateful windows of 1x%d chars (%.1f s)" % (n, T, el)}
 
 
+def end_to_end_leg(B, windows_per_file=48):
+    """Rater.train (the drop-in API) over B synthetic text files of windows_per_file x 256 characters each (one
+    stateful stream per file), cfg2 topology, ONE epoch incl. its validation pass; chars/s = the characters the
+    training steps consumed / the wall time of the whole train() call (vocabulary scan and file reading included)."""
+    import logging
+    import tempfile
+    from ocrd_keraslm_amd.lib import Rater
+    alphabet = [chr(0x100 + k) for k in range(VOC - 1)]
+    rng = np.random.default_rng(5)
+    p = 1.0 / (np.arange(1, VOC) + 1.0)
+    p /= p.sum()
+    size = windows_per_file * LENGTH + 1
+    n_val = max(1, B // 8)
+    with tempfile.TemporaryDirectory() as tmp:
+        names = []
+        for i in range(B + n_val):
+            ids = rng.choice(VOC - 1, size=size, p=p)
+            name = os.path.join(tmp, "a_b%d_%d.txt" % (i, 1700 + (i % 29) * 10))
+            with open(name, "w", encoding="utf-8") as f:
+                f.write("".join(alphabet[j] for j in ids))
+            names.append(name)
+        r = Rater(logger=logging.getLogger("bench.e2e"))
+        r.width, r.depth, r.length = WIDTH, DEPTH, LENGTH
+        r.stateful = True
+        r.streams = B
+        r.max_epochs = 1
+        r.seed = 1
+        r.configure()
+        files = [open(n, encoding="utf-8") for n in names[:B]]
+        val = [open(n, encoding="utf-8") for n in names[B:]]
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            t0 = time.perf_counter()
+            r.train(files, val_data=val)
+            el = time.perf_counter() - t0
+        finally:
+            os.chdir(cwd)
+            for f in files + val:
+                f.close()
+        steps = windows_per_file - 1          # (rating.py:342: ceil((size - length) / length) full windows per file)
+        chars = steps * B * LENGTH
+        return {"value": chars / el, "unit": "chars/s", "seconds": el, "train_steps": steps, "streams": B,
+                "note": "Rater.train, one epoch + validation, wall time of the whole call"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("KL_BENCH_STREAMS", "1024")),
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("KL_BENCH_STREAMS", "3072")),
                     help="stateful streams per GPU (B)")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-incremental", action="store_true")
     args = ap.parse_args()
@@ -194,9 +249,7 @@ def main():
         keep = torch.rand((DEPTH, B, WIDTH), device=device, generator=gen) >= 0.1
         masks = keep.to(torch.float32) / 0.9
         lm.train_window(idx, ctx, tgt, masks)
-        if all_reduce:
-            sync.average(lm)
-        lm.adam_step()
+        lm.adam_step(grad_scale=sync.reduce(lm) if all_reduce else 1.0)
 
     for w in range(args.warmup):
         step(w)
@@ -245,51 +298,87 @@ def main():
         # a step launch carries every layer's cell for B chars (SURVEY.md 8d per-char figure)
         flops_launch = fl if pers else B * flops_cell_per_char()
         achieved = flops_launch / per_launch_s / 1e12 if per_launch_s > 0 else 0.0
-        # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command
-        # (FETCH_SIZE doubled as the gfx950 guide prescribes); the summary is committed under profiles/
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_B%d.json" % B)))
-            for k, v in pmc["kernels"].items():
-                if k.startswith(name):
-                    traffic = v["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        # HBM bytes per launch: NOT measured here (counters need their own rocprofv3 --pmc passes, tools/profile_round.sh);
+        # taken from the committed summary of the same command at the same stream count, and labelled as such
+        traffic, traffic_source = None, None
+        for tag in ("r02", "r01"):
+            fn = os.path.join("profiles", "%s_pmc_hbm_traffic_B%d.json" % (tag, B))
+            try:
+                pmc = json.load(open(os.path.join(ROOT, fn)))
+                for k, v in pmc["kernels"].items():
+                    if k.startswith(name):
+                        traffic, traffic_source = v["hbm_bytes_per_launch"], fn + " (committed rocprofv3 --pmc summary, not this run)"
+            except Exception:
+                pass
+            if traffic is not None:
+                break
         roofline = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                    "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                     "launch_us": per_launch_s * 1e6, "launches_timed": n, "persistent": pers,
                     "flops_per_launch": flops_launch,
                     "other_kernel": {k: {"launches": v[0], "total_ms": v[1], "flops_per_launch": v[3]}
                                      for k, v in out.items() if k != name},
                     "whole_step_frac": value * 3 * flops_fwd_per_char() / world / 1e12 / MFMA_BF16_PEAK_TFLOPS}
 
-    # ---- incremental rescoring (cfg3): 1024 hypotheses x 512 chars on this GPU
+    # ---- incremental rescoring: cfg3 (1024 hypotheses x 512 chars) and the reference's batch cap (128 hypotheses),
+    # split precision; every rank runs it on its own GPU (independent hypothesis sets, no collective), values summed
     incremental = None
-    if rank == 0 and not args.no_incremental:
-        N, S = 1024, 512
+    if not args.no_incremental:
         lm.prepare(hipabi.KL_PREC_SPLIT)
-        lm.ensure_pool(2 * N)
-        r3 = np.random.default_rng(3)
-        ids = torch.from_numpy(r3.integers(1, VOC, size=(S, N)).astype(np.int32)).to(device)
-        cc = torch.from_numpy(r3.integers(0, 200, size=(N, 1)).astype(np.int32)).to(device)
-        a = torch.arange(N, dtype=torch.int32, device=device)
-        b = a + N
-        lm.pool.zero_()
-        warm = S // 5
-        for s in range(warm):
-            lm.step_slots(ids[s], cc, a, b)
-            a, b = b, a
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for s in range(warm, S):
-            lm.step_slots(ids[s], cc, a, b)
-            a, b = b, a
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t1
-        hv = N * (S - warm) / el
-        incremental = {"value": hv, "unit": "hypotheses*chars/s", "hypotheses": N, "chars": S, "precision": "split-bf16 (3 MFMA passes)",
-                       "us_per_step": el / (S - warm) * 1e6,
-                       "mfma_frac": hv * flops_fwd_per_char() / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+        legs = {}
+        for N, S in ((1024, 512), (128, 512)):
+            lm.ensure_pool(2 * N)
+            r3 = np.random.default_rng(3 + rank)
+            ids = torch.from_numpy(r3.integers(1, VOC, size=(S, N)).astype(np.int32)).to(device)
+            cc = torch.from_numpy(r3.integers(0, 200, size=(N, 1)).astype(np.int32)).to(device)
+            a = torch.arange(N, dtype=torch.int32, device=device)
+            b = a + N
+            lm.pool.zero_()
+            warm = S // 5
+            for s in range(warm):
+                lm.step_slots(ids[s], cc, a, b)
+                a, b = b, a
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t1 = time.perf_counter()
+            e0.record()
+            for s in range(warm, S):
+                lm.step_slots(ids[s], cc, a, b)
+                a, b = b, a
+            e1.record()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t1
+            gpu_us = e0.elapsed_time(e1) * 1e3 / (S - warm)
+            # algorithmic HBM bytes per step: states read + written, probabilities, indices; the bf16
+            # hi+lo weights of all layers are read once per step (L2/MALL-resident between steps or not)
+            state_bytes = N * (2 * (2 * DEPTH * WIDTH * 4) + VOC * 4 + 4 * (1 + N_CTX))
+            weight_bytes = sum(((WIDTH + 10 * N_CTX if l == 0 else WIDTH) + WIDTH) * 4 * WIDTH * 2 for l in range(DEPTH)) * 2
+            legs[N] = {"value": N * (S - warm) / el, "us_per_step": el / (S - warm) * 1e6, "gpu_us_per_step": gpu_us,
+                       "algorithmic_bytes_per_step": state_bytes + weight_bytes,
+                       "hbm_frac": (state_bytes + weight_bytes) / (gpu_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                       "mfma_frac": N * flops_fwd_per_char() / (gpu_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+        if world > 1:
+            t = torch.tensor([legs[1024]["value"], legs[128]["value"]], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            legs[1024]["value"], legs[128]["value"] = float(t[0].item()), float(t[1].item())
+        incremental = {"value": legs[1024]["value"], "unit": "hypotheses*chars/s", "hypotheses": 1024, "chars": 512,
+                       "precision": "split-bf16 (3 MFMA passes)", "n_gpus": world,
+                       "us_per_step": legs[1024]["us_per_step"], "gpu_us_per_step": legs[1024]["gpu_us_per_step"],
+                       "algorithmic_bytes_per_step": legs[1024]["algorithmic_bytes_per_step"],
+                       "hbm_frac": legs[1024]["hbm_frac"], "mfma_frac": legs[1024]["mfma_frac"],
+                       "n128": {"value": legs[128]["value"], "hypotheses": 128, "us_per_step": legs[128]["us_per_step"],
+                                "gpu_us_per_step": legs[128]["gpu_us_per_step"],
+                                "algorithmic_bytes_per_step": legs[128]["algorithmic_bytes_per_step"],
+                                "hbm_frac": legs[128]["hbm_frac"], "mfma_frac": legs[128]["mfma_frac"],
+                                "note": "the reference's batch cap (rating.py:49, 809)"}}
+
+    # ---- end to end: Rater.train over synthetic files (rank 0, one GPU): what the Python above the ABI costs
+    end_to_end = None
+    if rank == 0 and not args.no_end_to_end:
+        try:
+            end_to_end = end_to_end_leg(B)
+        except Exception as err:      # informative only
+            end_to_end = {"error": repr(err)}
 
     cpu = None
     cpu_torch = None
@@ -311,6 +400,7 @@ def main():
                        "streams_per_gpu": B, "global_batch": B * world, "seq_len": T,
                        "parallelism": "dp%d" % world, "final_ce": ce / max(args.steps, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_torch": cpu_torch, "incremental": incremental,
+            "end_to_end": end_to_end,
         }
         print(json.dumps(line))
     if world > 1:

@@ -14,7 +14,8 @@ on fixed seeded weights.  Everything ABOVE that seam -- windowing, padding,
 probability extraction, beam search, lattice decoding, Node ordering, traceback
 cutting -- is the reference's code, and its outputs are what the fixtures pin.
 
-Outputs (tests/golden/): windows.json, rater_seam.json
+Outputs (tests/golden/): windows.json, rater_seam.json, stateful_train.json (the stateful training front end:
+file-wise split, epoch sizes, window stream of a file list with resets and augmentations)
 """
 import json
 import os
@@ -211,7 +212,99 @@ def golden_seam():
     return out
 
 
+class MemFile(object):
+    """an open text file as run.py hands them to Rater.train (rating.py:72-80): .name, .read(), .seek()"""
+
+    def __init__(self, name, text):
+        import io
+        self.name = name
+        self._f = io.StringIO(text)
+
+    def read(self):
+        return self._f.read()
+
+    def seek(self, pos):
+        return self._f.seek(pos)
+
+
+class ResetRecorder(object):
+    """stands in for ResetStatesCallback (callbacks.py:36-69): _gen_data_from_files calls .reset(name)"""
+
+    def __init__(self, events):
+        self.events = events
+
+    def reset(self, name):
+        self.events.append({"reset": name})
+
+
+TRAIN_FILES = [("goethe_faust_1808.txt", 301), ("kant_kritik_1781.txt", 517), ("anon.txt", 129), ("a_b_1995.txt", 260),
+               ("x_y_1650.txt", 64), ("lessing_nathan_1779.txt", 190), ("zz_top_1700.txt", 66)]
+
+
+def golden_stateful_training():
+    """rating.py:317-350 (stateful _split_data), 977-1002 (_gen_data_from_files) and 1062-1077 (train=True
+    augmentations) of the unmodified reference, under fixed seeds of `random` and `numpy.random`."""
+    import random
+    length = 64
+    texts = {}
+    for k, (name, size) in enumerate(TRAIN_FILES):
+        texts[name] = ((TEXT[7 * k:] + TEXT) * 3)[:size]
+
+    def new_rater():
+        r = Rater()
+        r.width, r.depth, r.length = 16, 1, length
+        r.stateful, r.incremental = True, False
+        r.variable_length, r.first_window, r.batch_size = False, 0, 1
+        r.status = 1
+        return r
+
+    def files():
+        return [MemFile(name, texts[name]) for name, _ in TRAIN_FILES]
+
+    out = {"length": length, "files": [{"name": n, "text": texts[n]} for n, _ in TRAIN_FILES]}
+    splits = []
+    for seed, with_val in ((7, False), (8, False), (9, True)):
+        r = new_rater()
+        data = files()
+        val = data[-2:] if with_val else None
+        if with_val:
+            data = data[:-2]
+        random.seed(seed)
+        tr, va, split, n_tr, n_va, total, steps = r._split_data(data, val)
+        splits.append({"seed": seed, "with_val": with_val, "train": [f.name for f in tr], "val": [f.name for f in va],
+                       "split_is_none": split is None, "training_epoch_size": int(n_tr), "validation_epoch_size": int(n_va),
+                       "total_size": int(total), "steps": int(steps), "voc_size": int(r.voc_size),
+                       "chars": [r.mapping[1][i] for i in range(1, r.voc_size)]})
+    out["split_data"] = splits
+    gens = []
+    for seed, train, cd, xd, repeat_windows in ((5, True, 0.3, 0.4, 0), (6, True, 0.01, 0.1, 0), (5, False, 0.3, 0.4, 0),
+                                                (11, True, 0.5, 0.5, 12)):
+        r = new_rater()
+        data = files()
+        random.seed(3)
+        r._split_data(data, None)          # (vocabulary; the shuffled order is part of the fixture)
+        order = [f.name for f in data]
+        r.char_degradation, r.context_degradation = cd, xd
+        events = []
+        r.reset_cb = ResetRecorder(events)
+        np.random.seed(seed)
+        gen = r._gen_data_from_files(data, length, train=train, repeat=repeat_windows > 0)
+        n = 0
+        for x, y in gen:
+            tgt = np.where(y[0].any(axis=-1), y[0].argmax(axis=-1), -1)
+            events.append({"x": x[0][0].tolist(), "ctx": x[1][0].tolist(), "y": tgt.tolist()})
+            n += 1
+            if repeat_windows and n >= 40 + repeat_windows:      # (repeat=True never ends by itself)
+                break
+        gens.append({"np_seed": seed, "train": train, "char_degradation": cd, "context_degradation": xd,
+                     "repeat": repeat_windows > 0, "order": order, "events": events})
+    out["gen_data_from_files"] = gens
+    return out
+
+
 if __name__ == "__main__":
+    with open(os.path.join(HERE, "stateful_train.json"), "w") as f:
+        json.dump(golden_stateful_training(), f)
     with open(os.path.join(HERE, "windows.json"), "w") as f:
         json.dump(golden_windows(), f)
     with open(os.path.join(HERE, "rater_seam.json"), "w") as f:
