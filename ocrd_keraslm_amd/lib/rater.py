@@ -31,7 +31,7 @@ from random import shuffle
 
 import numpy as np
 
-from . import modelio, windows
+from . import lattice_beam, modelio, windows
 from .node import Node
 
 PREC_BF16 = 1
@@ -864,114 +864,50 @@ class Rater(object):
         '''Rate a lattice of string alternatives, decoding the best-scoring path
         incrementally (rating.py:712-859).  `graph` is a networkx.DiGraph whose edges
         carry `element` and `alternatives` (objects with `.Unicode`, `.conf`, `.index`).
-        Returns (path [(element, alternative, score)], entropy, traceback).'''
-        import networkx as nx
+        Returns (path [(element, alternative, score)], entropy, traceback).
 
+        The beam bookkeeping lives in lattice_beam.py: one table of tracks per edge, list operations on track
+        numbers and float keys, tree nodes only for the hypotheses that survive at an edge's destination.'''
         if not context:
             context = self.underspecify_contexts()
         self._ensure_precision()
         if not start_traceback:
             root = Node(state=None, value='\n', cost=0.0)
             start_traceback = ([root], root)
+        graph.nodes[start_node]['traceback'] = start_traceback[0]
+        clustering = bool(beam_clustering_dist)
 
-        def lattice_edges(G, start):
-            visited = [start]
-            for out in nx.topological_sort(G):
-                for in_, _ in G.in_edges([out]):
-                    if in_ in visited:
-                        yield in_, out
-                        visited.append(out)
-        graph.nodes[start_node]['traceback'], _ = start_traceback
-        out = 0
-        out_node = None
-        c_i = self.mapping[0]
-        for in_, out in lattice_edges(graph, start_node):
-            edge = graph.edges[in_, out]
-            element = edge['element']
-            textequivs = edge['alternatives']
-            in_node = graph.nodes[in_]
-            out_node = graph.nodes[out]
-            self.logger.debug("rating %d alternatives from %d to %d", len(textequivs), in_, out)
-            assert 'traceback' in in_node, \
-                "breadth-first search should have visited %d first in '%s'" % (in_, element.id)
-            beam = in_node['traceback']
-            final_beam = out_node['traceback'] if 'traceback' in out_node else []
-            next_beam = [Node(parent=hyp, state=hyp.state, value="", cost=0.0, extras=(element, textequiv))
-                         for hyp in beam for textequiv in textequivs]
-            unmapped_seen = dict()
-            max_batches = max(map(lambda x: len(x.Unicode), textequivs)) * 3
-            for _ in range(max_batches):
-                beam = []
-                while next_beam:
-                    candidate = next_beam.pop()       # worst first (rating.py:801)
-                    if candidate.value == candidate.extras[1].Unicode:
-                        if (beam_clustering_dist and
-                                self._history_clustering(candidate, final_beam, beam_clustering_dist)):
-                            continue
-                        insort_left(final_beam, candidate)
-                    else:
-                        insort_left(beam, candidate)
-                    if len(beam) >= self.batch_size:
-                        break
-                if not beam:
-                    break
-                elif not final_beam:
-                    pass
-                elif beam[0].cum_cost >= final_beam[0].cum_cost + 15:
-                    break
-                preds, states = self._predict_refs(
-                    [hyp.value[-1] if hyp.value else hyp.parent.value[-1] for hyp in beam],
-                    [hyp.state for hyp in beam], context, heads=bool(beam_clustering_dist))
-                for i, candidate in enumerate(beam):
-                    alt = candidate.extras[1]
-                    conf = alt.conf
-                    char = alt.Unicode[len(candidate.value)]
-                    if char not in c_i:
-                        if char not in unmapped_seen.setdefault(alt.index, []):
-                            self.logger.error('unmapped character "%s" at input alternative %d of element %s',
-                                              char, alt.index or i, element.id if element else "space")
-                            unmapped_seen[alt.index].append(char)
-                        idx = 0
-                    else:
-                        idx = c_i[char]
-                    cost = (-log(max(preds[i][idx], 1e-99), 2) * lm_weight +
-                            -log(max(conf, 1e-99), 2) * (1. - lm_weight))
-                    candidate.cum_cost += cost
-                    candidate.value += char
-                    candidate.state = states[i]
-                    if next_beam and candidate.cum_cost >= next_beam[0].cum_cost + 2.5:
-                        continue
-                    insort_left(next_beam, candidate)
-                next_beam = next_beam[:max_batches * self.batch_size]
-            out_node['traceback'] = final_beam[:beam_width]
-        assert out == end_node, \
-            'breadth-first search failed to reach true end node (%d instead of %d)' % (out, end_node)
-        assert out_node is not None and 'traceback' in out_node, \
+        def predict(chars, states):
+            return self._predict_refs(chars, states, context, heads=clustering)
+
+        def close_states(a, b):
+            return all(self._state_distance_below(a, b, k, beam_clustering_dist) for k in range(self.depth))
+
+        reached = None
+        for source, reached in lattice_beam.lattice_edges(graph, start_node):
+            edge = graph.edges[source, reached]
+            element, alternatives = edge['element'], edge['alternatives']
+            self.logger.debug("rating %d alternatives from %d to %d", len(alternatives), source, reached)
+            assert 'traceback' in graph.nodes[source], \
+                "breadth-first search should have visited %d first in '%s'" % (source, element.id)
+            target = graph.nodes[reached]
+            tracks = lattice_beam.EdgeTracks(graph.nodes[source]['traceback'], alternatives, element, self.mapping[0],
+                                             lm_weight, self.logger)
+            finished = lattice_beam.FinishedBeam(target.get('traceback', []))
+            lattice_beam.decode_edge(tracks, finished, predict, self.batch_size,
+                                     max(len(a.Unicode) for a in alternatives) * 3,
+                                     close_states if clustering else None)
+            target['traceback'] = [ref if kind == "node" else tracks.node(ref) for kind, ref in finished.items[:beam_width]]
+        assert reached == end_node, \
+            'breadth-first search failed to reach true end node (%s instead of %d)' % (reached, end_node)
+        assert 'traceback' in graph.nodes[reached], \
             "breadth-first search failed to reach end node with any result"
-        return self.next_path(out_node['traceback'], start_traceback)
+        return self.next_path(graph.nodes[reached]['traceback'], start_traceback)
 
     def next_path(self, beam, traceback):
         '''Advance from `traceback` to `beam` (rating.py:862-885): lock into the best
         hypothesis' ancestor in the previous beam, emit its path, cut the others.'''
-        prev_beam, prev_start_node = traceback
-        best_node = beam[0]
-        best_path = best_node.to_sequence(stop_at=prev_beam)
-        start_node = best_path[-1]
-        result = []
-        for node in best_path:
-            if node.extras:
-                element, textequiv = node.extras
-                parent_cost = node.parent.cum_cost if node.parent else prev_start_node.cum_cost
-                score = pow(2.0, -(node.cum_cost - parent_cost) / len(textequiv.Unicode))
-                result.append((element, textequiv, score))
-        next_beam = []
-        for hyp in beam:
-            other_path = hyp.to_sequence(stop_at=[start_node])
-            if not other_path:
-                continue
-            hyp.cut_at(start_node)
-            insort_left(next_beam, hyp)
-        return result, start_node.cum_cost - prev_start_node.cum_cost, (next_beam, start_node)
+        return lattice_beam.advance_traceback(beam, traceback)
 
     def _state_distance_below(self, a, b, k, distance):
         if isinstance(a, StateRef) and isinstance(b, StateRef):
@@ -981,20 +917,6 @@ class Rater(object):
             d2 = float(_np(self.model.state_dist2([a.slot], [b.slot], k))[0])
             return d2 < distance * distance
         return np.linalg.norm(np.asarray(a[k]) - np.asarray(b[k])) < distance
-
-    def _history_clustering(self, candidate, beam, distance=5):
-        '''Whether `candidate` is redundant w.r.t. a hypothesis in `beam` with the same
-        text and close state vectors (entries k < depth of [h1,c1,...], as the reference
-        compares them, rating.py:887-916); removes the dominated one.'''
-        for hyp in beam:
-            if (candidate.value == hyp.value and
-                    all(self._state_distance_below(candidate.state, hyp.state, k, distance)
-                        for k in range(self.depth))):
-                if hyp.cum_cost < candidate.cum_cost:
-                    return True
-                beam.remove(hyp)
-                break
-        return False
 
     # ------------------------------------------------------------------ model I/O
     def save(self, filename):

@@ -153,6 +153,13 @@ LATTICES = [
 ]
 
 
+TIE_LATTICES = [
+    [[("Die", 0.9), ("Die", 0.9), ("Dle", 0.9)], [(" ", 1.0), (" ", 1.0)], [("Muth", 0.6), ("Mnth", 0.6), ("Muth", 0.6)],
+     [(" ", 1.0)], [("ist", 0.8), ("ist", 0.8), ("isl", 0.8), ("ist", 0.8)]],
+    [[("Habe", 0.75), ("Habe", 0.75)], [(" ", 1.0)], [("dich", 0.7), ("dich", 0.7), ("dieh", 0.7)]],
+]
+
+
 def golden_seam():
     out = {}
     # --- stateful: rate, rate2, test ---------------------------------------------------
@@ -200,6 +207,30 @@ def golden_seam():
                       "entropy": float(entropy), "beam": [float(n.cum_cost) for n in traceback[0]], "calls": []})
         bests.append({"lm_weight": lm_weight, "beam_width": beam_width, "dist": dist, "pages": pages})
     out["rate_best"] = bests
+    # --- exact cost ties: duplicated alternatives (same text, same confidence, different index) and duplicated
+    # incoming hypotheses cost exactly the same at every character, so WHICH of them survives is decided by the
+    # insertion order of insort_left alone (rating.py:703, 807, 849)
+    ties = []
+    for lm_weight, beam_width, dist in ((0.5, 10, 0), (0.5, 2, 0), (0.7, 4, 5)):
+        traceback = None
+        pages = []
+        for segs in TIE_LATTICES:
+            g, s, e = lattice(segs)
+            r.model.calls = []
+            path, entropy, traceback = r.rate_best(g, s, e, start_traceback=traceback, context=[17],
+                                                   lm_weight=lm_weight, beam_width=beam_width,
+                                                   beam_clustering_dist=dist)
+            pages.append({"path": [[el.id, alt.Unicode, alt.index, float(score)] for el, alt, score in path],
+                          "entropy": float(entropy),
+                          "beam": [[float(n.cum_cost), n.extras[1].index if n.extras else -1] for n in traceback[0]],
+                          "calls": list(r.model.calls)})
+        path, entropy, traceback = r.next_path(traceback[0], ([], traceback[1]))
+        pages.append({"path": [[el.id, alt.Unicode, alt.index, float(score)] for el, alt, score in path],
+                      "entropy": float(entropy),
+                      "beam": [[float(n.cum_cost), n.extras[1].index if n.extras else -1] for n in traceback[0]], "calls": []})
+        ties.append({"lm_weight": lm_weight, "beam_width": beam_width, "dist": dist, "pages": pages})
+    out["rate_best_ties"] = ties
+    out["tie_lattices"] = TIE_LATTICES
     out["model"] = {"depth": 2, "width": 32, "length": 16, "seed": 4, "emb_std": 0.5,
                     "chars": sorted(set(TEXT))}
     out["lattices"] = LATTICES

@@ -172,6 +172,37 @@ def test_rate_best_matches_reference(factory, tol):
                 assert calls == ref["calls"]
 
 
+@pytest.mark.parametrize("factory,tol", ENGINES)
+def test_rate_best_exact_ties_match_reference(factory, tol):
+    """Lattices whose alternatives (and therefore hypotheses) cost EXACTLY the same: which duplicate survives in the
+    path and in the beam is decided by insort_left's tie rule and the order of the list operations alone."""
+    r = make_rater(factory, False, True)
+    for case in SEAM["rate_best_ties"]:
+        traceback = None
+        pages = []
+        for segs in SEAM["tie_lattices"]:
+            g, s, e = lattice(segs)
+            if hasattr(r.model, "step_calls"):
+                r.model.step_calls.clear()
+            path, entropy, traceback = r.rate_best(g, s, e, start_traceback=traceback, context=[17],
+                                                   lm_weight=case["lm_weight"], beam_width=case["beam_width"],
+                                                   beam_clustering_dist=case["dist"])
+            pages.append((path, entropy, traceback, list(getattr(r.model, "step_calls", []))))
+        path, entropy, traceback = r.next_path(traceback[0], ([], traceback[1]))
+        pages.append((path, entropy, traceback, []))
+        exact = tol < 1e-6      # (on the GPU engine duplicates are still bitwise equal -- same inputs, same kernel -- but
+        #                          near-ties between different texts may order differently: compare what is pinned)
+        for (path, entropy, tb, calls), ref in zip(pages, case["pages"]):
+            assert [[el.id, alt.Unicode] for el, alt, _ in path] == [[a, b] for a, b, _, _ in ref["path"]]
+            if exact:
+                assert [alt.index for _, alt, _ in path] == [i for _, _, i, _ in ref["path"]]
+                assert [n.extras[1].index if n.extras else -1 for n in tb[0]] == [i for _, i in ref["beam"]]
+                if hasattr(r.model, "step_calls") and ref["calls"]:
+                    assert calls == ref["calls"]
+            assert len(tb[0]) == len(ref["beam"])
+            assert abs(entropy - ref["entropy"]) < max(tol * 100, 1e-8)
+
+
 def test_status_machine_and_assertions():
     r = Rater(engine_factory=OracleLM)
     with pytest.raises(AssertionError):
