@@ -74,6 +74,7 @@ struct WindowWs {
   float* reg_scratch;                 // statistics of the embedding regularisers
   // training only
   std::vector<bf16_t*> G, dZ, Hd;
+  std::vector<bf16_t*> Cb;            // second-generation wide scans: cell states for the backward scan as bf16 [(T+1)B][W]
   std::vector<bf16_t*> Xhi, Xlo;      // inference: state planes exchanged by the split-precision scan [(T+1)B][W]
   std::vector<bf16_t*> HTf, HdT;      // transposed outputs written by the wide forward scans: [W][(T+1)B], [W][BT]
   bool ht_ready = false;              // ... valid for this window
@@ -125,6 +126,7 @@ struct kl_handle {
   bool scan2 = true;            // second-generation wide scans where their grid plan applies (KL_SCAN2=0: first generation)
   int scan2_rows = 0;           // KL_SCAN2_ROWS = 16 / 32: rows per forward phase (0: chosen by shape)
   int scan2_pf = -1;            // KL_SCAN2_PF: where the forward scan requests its next tile (0: top of a phase, 1: behind the MFMA phase, 2: two phases ahead; -1: by shape)
+  bool scan2_bf16 = true;       // KL_SCAN2_BF16=0: f32 instead of bf16 for what the scans exchange with later kernels (P, dH, c for backward)
   int scan2_pfb = -1;           // KL_SCAN2_PFB: the same for the backward scan (-1: by shape)
   int wide_fwd_min = 96;        // layer-sequential wide forward scans from this many 64-unit workgroups (KL_WIDE_FWD_MIN; 0 = never)
   double trace_flops[2] = {0.0, 0.0};   // algorithmic FLOPs of ONE timed launch
@@ -269,12 +271,13 @@ size_t carve_window(const kl_handle* h, void* base, int B, int T, int training, 
   o.scan_status = cv.take<unsigned>(4 + 256);   // status words [4] + XCC posts of the wide scans' workgroups [256]
   o.reg_scratch = cv.take<float>(3 * (W > (size_t)c.ctx_dim ? W : (size_t)c.ctx_dim) + (V > (size_t)c.ctx_vocab ? V : (size_t)c.ctx_vocab) + 8);
   if (training) {
-    o.G.assign(L, nullptr); o.dZ.assign(L, nullptr); o.Hd.assign(L, nullptr);
+    o.G.assign(L, nullptr); o.dZ.assign(L, nullptr); o.Hd.assign(L, nullptr); o.Cb.assign(L, nullptr);
     o.dc0.assign(L, nullptr); o.dc1.assign(L, nullptr);
     for (size_t l = 0; l < L; ++l) {
       o.G[l] = cv.take<bf16_t>(BT * 4 * W);
       o.dZ[l] = cv.take<bf16_t>(BT * 4 * W);
       o.Hd[l] = l > 0 ? cv.take<bf16_t>(BT * W) : nullptr;
+      o.Cb[l] = cv.take<bf16_t>((BT + B) * W);
       o.dc0[l] = cv.take<float>((size_t)B * W);
       o.dc1[l] = cv.take<float>((size_t)B * W);
     }
@@ -443,8 +446,11 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       if (l > 0) {
         const bool masked_in = masks != nullptr && (l - 1) > 0;
         const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
-        KL_TRY(kl_launch_gemm_tn(X, v2 ? d.KTp[l] : d.KT_hi[l], w.P1, v2 ? d.bp[l] : P + h->off_b[l], B * T, 4 * W, W, W, W, 4 * W, 0, 1, 1.f, s));
+        // (second generation: P in bf16, gate-interleaved -- half the bytes written here and read by the scan)
+        KL_TRY(kl_launch_gemm_tn(X, v2 ? d.KTp[l] : d.KT_hi[l], w.P1, v2 ? d.bp[l] : P + h->off_b[l], B * T, 4 * W, W, W, W, 4 * W,
+                                 v2 && h->scan2_bf16 ? 1 : 0, 1, 1.f, s));
         a.P = w.P1;
+        a.p_bf16 = v2 && h->scan2_bf16 ? 1 : 0;
       } else if (v2) {
         KL_TRY(kl_launch_ids_tm(idx, ctx, c.n_ctx, B, T, W, c.voc_size, c.ctx_vocab, w.ids_tm, s));
         a.EK = d.EKp;
@@ -460,6 +466,7 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
         a.bias = P + h->off_b[0];
       }
       a.H = (bf16_t*)w.H[l]; a.C = w.C[l]; a.G = w.G[l];
+      a.Cb = (v2 && w.scan2_bwd && h->scan2_bf16) ? w.Cb[l] : nullptr;
       a.Hd = masked ? w.Hd[l] : nullptr;
       a.mask = masked ? masks + (size_t)l * BW : nullptr;
       a.HT = w.km_plan ? nullptr : w.HTf[l]; a.ldt = (long)(T + 1) * B;       // (K-major GEMMs: no transposed outputs)
@@ -780,6 +787,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   if (env8b) h->scan2_rows = atoi(env8b);
   const char* env8c = getenv("KL_SCAN2_PF");
   if (env8c) h->scan2_pf = atoi(env8c);
+  const char* env8e = getenv("KL_SCAN2_BF16");
+  if (env8e) h->scan2_bf16 = atoi(env8e) != 0;
   const char* env8d = getenv("KL_SCAN2_PFB");
   if (env8d) h->scan2_pfb = atoi(env8d);
   const char* env5 = getenv("KL_WIDE_FWD_MIN");
@@ -879,7 +888,9 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   KL_TRY(kl_launch_softmax_ce(w.logits, V, BT, V, tgt, B, T, 1.0f / (h->last_only ? (float)B : (float)BT), w.dlogits, Vp, loss_acc,
                               w.rowstat, 1, s, h->last_only));
   // B1: dH = dlogits . E ; dE += dlogits^T . Htop
-  KL_TRY(kl_launch_gemm_tn(w.dlogits, d.ET, w.dH, nullptr, BT, W, Vp, Vp, Vp, W, 0, 1, 1.f, s));
+  // (second-generation backward scan: dH travels as bf16)
+  const int dh_mode = w.scan2_bwd ? 1 : 0;
+  KL_TRY(kl_launch_gemm_tn(w.dlogits, d.ET, w.dH, nullptr, BT, W, Vp, Vp, Vp, W, dh_mode, 1, 1.f, s));
   if (BTp != BT) {
     KL_TRY(kl_zero_async(w.dlogitsT, (size_t)Vp * BTp * sizeof(bf16_t), s));
     KL_TRY(kl_zero_async(w.HT, (size_t)W * BTp * sizeof(bf16_t), s));
@@ -977,7 +988,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   if (sequential || w.scan2_bwd) {
     for (int l = L - 1; l >= 0; --l) {
       if (l < L - 1)   // dX_l = dZ_{l+1} . K_{l+1}^T  -> w.dH (free once the layer above has been scanned)
-        KL_TRY(kl_launch_gemm_tn(w.dZ[l + 1], d.Kn[l + 1], w.dH, nullptr, BT, W, 4 * W, 4 * W, 4 * W, W, 0, 1, 1.f, s));
+        KL_TRY(kl_launch_gemm_tn(w.dZ[l + 1], d.Kn[l + 1], w.dH, nullptr, BT, W, 4 * W, 4 * W, 4 * W, W, dh_mode, 1, 1.f, s));
       KlScanBwd a;
       memset(&a, 0, sizeof(a));
       a.B = B; a.T = T; a.W = W; a.L = 1;
@@ -987,6 +998,8 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       a.dZ[0] = w.dZ[l];
       a.mask[0] = (masks != nullptr && l > 0) ? masks + (size_t)l * BW : nullptr;
       a.dH = w.dH;
+      a.dHb = reinterpret_cast<const bf16_t*>(w.dH);
+      a.Cb = (w.scan2_bwd && h->scan2_bf16) ? w.Cb[l] : nullptr;
       a.counters = w.scan_cnt;
       a.status = w.scan_status + 1;
       // (sentinels pay with several row blocks per workgroup, where the next tile is prefetched; with one

@@ -436,6 +436,38 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
     }
     return;
   }
+  if (OUT == 1 && (ldc & 3) == 0 && (n0 + LBN <= N) && ((size_t)Cv & 7) == 0) {
+    // bf16 stores in whole rows (dH / dX of the second-generation backward scan): as the f32 form below, 8 bytes per lane,
+    // 32 lanes = one 256-byte row segment
+    constexpr int LDP = LBN + 4;
+    float* ct = reinterpret_cast<float*>(smem);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < RF; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ct[(wm * WROWS + i * 16 + fq * 4 + r) * LDP + wn * WCOLS + j * 16 + fr] = acc[i][j][r] * alpha;
+    __syncthreads();
+    const int c4 = (tid & 31) * 4;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) bv = f32x4{bias[n0 + c4], bias[n0 + c4 + 1], bias[n0 + c4 + 2], bias[n0 + c4 + 3]};
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(Cv);
+    constexpr int RPP = 64 * NW / 32;
+#pragma unroll 4
+    for (int p = 0; p < TBM / RPP; ++p) {
+      const int row = p * RPP + (tid >> 5);
+      if (m0 + row < M) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ct + row * LDP + c4) + bv;
+        uint2 pk;
+        pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2*>(Cb + (long)(m0 + row) * ldc + n0 + c4) = pk;
+      }
+    }
+    return;
+  }
   if (OUT == 0 && (ldc & 3) == 0 && (n0 + LBN <= N) && ((size_t)Cv & 15) == 0) {
     // f32 stores in whole rows: the accumulator layout (4 rows x 1 column per lane) would
     // write 64-byte row segments; turn the tile through LDS (the ring is free now) so that
@@ -525,7 +557,7 @@ __device__ __forceinline__ void quad_transpose(f32x4& m, int k) {
 
 __global__ __launch_bounds__(512, 1) void gemm_tn_pers_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* __restrict__ C, const float* __restrict__ bias,
-    int M, int N, int K, long lda, long ldb, long ldc, float alpha, int tiles_n, int total) {
+    int M, int N, int K, long lda, long ldb, long ldc, float alpha, int tiles_n, int total, int out_bf16) {
   constexpr int RF = 4, WN = 2;               // 8 waves as 4 x 2, each 64 x 64
   constexpr int WROWS = 64, TBM = 256, WCOLS = 64, NT = 4;
   constexpr int PA = 4, PB = 2, NP = 6, NP0 = 3;
@@ -642,9 +674,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pers_kernel(
       // the tile is complete: out it goes, straight from the accumulators
       const int L = first + it_c * (int)gridDim.x;
       const int m0 = (L / tiles_n) * TBM, n0 = (L % tiles_n) * LBN;
-      const long bytes = ((long)(M - m0 - 1) * ldc + (N - n0)) * 4;
+      // (out_bf16: C is a bf16 matrix -- the gate-input rows P of the second-generation wide scans: half the bytes)
+      const int esz = out_bf16 ? 2 : 4;
+      const long bytes = ((long)(M - m0 - 1) * ldc + (N - n0)) * esz;
       const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
-          C + (long)m0 * ldc + n0, 0, (int)(unsigned)(bytes > 0xffffffffL ? 0xffffffffL : bytes), 0x00020000);
+          reinterpret_cast<char*>(C) + ((long)m0 * ldc + n0) * esz, 0, (int)(unsigned)(bytes > 0xffffffffL ? 0xffffffffL : bytes), 0x00020000);
       const int k = fr & 3, c4 = fr & ~3;
 #pragma unroll
       for (int i = 0; i < RF; ++i) {
@@ -658,8 +692,14 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_pers_kernel(
           if (bias != nullptr && n0 + col + 3 < N) bv = *reinterpret_cast<const f32x4*>(bias_l + n0 + col);
           v = v * alpha + bv;
           // (a column past N would land in the next row's bytes: push it out of the buffer instead)
-          const unsigned off = (n0 + col < N) ? (unsigned)(((long)row * ldc + col) * 4) : 0xfffffff0u;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4g, v), rsC, (int)off, 0, 0);
+          const unsigned off = (n0 + col < N) ? (unsigned)(((long)row * ldc + col) * esz) : 0xfffffff0u;
+          if (out_bf16) {
+            typedef __attribute__((ext_vector_type(2))) unsigned int u32x2g;
+            const u32x2g pk = u32x2g{(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
+            __builtin_amdgcn_raw_buffer_store_b64(pk, rsC, (int)off, 0, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4g, v), rsC, (int)off, 0, 0);
+          }
           acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
@@ -737,7 +777,7 @@ int kl_launch_gemm_tn(const bf16_t* A, const bf16_t* B, void* C, const float* bi
   static const bool small_all = getenv("KL_GEMM_SMALL_ALL") && getenv("KL_GEMM_SMALL_ALL")[0] == '1';   // experiment
   static const bool pers = !(getenv("KL_GEMM_PERS") && getenv("KL_GEMM_PERS")[0] == '0');
   // (measured at M = 262144: K = 512 -- P, logits -- 8-10 % faster than one workgroup per tile; K = 2048 and K = 256 not)
-  if (pers && !small_all && long_mode >= 2 && long_ok && out_mode == 0 && K >= 6 * BK && K <= 16 * BK && (N & 3) == 0 && (ldc & 3) == 0 &&
+  if (pers && !small_all && long_mode >= 2 && long_ok && (out_mode == 0 || out_mode == 1) && K >= 6 * BK && K <= 16 * BK && (N & 3) == 0 && (ldc & 3) == 0 &&
       ((size_t)C & 15) == 0 && (bias == nullptr || N <= 2048) &&
       (long)((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) >= 512) {
     // many-row shapes with several tiles per CU: persistent workgroups (see gemm_tn_pers_kernel)
@@ -757,7 +797,7 @@ int kl_launch_gemm_tn(const bf16_t* A, const bf16_t* B, void* C, const float* bi
       attr_set = true;
     }
     hipLaunchKernelGGL(gemm_tn_pers_kernel, dim3(n_wg), dim3(512), lds, stream, A, B, (float*)C, bias, M, N, K, lda, ldb, ldc,
-                       alpha, tiles_n, total);
+                       alpha, tiles_n, total, out_mode == 1 ? 1 : 0);
     return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
   }
   if (!small_all && long_mode >= 2 && long_ok && splits == 1 && K >= 256 && (long)((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) >= 256) {

@@ -146,6 +146,9 @@ struct KlScanFwdWide {
   const int* ids_tm;                   // [T+1][B][2] byte offsets of the EK / CtxK[0] rows, time-major (kl_launch_ids_tm)
   int V, ctx_vocab;                    // rows of EK / CtxK[0]
   int pf_mode;                         // where the next phase's tile is requested: 0 = top of a phase, 1 = behind the MFMA phase
+  bf16_t* Cb;                          // second generation: cell states for the backward scan as bf16 [(T+1)B][W] (blocks 1..T written;
+                                       // C then only receives block T, the carried-out state); null: every block goes to C in f32
+  int p_bf16;                          // second generation: P is bf16 [T*B][W][4 gates] (8 bytes per cell) instead of f32
 };
 bool kl_scan_fwd_wide_applicable(int B, int T, int W);
 int kl_launch_scan_fwd_wide(KlScanFwdWide args, hipStream_t stream);
@@ -175,6 +178,8 @@ struct KlScanBwd {
   int sentinel;                        // wide one-layer kernel only: 1 = hand-off by data sentinels (dZ pre-filled with 0xFFFF halfwords)
   unsigned* xcc_slots; unsigned gen;   // as KlScanFwdWide (sentinel hand-off only)
   int pf_mode;                         // second generation: as KlScanFwdWide
+  const bf16_t* dHb;                   // second generation: the gradient from above as bf16 [T*B][W] (dH unused)
+  const bf16_t* Cb;                    // second generation: cell states as bf16 [(T+1)B][W], blocks 1..T (null: C, f32)
 };
 int kl_launch_scan_bwd(KlScanBwd args, hipStream_t stream);
 bool kl_scan_bwd_wide_applicable(int B, int T, int W);

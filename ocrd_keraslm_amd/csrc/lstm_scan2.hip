@@ -58,6 +58,9 @@ __device__ __forceinline__ void aload8_glb(u32x2& d, const void* sbase, unsigned
 __device__ __forceinline__ void aload4_glb(unsigned& d, const void* sbase, unsigned voff) {
   asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(d) : "v"(voff), "s"(sbase) : "memory");
 }
+__device__ __forceinline__ void aload2_glb(unsigned& d, const void* sbase, unsigned voff) {
+  asm volatile("s_nop 4\n\tglobal_load_ushort %0, %1, %2" : "+v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
 __device__ __forceinline__ void aload16_buf(u32x4& d, __amdgpu_buffer_rsrc_t r, unsigned voff) {
   asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(d) : "v"(voff), "s"(r) : "memory");
 }
@@ -218,6 +221,8 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide2_kernel(const KlSc
   const long BW = (long)B * W;
   const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(a.H, (long)(T + 1) * BW * 2);
   const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(a.C, (long)(T + 1) * BW * 4);
+  const __amdgpu_buffer_rsrc_t rs_cb = make_rsrc(a.Cb, a.Cb ? (long)(T + 1) * BW * 2 : 0);
+  const __amdgpu_buffer_rsrc_t rs_cnull = make_rsrc(a.C, 0);
   const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.G, (long)T * BW * 4 * 2);
   const __amdgpu_buffer_rsrc_t rs_hd = make_rsrc(a.Hd, a.Hd ? (long)T * BW * 2 : 0);          // zero records: stores dropped
   const __amdgpu_buffer_rsrc_t rs_ek = make_rsrc(a.EK, TAB ? (long)a.V * 4 * W * 4 : 0);
@@ -282,6 +287,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide2_kernel(const KlSc
   // context row pieces, addressed through the ids in LDS
   const unsigned z_lane = (unsigned)((crow * 4 * W + (u0 + cunit) * 4) * 4);
   const unsigned tab_lane = (unsigned)((u0 + cunit) * 16);
+  const unsigned zb_lane = (unsigned)((crow * 4 * W + (u0 + (cunit & ~1)) * 4) * 2);      // (bf16 P: the 16 bytes of units 2k, 2k + 1)
   auto issue_ids = [&](int t, int r0, int slot) {       // (wave 0: the 256 bytes of (EK, context) row offsets from row r0 of block t on)
     if (wave == 0) {
       *reinterpret_cast<unsigned*>(ids_l + slot * 256 + lane * 4) = 0xFFFFFFFFu;
@@ -309,8 +315,13 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide2_kernel(const KlSc
     } else {
 #pragma unroll
       for (int s = 0; s < NB; ++s) {
-        const __amdgpu_buffer_rsrc_t rs_p = make_rsrc(a.P + ((long)t * B + r0 + s * 16) * 4 * W, (long)16 * 4 * W * 4);
-        glds16_plain(rs_p, z_lane, lds_zin + (unsigned)(s * 1024));
+        if (a.p_bf16) {      // 8 bytes per cell: a lane fetches the 16 bytes of its pair of units and uses its half
+          const __amdgpu_buffer_rsrc_t rs_p = make_rsrc(reinterpret_cast<const bf16_t*>(a.P) + ((long)t * B + r0 + s * 16) * 4 * W, (long)16 * 4 * W * 2);
+          glds16_plain(rs_p, zb_lane, lds_zin + (unsigned)(s * 1024));
+        } else {
+          const __amdgpu_buffer_rsrc_t rs_p = make_rsrc(a.P + ((long)t * B + r0 + s * 16) * 4 * W, (long)16 * 4 * W * 4);
+          glds16_plain(rs_p, z_lane, lds_zin + (unsigned)(s * 1024));
+        }
         ++vq;
       }
     }
@@ -455,6 +466,9 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide2_kernel(const KlSc
         if (TAB) {
           acc[s] = *reinterpret_cast<const f32x4*>(my_zin + (2 * s) * 1024);
           if (has_ctx) acc[s] += *reinterpret_cast<const f32x4*>(my_zin + (2 * s + 1) * 1024);
+        } else if (a.p_bf16) {
+          const uint2 pb = *reinterpret_cast<const uint2*>(my_zin + s * 1024 + (cunit & 1) * 8);
+          acc[s] = f32x4{u2f(pb.x << 16), u2f(pb.x & 0xffff0000u), u2f(pb.y << 16), u2f(pb.y & 0xffff0000u)};
         } else {
           acc[s] = *reinterpret_cast<const f32x4*>(my_zin + s * 1024);
         }
@@ -553,9 +567,19 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide2_kernel(const KlSc
           const int wv_c0 = NB == 2 ? 4 : 10, wv_c1 = NB == 2 ? 12 : 14;
           if (wave >= wv_c0 && wave < wv_c1) {
             const int prow = cq >> 4, seg = cq & 15;
-            store16(rs_c, (unsigned)((prow * W + seg * 4) * 4), ((trow + B) * W + u0) * 4u,
-                    *reinterpret_cast<const uint4*>(st_c + prow * F2_C_LD + seg * 16));
-            ++vq;
+            const uint4 cv = *reinterpret_cast<const uint4*>(st_c + prow * F2_C_LD + seg * 16);
+            if (a.Cb) {
+              // the backward scan reads bf16 cell states (half the bytes); the carried-out state (block T) stays f32 in C
+              uint2 cb;
+              cb.x = (unsigned)f2bf(u2f(cv.x)) | ((unsigned)f2bf(u2f(cv.y)) << 16);
+              cb.y = (unsigned)f2bf(u2f(cv.z)) | ((unsigned)f2bf(u2f(cv.w)) << 16);
+              __builtin_amdgcn_raw_buffer_store_b64(u32x2{cb.x, cb.y}, rs_cb, (int)((prow * W + seg * 4) * 2), (int)(((trow + B) * W + u0) * 2u), 0);
+              store16(t == T - 1 ? rs_c : rs_cnull, (unsigned)((prow * W + seg * 4) * 4), ((trow + B) * W + u0) * 4u, cv);
+              vq += 2;
+            } else {
+              store16(rs_c, (unsigned)((prow * W + seg * 4) * 4), ((trow + B) * W + u0) * 4u, cv);
+              ++vq;
+            }
           } else if (!TAB && wave >= wv_c1) {
             const int prow = hq >> 3, seg = hq & 7;
             store16(rs_hd, (unsigned)((prow * W + seg * 8) * 2), (trow * W + u0) * 2u,
@@ -594,14 +618,8 @@ constexpr int bwd2_lds_bytes(int ksteps) { return 2 * 4 * ksteps * 1024 + 16 * 1
 // Rolling sentinels (a.sentinel == 2) as in the first generation: the publishing lanes re-arm step t - 2 while they store
 // step t.  The re-arming store has completed before the same lanes publish step t - 1: a whole step of NP >= 2 blocks
 // lies between them, and the counted tile wait at the top of the block after next covers every store of this one.
-// Registers v124..v127 are kept out of the compiler's hands (amdgpu_num_vgpr(120) asks for it, tools/audit_async_regs.py
-// checks the generated code -- the attribute alone did not stop hipcc from using v120/v121 in the six-block variant): the epilogue inputs of the NEXT block (gates 8
-// bytes, c_{t-1} and dh 4 bytes each) land there, requested half a block ahead -- an HBM round trip
-// under this load takes ~3500 cycles -- and are moved into compiler registers behind the counted wait.  (As ordinary
-// asm outputs carried around the loop they were copied by the compiler at the loop head before the data had landed.)
-#define KL_B2_IN_REGS "v124", "v125", "v126", "v127"
 template <int KSTEPS, int NP>
-__global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(120))) void lstm_scan_bwd_wide2_kernel(const KlScanBwd a) {
+__global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlScanBwd a) {
   constexpr int W = KSTEPS * 32;
   constexpr int NWG_RB = W / 64;
   constexpr int JW = KSTEPS / 4;          // tile pieces per wave
@@ -632,7 +650,8 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(120))) void
   const bf16_t* Gl = a.G[0];
   const float* Cl = a.C[0];
   bf16_t* dZl = a.dZ[0];
-  const float* dH = a.dH;
+  const bf16_t* dHb = a.dHb;
+  const bf16_t* Cb = a.Cb;
   const float* maskl = a.mask[0];
   unsigned* status = a.status;
   // per block of this workgroup (slot 0 = the current one: rotated): running dc, the cell state c_t of the step
@@ -686,18 +705,6 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(120))) void
   // the top of the block they belong to and consumed behind its MFMA phase.  They are NOT carried around the loop:
   // a loop-carried asm destination was copied by the compiler at the loop head before its data had landed.
   const unsigned in_lane4 = (unsigned)((u0 + eu) * 4);
-  auto issue_inputs = [&](int t, int r0) {
-    const long trow = (long)t * B + r0 + er;
-    asm volatile("v_mov_b32 v124, -1\n\tv_mov_b32 v125, -1\n\tv_mov_b32 v126, -1\n\tv_mov_b32 v127, -1\n\t"
-                 "s_nop 4\n\tglobal_load_dwordx2 v[124:125], %0, %1"
-                 :: "v"(in_lane4 * 2), "s"(Gl + trow * W * 4) : "memory", KL_B2_IN_REGS);
-    asm volatile("s_nop 4\n\tglobal_load_dword v126, %0, %1" :: "v"(in_lane4), "s"(Cl + trow * W) : "memory", KL_B2_IN_REGS);
-    asm volatile("s_nop 4\n\tglobal_load_dword v127, %0, %1" :: "v"(in_lane4), "s"(dH + trow * W) : "memory", KL_B2_IN_REGS);
-    vq += 3;
-    seq_in = vq;
-  };
-  issue_inputs(T - 1, rg * 16);
-
   int n = 0;
   for (int t = T - 1; t >= 0; --t) {
 #pragma unroll 1
@@ -710,14 +717,25 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(120))) void
       if (ip2 >= NP) { ip2 = 0; t2 = t1 - 1; }
       const int r1 = (rg + ip1 * n_rg) * 16, r2 = (rg + ip2 * n_rg) * 16;
       SSTAMP(16);
-      // dropout keep-mask on dH (top layer; constant over the steps, served by L2): an asm load of THIS iteration into an
-      // armed compiler register, consumed behind the MFMA phase
-      unsigned mkin = maskl ? 0xFFFFFFFFu : 0x3f800000u;      // (no mask: 1.0f)
-      int seq_mk = 0;
-      if (maskl) {
-        aload4_glb(mkin, maskl + (long)(r0 + er) * W, in_lane4);
-        ++vq;
-        seq_mk = vq;
+      // Epilogue inputs of this block (gates 8 bytes, c_{t-1} and dh as bf16 or f32, the dropout mask on dH): asm loads of THIS
+      // iteration into compiler registers armed with all-ones (which no valid datum is: a 16-bit load zero-extends),
+      // consumed behind the MFMA phase.  They are not carried around the loop -- a loop-carried asm destination was copied
+      // by the compiler at the loop head before its data had landed -- and not kept in registers "reserved" from the
+      // compiler either: hipcc honoured neither amdgpu_num_vgpr nor asm clobbers once a variant needed the registers.
+      u32x2 gin = u32x2{0xFFFFFFFFu, 0xFFFFFFFFu};
+      unsigned cpin = 0xFFFFFFFFu, dhin = 0xFFFFFFFFu, mkin = maskl ? 0xFFFFFFFFu : 0x3f800000u;      // (no mask: 1.0f)
+      {
+        const long trow = (long)t * B + r0 + er;
+        aload8_glb(gin, Gl + trow * W * 4, in_lane4 * 2);
+        if (Cb && t > 0) aload2_glb(cpin, Cb + trow * W, in_lane4 >> 1);
+        else aload4_glb(cpin, Cl + trow * W, in_lane4);
+        aload2_glb(dhin, dHb + trow * W, in_lane4 >> 1);
+        vq += 3;
+        if (maskl) {
+          aload4_glb(mkin, maskl + (long)(r0 + er) * W, in_lane4);
+          ++vq;
+        }
+        seq_in = vq;
       }
       if (a.pf_mode == 0 && alive && t1 >= 0 && t1 < T - 1) issue_tile(t1, r1, buf ^ 1);       // (a.pf_mode: see the forward scan)
       if (alive && t < T - 1) {
@@ -788,31 +806,26 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(120))) void
       if (a.pf_mode == 1 && alive && t1 >= 0 && t1 < T - 1) issue_tile(t1, r1, buf ^ 1);     // (its buffer was last read a block ago)
       if (a.pf_mode == 2 && alive && t2 >= 0 && t2 < T - 1) issue_tile(t2, r2, buf);         // (every wave has finished this block's MFMAs)
       // ---- epilogue: thread = (row er, unit eu)
-      // this block's inputs (requested behind the epilogue of the block before); loads and stores retire independently,
-      // so the count is an estimate: the registers were armed with all-ones, which no valid datum is, and are checked
+      // (loads and stores retire independently, so the count is an estimate: the armed registers are checked)
       wait_vm(vq - seq_in);
-      u32x2 gin;
-      unsigned cpin, dhin;
-      asm volatile("v_mov_b32 %0, v124\n\tv_mov_b32 %1, v125\n\tv_mov_b32 %2, v126\n\tv_mov_b32 %3, v127"
-                   : "=v"(gin.x), "=v"(gin.y), "=v"(cpin), "=v"(dhin));
-      if (maskl) {
-        wait_vm(vq - seq_mk);
-        use_regs(mkin);
-      }
+      use_regs(gin);
+      use_regs(cpin);
+      use_regs(dhin);
+      use_regs(mkin);
       if (__any(max(max(gin.x, gin.y), max(cpin, max(dhin, mkin))) == 0xFFFFFFFFu)) {
 #ifdef KL_STAMP
         if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[29] += 1;
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("v_mov_b32 %0, v124\n\tv_mov_b32 %1, v125\n\tv_mov_b32 %2, v126\n\tv_mov_b32 %3, v127"
-                     : "=v"(gin.x), "=v"(gin.y), "=v"(cpin), "=v"(dhin));
+        use_regs(gin);
+        use_regs(cpin);
+        use_regs(dhin);
         use_regs(mkin);
       }
-      if (t1 >= 0) issue_inputs(t1, r1);       // (v124..v127 are free again)
       const float gi = bf2f((bf16_t)(gin.x & 0xffffu)), gf = bf2f((bf16_t)(gin.x >> 16));
       const float gg = bf2f((bf16_t)(gin.y & 0xffffu)), go = bf2f((bf16_t)(gin.y >> 16));
-      const float cp = u2f(cpin);
-      float dh = u2f(dhin);
+      const float cp = (Cb && t > 0) ? u2f(cpin << 16) : u2f(cpin);
+      float dh = u2f(dhin << 16);
       SSTAMP(21);
       const int wz = (eu >> 4) * 4;      // the four K-quarter waves of this unit group
       dh = dh * u2f(mkin) + (zt[wz][er][eu & 15] + zt[wz + 1][er][eu & 15] + zt[wz + 2][er][eu & 15] + zt[wz + 3][er][eu & 15]);
