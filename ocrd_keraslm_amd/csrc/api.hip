@@ -125,6 +125,7 @@ struct kl_handle {
   bool fused_step = true;       // incremental step, n >= 256: cell fused into the GEMM epilogue (KL_FUSED_STEP=0: separate kernels)
   bool scan2 = true;            // second-generation wide scans where their grid plan applies (KL_SCAN2=0: first generation)
   int scan2_rows = 0;           // KL_SCAN2_ROWS = 16 / 32: rows per forward phase (0: chosen by shape)
+  bool scan3 = false;           // KL_SCAN3 = 1: forward scans with the halves of a workgroup one barrier apart (lstm_scan_fwd_wide3_kernel)
   int scan2_pf = -1;            // KL_SCAN2_PF: where the forward scan requests its next tile (0: top of a phase, 1: behind the MFMA phase, 2: two phases ahead; -1: by shape)
   bool scan2_bf16 = true;       // KL_SCAN2_BF16=0: f32 instead of bf16 for what the scans exchange with later kernels (P, dH, c for backward)
   int scan2_pfb = -1;           // KL_SCAN2_PFB: the same for the backward scan (-1: by shape)
@@ -401,6 +402,7 @@ int plan_scan2(const kl_handle* h, int B, int T, bool km_plan, bool need_bwd) {
   if (W != 512) return 0;      // (one tile row = one 1 KiB DMA piece)
   if (h->wide_fwd_min <= 0 || !kl_scan_fwd_wide_applicable(B, T, W) || ((B + 15) / 16) * (W / 64) < h->wide_fwd_min) return 0;
   if (need_bwd && (!h->wide_bwd || !h->seq_bwd || !h->sentinel_bwd || !h->sentinel_roll || !kl_scan_wide2_phases(B, T, W, 16, 6))) return 0;
+  if (h->scan3 && kl_scan_wide2_phases(B, T, W, 16, 8)) return 16;
   const int p16 = kl_scan_wide2_phases(B, T, W, 16, 4), p32 = kl_scan_wide2_phases(B, T, W, 32, 4);
   if (h->scan2_rows == 16) return p16 ? 16 : 0;
   if (h->scan2_rows == 32) return p32 ? 32 : 0;
@@ -483,11 +485,14 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       // (two phases ahead needs the rows to have been published a phase before the request: three or more phases per workgroup)
       a.pf_mode = h->scan2_pf >= 0 ? h->scan2_pf : (v2 && kl_scan_wide2_phases(B, T, W, w.scan2_rows, 4) >= 3 ? 2 : 1);
       if (l == L - 1) h->trace_begin(0, s);
-      if (v2) KL_TRY(kl_launch_scan_fwd_wide2(a, w.scan2_rows, s));
+      const bool v3 = v2 && h->scan3 && w.scan2_rows == 16;
+      if (v3 && h->scan2_pf < 0) a.pf_mode = kl_scan_wide2_phases(B, T, W, 16, 8) >= 6 ? 2 : 1;
+      if (v3) KL_TRY(kl_launch_scan_fwd_wide3(a, s));
+      else if (v2) KL_TRY(kl_launch_scan_fwd_wide2(a, w.scan2_rows, s));
       else KL_TRY(kl_launch_scan_fwd_wide(a, s));
       if (l == L - 1) {
         h->trace_persistent[0] = true;
-        h->trace_name[0] = v2 ? "lstm_scan_fwd_wide2_kernel" : "lstm_scan_fwd_wide_kernel";
+        h->trace_name[0] = v3 ? "lstm_scan_fwd_wide3_kernel" : v2 ? "lstm_scan_fwd_wide2_kernel" : "lstm_scan_fwd_wide_kernel";
         h->trace_flops[0] = (double)B * T * (2.0 * W * 4.0 * W);   // one layer's recurrent contraction
         h->trace_end(0, s);
       }
@@ -783,6 +788,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->fused_step = !(env6 && env6[0] == '0');
   const char* env8 = getenv("KL_SCAN2");
   if (env8) h->scan2 = atoi(env8) != 0;
+  const char* env8s = getenv("KL_SCAN3");
+  if (env8s) h->scan3 = atoi(env8s) != 0;
   const char* env8b = getenv("KL_SCAN2_ROWS");
   if (env8b) h->scan2_rows = atoi(env8b);
   const char* env8c = getenv("KL_SCAN2_PF");

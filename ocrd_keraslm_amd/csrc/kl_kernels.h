@@ -156,6 +156,7 @@ int kl_launch_scan_fwd_wide(KlScanFwdWide args, hipStream_t stream);
 // (forward scans: max_np 4; backward scan, always 16-row blocks: 6)
 int kl_scan_wide2_phases(int B, int T, int W, int rows, int max_np);
 int kl_launch_scan_fwd_wide2(KlScanFwdWide args, int rows, hipStream_t stream);
+int kl_launch_scan_fwd_wide3(KlScanFwdWide args, hipStream_t stream);      // 16-row phases, halves of a workgroup one barrier apart
 int kl_launch_permute_gate_cols_f32(const float* in, const float* bias, float* out, long rows, int W, hipStream_t stream);
 int kl_launch_permute_gate_rows_bf16(const bf16_t* in, bf16_t* out, int W, int K, hipStream_t stream);
 int kl_launch_ids_tm(const int* idx, const int* ctx, int n_ctx, int B, int T, int W, int V, int ctx_vocab, int* out,

@@ -21,7 +21,18 @@ for _ in range(n): step()
 torch.cuda.synchronize()
 dt=(time.time()-t)/n
 print(f"train B={B} T={T}: {dt*1e3:.2f} ms/step, {B*T/dt/1e6:.2f} Mchars/s, loss", lm.read_loss())
-import os
+if os.environ.get('KL_PROBE_TRACE'):
+    import ctypes as C
+    hipabi.check(lm.lib.kl_trace_enable(lm.handle, 1))
+    for _ in range(3): step()
+    torch.cuda.synchronize()
+    for kind in (0, 1):
+        nn, ms, pers, fl = C.c_int(), C.c_float(), C.c_int(), C.c_double()
+        hipabi.check(lm.lib.kl_trace_read(lm.handle, kind, C.byref(nn), C.byref(ms), C.byref(pers), C.byref(fl)))
+        print("  %s: %.3f ms per launch (%d launches), %.1f%% of the MFMA roof" % (
+            lm.lib.kl_trace_kernel_name(lm.handle, kind).decode(), ms.value / max(nn.value, 1), nn.value,
+            100 * fl.value / (ms.value / max(nn.value, 1) * 1e-3) / 2.5e15 if ms.value else 0))
+    hipabi.check(lm.lib.kl_trace_enable(lm.handle, 0))
 if os.environ.get('KL_PROBE_TRAIN_ONLY'): sys.exit(0)
 # forward only (inference split)
 lm.prepare(hipabi.KL_PREC_SPLIT)
