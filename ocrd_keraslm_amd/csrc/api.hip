@@ -125,9 +125,9 @@ struct kl_handle {
   bool fused_step = true;       // incremental step, n >= 256: cell fused into the GEMM epilogue (KL_FUSED_STEP=0: separate kernels)
   bool scan2 = true;            // second-generation wide scans where their grid plan applies (KL_SCAN2=0: first generation)
   int scan2_rows = 0;           // KL_SCAN2_ROWS = 16 / 32: rows per forward phase (0: chosen by shape)
-  bool scan3 = false;           // KL_SCAN3 = 1: forward scans with the halves of a workgroup one barrier apart (lstm_scan_fwd_wide3_kernel)
   int scan2_pf = -1;            // KL_SCAN2_PF: where the forward scan requests its next tile (0: top of a phase, 1: behind the MFMA phase, 2: two phases ahead; -1: by shape)
   bool scan2_bf16 = true;       // KL_SCAN2_BF16=0: f32 instead of bf16 for what the scans exchange with later kernels (P, dH, c for backward)
+  bool fuse_wg = true;          // KL_FUSE_WG = 0: one launch per weight-gradient product (else products over the same dZ share a pass)
   int scan2_pfb = -1;           // KL_SCAN2_PFB: the same for the backward scan (-1: by shape)
   int wide_fwd_min = 96;        // layer-sequential wide forward scans from this many 64-unit workgroups (KL_WIDE_FWD_MIN; 0 = never)
   double trace_flops[2] = {0.0, 0.0};   // algorithmic FLOPs of ONE timed launch
@@ -402,12 +402,11 @@ int plan_scan2(const kl_handle* h, int B, int T, bool km_plan, bool need_bwd) {
   if (W != 512) return 0;      // (one tile row = one 1 KiB DMA piece)
   if (h->wide_fwd_min <= 0 || !kl_scan_fwd_wide_applicable(B, T, W) || ((B + 15) / 16) * (W / 64) < h->wide_fwd_min) return 0;
   if (need_bwd && (!h->wide_bwd || !h->seq_bwd || !h->sentinel_bwd || !h->sentinel_roll || !kl_scan_wide2_phases(B, T, W, 16, 6))) return 0;
-  if (h->scan3 && kl_scan_wide2_phases(B, T, W, 16, 8)) return 16;
   const int p16 = kl_scan_wide2_phases(B, T, W, 16, 4), p32 = kl_scan_wide2_phases(B, T, W, 32, 4);
   if (h->scan2_rows == 16) return p16 ? 16 : 0;
   if (h->scan2_rows == 32) return p32 ? 32 : 0;
-  // (by shape: 32-row phases once three of them keep a workgroup busy while a publish travels, else 16-row phases)
-  if (p32 >= 3) return 32;
+  // (by shape, measured at B = 1024 .. 3072: 32-row phases as soon as a workgroup has two of them per step)
+  if (p32 >= 2) return 32;
   if (p16) return 16;
   return p32 ? 32 : 0;
 }
@@ -485,14 +484,11 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       // (two phases ahead needs the rows to have been published a phase before the request: three or more phases per workgroup)
       a.pf_mode = h->scan2_pf >= 0 ? h->scan2_pf : (v2 && kl_scan_wide2_phases(B, T, W, w.scan2_rows, 4) >= 3 ? 2 : 1);
       if (l == L - 1) h->trace_begin(0, s);
-      const bool v3 = v2 && h->scan3 && w.scan2_rows == 16;
-      if (v3 && h->scan2_pf < 0) a.pf_mode = kl_scan_wide2_phases(B, T, W, 16, 8) >= 6 ? 2 : 1;
-      if (v3) KL_TRY(kl_launch_scan_fwd_wide3(a, s));
-      else if (v2) KL_TRY(kl_launch_scan_fwd_wide2(a, w.scan2_rows, s));
+      if (v2) KL_TRY(kl_launch_scan_fwd_wide2(a, w.scan2_rows, s));
       else KL_TRY(kl_launch_scan_fwd_wide(a, s));
       if (l == L - 1) {
         h->trace_persistent[0] = true;
-        h->trace_name[0] = v3 ? "lstm_scan_fwd_wide3_kernel" : v2 ? "lstm_scan_fwd_wide2_kernel" : "lstm_scan_fwd_wide_kernel";
+        h->trace_name[0] = v2 ? "lstm_scan_fwd_wide2_kernel" : "lstm_scan_fwd_wide_kernel";
         h->trace_flops[0] = (double)B * T * (2.0 * W * 4.0 * W);   // one layer's recurrent contraction
         h->trace_end(0, s);
       }
@@ -788,14 +784,14 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->fused_step = !(env6 && env6[0] == '0');
   const char* env8 = getenv("KL_SCAN2");
   if (env8) h->scan2 = atoi(env8) != 0;
-  const char* env8s = getenv("KL_SCAN3");
-  if (env8s) h->scan3 = atoi(env8s) != 0;
   const char* env8b = getenv("KL_SCAN2_ROWS");
   if (env8b) h->scan2_rows = atoi(env8b);
   const char* env8c = getenv("KL_SCAN2_PF");
   if (env8c) h->scan2_pf = atoi(env8c);
   const char* env8e = getenv("KL_SCAN2_BF16");
   if (env8e) h->scan2_bf16 = atoi(env8e) != 0;
+  const char* env8f = getenv("KL_FUSE_WG");
+  if (env8f) h->fuse_wg = atoi(env8f) != 0;
   const char* env8d = getenv("KL_SCAN2_PFB");
   if (env8d) h->scan2_pfb = atoi(env8d);
   const char* env5 = getenv("KL_WIDE_FWD_MIN");
@@ -926,7 +922,14 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   auto weight_grads = [&](int l, bool dzt_ready, bool db_done, bool dz_km) -> int {
     if (!dzt_ready && !dz_km) KL_TRY(kl_launch_transpose_bf16(w.dZ[l], 4 * W, w.dZT, BTp, BT, 4 * W, s));
     // dU_l = Hprev^T . dZ   (Hprev = H blocks 0..T-1)
-    if (dz_km) {
+    // (dz_km: every product over the layer's dZ rows in as few passes over them as possible -- KlGemmSecond, gemm.hip)
+    const bool pair_uk = dz_km && l > 0 && h->fuse_wg && (W % 128) == 0;
+    if (pair_uk) {
+      const bool masked_in = masks != nullptr && (l - 1) > 0;
+      const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
+      KL_TRY(kl_launch_gemm_an2(w.dZ[l], (const bf16_t*)w.H[l], grads + h->off_U[l], 4 * W, W, BT, 4 * W, W, 4 * W, 1,
+                                X, grads + h->off_K[l], W, W, 4 * W, 1, s, 1));
+    } else if (dz_km) {
       KL_TRY(kl_launch_gemm_an(w.dZ[l], (const bf16_t*)w.H[l], grads + h->off_U[l], 4 * W, W, BT, 4 * W, W, 4 * W, 1, s, 1));
     } else if (w.ht_ready) {
       KL_TRY(kl_launch_gemm_tn(w.HTf[l], w.dZT, grads + h->off_U[l], nullptr, W, 4 * W, BT, ldtf, BTp, 4 * W, 2, ksplit, 1.f, s));
@@ -939,7 +942,9 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       // dK_l = X^T . dZ with X = (masked) outputs of layer l-1
       const bool masked_in = masks != nullptr && (l - 1) > 0;
       const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
-      if (dz_km) {
+      if (pair_uk) {
+        // (done with dU above)
+      } else if (dz_km) {
         KL_TRY(kl_launch_gemm_an(w.dZ[l], X, grads + h->off_K[l], 4 * W, W, BT, 4 * W, W, 4 * W, 1, s, 1));
       } else if (w.ht_ready) {
         const bf16_t* XT = masked_in ? w.HdT[l - 1] : w.HTf[l - 1] + B;
@@ -953,7 +958,15 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       KL_TRY(kl_zero_async(w.OHT, (size_t)Vp * BTp * sizeof(bf16_t), s));
       KL_TRY(kl_launch_onehot_t(idx, B, T, V, 0, 1, w.OHT, BTp, s));
       KL_TRY(kl_zero_async(w.dEKT, (size_t)4 * W * Vp * sizeof(float), s));
-      if (dz_km) KL_TRY(kl_launch_gemm_an(w.dZ[l], w.OHT, w.dEKT, 4 * W, Vp, BT, 4 * W, BTp, Vp, 0, s));
+      // (the first context variable's one-hot product rides along with the characters': one pass over dZ for both)
+      const bool pair_ctx = dz_km && h->fuse_wg && c.n_ctx >= 1 && (Vp % 128) == 0;
+      if (pair_ctx) {
+        KL_TRY(kl_zero_async(w.OHC[0], (size_t)c.ctx_vocab * BTp * sizeof(bf16_t), s));
+        KL_TRY(kl_launch_onehot_t(ctx, B, T, c.ctx_vocab, 0, c.n_ctx, w.OHC[0], BTp, s));
+        KL_TRY(kl_zero_async(w.dCtxKT[0], (size_t)4 * W * c.ctx_vocab * sizeof(float), s));
+        KL_TRY(kl_launch_gemm_an2(w.dZ[l], w.OHT, w.dEKT, 4 * W, Vp, BT, 4 * W, BTp, Vp, 0,
+                                  w.OHC[0], w.dCtxKT[0], c.ctx_vocab, BTp, c.ctx_vocab, 0, s, 0));
+      } else if (dz_km) KL_TRY(kl_launch_gemm_an(w.dZ[l], w.OHT, w.dEKT, 4 * W, Vp, BT, 4 * W, BTp, Vp, 0, s));
       else KL_TRY(kl_launch_gemm_tn(w.dZT, w.OHT, w.dEKT, nullptr, 4 * W, Vp, BTp, BTp, BTp, Vp, 2, ksplit, 1.f, s));
       KL_TRY(kl_launch_f32_to_bf16_t(w.dEKT, Vp, 4 * W, Vp, w.dEKT_bf, nullptr, Vp, 0, s));
       KL_TRY(kl_launch_f32_to_bf16_t(w.dEKT, Vp, 4 * W, Vp, w.dEK_bf, nullptr, 4 * W, 1, s));
@@ -962,12 +975,14 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       // dE += dEK . K0[:W]^T     (C[V][W] = dEK[V][4W] . Kn0[W][4W]^T)
       KL_TRY(kl_launch_gemm_tn(w.dEK_bf, d.Kn[0], grads + h->off_E, nullptr, V, W, 4 * W, 4 * W, 4 * W, W, 2, 1, 1.f, s));
       for (int n = 0; n < c.n_ctx; ++n) {
-        KL_TRY(kl_zero_async(w.OHC[n], (size_t)c.ctx_vocab * BTp * sizeof(bf16_t), s));
-        KL_TRY(kl_launch_onehot_t(ctx, B, T, c.ctx_vocab, n, c.n_ctx, w.OHC[n], BTp, s));
-        KL_TRY(kl_zero_async(w.dCtxKT[n], (size_t)4 * W * c.ctx_vocab * sizeof(float), s));
-        if (dz_km) KL_TRY(kl_launch_gemm_an(w.dZ[l], w.OHC[n], w.dCtxKT[n], 4 * W, c.ctx_vocab, BT, 4 * W, BTp, c.ctx_vocab, 0, s));
-        else KL_TRY(kl_launch_gemm_tn(w.dZT, w.OHC[n], w.dCtxKT[n], nullptr, 4 * W, c.ctx_vocab, BTp, BTp, BTp,
-                                      c.ctx_vocab, 2, ksplit, 1.f, s));
+        if (!(pair_ctx && n == 0)) {
+          KL_TRY(kl_zero_async(w.OHC[n], (size_t)c.ctx_vocab * BTp * sizeof(bf16_t), s));
+          KL_TRY(kl_launch_onehot_t(ctx, B, T, c.ctx_vocab, n, c.n_ctx, w.OHC[n], BTp, s));
+          KL_TRY(kl_zero_async(w.dCtxKT[n], (size_t)4 * W * c.ctx_vocab * sizeof(float), s));
+          if (dz_km) KL_TRY(kl_launch_gemm_an(w.dZ[l], w.OHC[n], w.dCtxKT[n], 4 * W, c.ctx_vocab, BT, 4 * W, BTp, c.ctx_vocab, 0, s));
+          else KL_TRY(kl_launch_gemm_tn(w.dZT, w.OHC[n], w.dCtxKT[n], nullptr, 4 * W, c.ctx_vocab, BTp, BTp, BTp,
+                                        c.ctx_vocab, 2, ksplit, 1.f, s));
+        }
         const size_t krow = (size_t)(W + n * c.ctx_dim) * 4 * W;
         KL_TRY(kl_launch_ctx_grads(P + h->off_Ctx[n], P + h->off_K[0] + krow, 4 * W, c.ctx_vocab, c.ctx_dim,
                                    w.dCtxKT[n], c.ctx_vocab, 4 * W, grads + h->off_K[0] + krow, 4 * W,
@@ -1012,8 +1027,9 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       // (sentinels pay with several row blocks per workgroup, where the next tile is prefetched; with one
       // block the cheap counter poll beats re-fetching 64 KiB tiles; XCD-local publishes measured slower here)
       a.sentinel = (w.scan2_bwd || (h->sentinel_bwd && wide_fits && (kl_scan_wide_blocks_per_wg(B, W) > 1 || h->sentinel_bwd_all))) ? 1 : 0;
-      // (measured: with two blocks per workgroup a request at the top of a block comes too early and is re-fetched)
-      a.pf_mode = h->scan2_pfb >= 0 ? h->scan2_pfb : (kl_scan_wide2_phases(B, T, W, 16, 6) >= 3 ? 0 : 1);
+      // (measured at B = 1024 .. 3072: the request behind the MFMA phase is the best or tied everywhere; at the top of the block
+      //  one tile in ten is requested before it is published, and the re-fetch costs more than the earlier request saves)
+      a.pf_mode = h->scan2_pfb >= 0 ? h->scan2_pfb : 1;
       a.xcc_slots = (a.sentinel && h->xcd_local_bwd) ? w.scan_status + 4 : nullptr;
       a.gen = (unsigned)(1 + L + l);
       if (a.sentinel && h->sentinel_roll && T >= 3) {

@@ -205,11 +205,28 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+// Two products over ONE A operand in one launch: C = A.B^T for the column tiles below n_first, C2 = A.B2^T for the
+// tiles from n_first on (n_first a multiple of the 128-column tile).  The weight-gradient contractions of a layer all read
+// the same T*B rows of dZ -- 3.2 GB at the benchmark shape, which is what bounds each of them -- so the recurrent and
+// the input kernel's gradients (and the two look-up tables' of layer 0) share one pass over it.
+struct KlGemmSecond {
+  const bf16_t* B;      // null: a single product
+  void* C;
+  int n_first, N;
+  long ldb, ldc;
+  int c_transposed;
+};
+
 template <int OUT, bool ILV, int RF, int WM, int WN, bool ATR = false, bool BTR = false>
 __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
-    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv,
-    const float* __restrict__ bias, int M, int N, int K, long lda, long ldb, long ldc,
-    int k_per_split, float alpha, const KlGateEpi epi, int xcd_remap, int c_t) {
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B_, void* __restrict__ Cv_,
+    const float* __restrict__ bias, int M, int N_, int K, long lda, long ldb_, long ldc_,
+    int k_per_split, float alpha, const KlGateEpi epi, int xcd_remap, int c_t_, const KlGemmSecond second) {
+  // (second.B: column tiles from second.n_first on belong to a second product over the same A -- see KlGemmSecond)
+  const bf16_t* __restrict__ B = B_;
+  void* __restrict__ Cv = Cv_;
+  int N = N_, c_t = c_t_;
+  long ldb = ldb_, ldc = ldc_;
   static_assert(!(ATR || BTR) || (RF == 4 && WM == 4 && WN == 2), "K-major operands: 256 x 128 tiles only");
   constexpr bool PRIO = KL_GEMM_PRIO;
   constexpr int NW = WM * WN;
@@ -244,7 +261,20 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tn_long_kernel(
     }
   }
   const int m0 = by * TBM;
-  const int n0 = bx * LBN;
+  int n0 = bx * LBN;
+  if (second.B != nullptr) {
+    if (n0 >= second.n_first) {
+      n0 -= second.n_first;
+      B = second.B;
+      Cv = second.C;
+      N = second.N;
+      ldb = second.ldb;
+      ldc = second.ldc;
+      c_t = second.c_transposed;
+    } else {
+      N = second.n_first;
+    }
+  }
   const int kbeg = bz * k_per_split;
   const int kend = min(K, kbeg + k_per_split);
   const int nkt = (kend - kbeg) / BK;     // host guarantees whole k-tiles
@@ -731,9 +761,9 @@ int launch_long_t(int out_mode, dim3 grid, hipStream_t stream, const bf16_t* A, 
       attr_set = true;                                                                                                   \
     }                                                                                                                    \
     if (ilv) hipLaunchKernelGGL((gemm_tn_long_kernel<O, true, RF, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, A, B, C,  \
-                                bias, M, N, K, lda, ldb, ldc, k_per_split, alpha, epi, remap, 0);                        \
+                                bias, M, N, K, lda, ldb, ldc, k_per_split, alpha, epi, remap, 0, KlGemmSecond{});                        \
     else hipLaunchKernelGGL((gemm_tn_long_kernel<O, false, RF, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, A, B, C,     \
-                            bias, M, N, K, lda, ldb, ldc, k_per_split, alpha, epi, remap, 0);                            \
+                            bias, M, N, K, lda, ldb, ldc, k_per_split, alpha, epi, remap, 0, KlGemmSecond{});                            \
   } while (0)
   if (out_mode == 0) KL_LONG_CASE(0);
   else if (out_mode == 1) KL_LONG_CASE(1);
@@ -846,11 +876,14 @@ bool kl_gemm_an_applicable(int M, int N, int K, long lda_km) {
   return (long)kps * lda_km * 2 < 0x7fffffffL;
 }
 
-int kl_launch_gemm_an(const bf16_t* A_km, const bf16_t* B, float* C, int M, int N, int K, long lda_km, long ldb, long ldc,
-                      int c_transposed, hipStream_t stream, int b_km) {
+int kl_launch_gemm_an2(const bf16_t* A_km, const bf16_t* B, float* C, int M, int N, int K, long lda_km, long ldb, long ldc,
+                       int c_transposed, const bf16_t* B2, float* C2, int N2, long ldb2, long ldc2, int c_transposed2,
+                       hipStream_t stream, int b_km) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  if (!kl_gemm_an_applicable(M, N, K, lda_km) || (ldb & 7) || (!b_km && ldb >= (1L << 22))) return KL_ERR_SHAPE;
-  const int tiles = (M / LBM) * ((N + LBN - 1) / LBN);
+  if (B2 != nullptr && ((N % LBN) || N2 <= 0 || (ldb2 & 7) || (!b_km && ldb2 >= (1L << 22)))) return KL_ERR_SHAPE;
+  const int n_all = B2 != nullptr ? N + N2 : N;
+  if (!kl_gemm_an_applicable(M, n_all, K, lda_km) || (ldb & 7) || (!b_km && ldb >= (1L << 22))) return KL_ERR_SHAPE;
+  const int tiles = (M / LBM) * ((n_all + LBN - 1) / LBN);
   int sp = (256 + tiles - 1) / tiles;          // ~ one workgroup per CU
   const int nk = K / BK;
   if (sp > nk / 16) sp = nk / 16;              // at least 16 k-steps per workgroup
@@ -858,10 +891,21 @@ int kl_launch_gemm_an(const bf16_t* A_km, const bf16_t* B, float* C, int M, int 
   const int kps = ((nk + sp - 1) / sp) * BK;
   sp = (K + kps - 1) / kps;
   if ((long)kps * lda_km * 2 >= 0x7fffffffL) return KL_ERR_SHAPE;     // 32-bit offsets inside one split
-  if (b_km && (long)kps * ldb * 2 >= 0x7fffffffL) return KL_ERR_SHAPE;
-  dim3 grid((N + LBN - 1) / LBN, M / LBM, sp);
+  if (b_km && ((long)kps * ldb * 2 >= 0x7fffffffL || (B2 != nullptr && (long)kps * ldb2 * 2 >= 0x7fffffffL))) return KL_ERR_SHAPE;
+  dim3 grid((n_all + LBN - 1) / LBN, M / LBM, sp);
   KlGateEpi epi;
   memset(&epi, 0, sizeof(epi));
+  KlGemmSecond second;
+  memset(&second, 0, sizeof(second));
+  if (B2 != nullptr) {
+    second.B = B2;
+    second.C = C2;
+    second.n_first = N;
+    second.N = N2;
+    second.ldb = ldb2;
+    second.ldc = ldc2;
+    second.c_transposed = c_transposed2;
+  }
   const size_t lds = (size_t)LSTAGES * (LBM + LBN) * 128;
   static const int remap = !(getenv("KL_GEMM_XCD") && getenv("KL_GEMM_XCD")[0] == '0');
   static bool attr_set = false;
@@ -874,11 +918,16 @@ int kl_launch_gemm_an(const bf16_t* A_km, const bf16_t* B, float* C, int M, int 
   }
   if (b_km)
     hipLaunchKernelGGL((gemm_tn_long_kernel<2, true, 4, 4, 2, true, true>), grid, dim3(512), lds, stream, A_km, B, (void*)C,
-                       (const float*)nullptr, M, N, K, lda_km, ldb, ldc, kps, 1.f, epi, remap, c_transposed);
+                       (const float*)nullptr, M, N, K, lda_km, ldb, ldc, kps, 1.f, epi, remap, c_transposed, second);
   else
     hipLaunchKernelGGL((gemm_tn_long_kernel<2, true, 4, 4, 2, true, false>), grid, dim3(512), lds, stream, A_km, B, (void*)C,
-                       (const float*)nullptr, M, N, K, lda_km, ldb, ldc, kps, 1.f, epi, remap, c_transposed);
+                       (const float*)nullptr, M, N, K, lda_km, ldb, ldc, kps, 1.f, epi, remap, c_transposed, second);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+int kl_launch_gemm_an(const bf16_t* A_km, const bf16_t* B, float* C, int M, int N, int K, long lda_km, long ldb, long ldc,
+                      int c_transposed, hipStream_t stream, int b_km) {
+  return kl_launch_gemm_an2(A_km, B, C, M, N, K, lda_km, ldb, ldc, c_transposed, nullptr, nullptr, 0, 0, 0, 0, stream, b_km);
 }
 
 // z = A3 . WTperm^T with the LSTM cell as epilogue (see OUT == 3 above).  A3 [n][lda] bf16 rows,

@@ -36,6 +36,10 @@ int kl_launch_gemm_tn(const bf16_t* A, const bf16_t* B, void* C, const float* bi
 bool kl_gemm_an_applicable(int M, int N, int K, long lda_km);
 int kl_launch_gemm_an(const bf16_t* A_km, const bf16_t* B, float* C, int M, int N, int K, long lda_km, long ldb, long ldc,
                       int c_transposed, hipStream_t stream, int b_km = 0);
+// ... and a second product over the same A in the same launch: C2 (+)= A^T-view . B2^T (N a multiple of 128; see KlGemmSecond)
+int kl_launch_gemm_an2(const bf16_t* A_km, const bf16_t* B, float* C, int M, int N, int K, long lda_km, long ldb, long ldc,
+                       int c_transposed, const bf16_t* B2, float* C2, int N2, long ldb2, long ldc2, int c_transposed2,
+                       hipStream_t stream, int b_km);
 
 // ---- lstm_step.hip ------------------------------------------------------
 // One (activation, weight) operand pair of a thin fused step: rows of A are
@@ -156,7 +160,6 @@ int kl_launch_scan_fwd_wide(KlScanFwdWide args, hipStream_t stream);
 // (forward scans: max_np 4; backward scan, always 16-row blocks: 6)
 int kl_scan_wide2_phases(int B, int T, int W, int rows, int max_np);
 int kl_launch_scan_fwd_wide2(KlScanFwdWide args, int rows, hipStream_t stream);
-int kl_launch_scan_fwd_wide3(KlScanFwdWide args, hipStream_t stream);      // 16-row phases, halves of a workgroup one barrier apart
 int kl_launch_permute_gate_cols_f32(const float* in, const float* bias, float* out, long rows, int W, hipStream_t stream);
 int kl_launch_permute_gate_rows_bf16(const bf16_t* in, bf16_t* out, int W, int K, hipStream_t stream);
 int kl_launch_ids_tm(const int* idx, const int* ctx, int n_ctx, int B, int T, int W, int V, int ctx_vocab, int* out,

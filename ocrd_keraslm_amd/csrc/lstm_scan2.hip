@@ -608,335 +608,6 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide2_kernel(const KlSc
 
 namespace {
 
-// ---------------------------------------------------------------- forward, the two halves of a workgroup half a phase apart
-// In lstm_scan_fwd_wide2_kernel all 16 waves contract together and then all update their cells together: the matrix
-// pipes idle during the epilogue (~2500 VALU cycles per SIMD and 32 rows against 2048 MFMA cycles) and the vector pipes
-// during the MFMAs.  Here waves 0-7 (hidden units 0-31 of the workgroup's 64) and waves 8-15 (units 32-63) run the SAME
-// program ONE BARRIER APART: between two barriers one half contracts phase n while the other updates the cells of the
-// phase it contracted in the interval before, so every SIMD always hosts two contracting and two updating waves.
-//
-//   half-step hs:  barrier; group g does k = hs - g:   k even: store its half of phase k/2 - 1, start the accumulators
-//                                                              of phase k/2 from the gate inputs, contract;
-//                                                      k odd:  cell update of phase (k-1)/2 -> staging in LDS.
-//
-// Both groups execute every barrier, so the count is the same for all waves.  A tile is needed from hs = 2n (group 0) to
-// hs = 2n + 1 (group 1); it lives in one of THREE buffers, and the tile of phase m + a.pf_mode (1 or 2 phases ahead) is
-// requested behind barrier hs = 2m.  The halves of a phase's outputs leave at different times (each group stores its own
-// staging rows at the start of its next contraction), which the consumers' per-piece validity check does not mind.
-// 16-row phases only (NB = 1), width 512.
-constexpr int fwd3_lds_bytes(bool tab) {
-  return 3 * 16 * 1024 + 16 * (tab ? 2 : 1) * 1024 + 16 * (F2_G_LD + F2_C_LD + F2_H_LD) + (tab ? 512 : 16 * F2_H_LD) + 16;
-}
-
-template <int NP, bool TAB>
-__global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide3_kernel(const KlScanFwdWide a) {
-  constexpr int KSTEPS = 16, W = 512, NWG_RB = W / 64, ROWS = 16, NBUF = 3;
-  constexpr int NZ = TAB ? 2 : 1;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 3, wg = wave & 7;
-  const int n_rg = a.n_rg, B = a.B, T = a.T;
-  const int xcd = blockIdx.x & 7, yy = blockIdx.x >> 3;
-  const int cg = yy % NWG_RB, rq = yy / NWG_RB, rg = xcd * ((n_rg + 7) >> 3) + rq;
-  if (rg >= n_rg) return;
-  const int u0 = cg * 64;
-  const int n_ph = T * NP;
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const zin_l = smem + NBUF * 16 * 1024;
-  unsigned char* const st_g = zin_l + 16 * NZ * 1024;
-  unsigned char* const st_c = st_g + ROWS * F2_G_LD;
-  unsigned char* const pub = st_c + ROWS * F2_C_LD;
-  unsigned char* const st_hd = pub + ROWS * F2_H_LD;                       // (P mode)
-  unsigned char* const ids_l = pub + ROWS * F2_H_LD;                       // (table mode: [2][256])
-  int& ok_flag = *reinterpret_cast<int*>(pub + ROWS * F2_H_LD + (TAB ? 512 : ROWS * F2_H_LD));
-  const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)smem;
-  const unsigned lds_zin = lds_base + (unsigned)(NBUF * 16 * 1024 + wave * NZ * 1024);
-  const unsigned lds_ids = lds_base + (unsigned)(ids_l - smem);
-  const unsigned char* const my_zin = zin_l + wave * NZ * 1024 + lane * 16;
-
-  const int jr = lane & 3, a4 = (lane >> 2) & 3, q4 = lane >> 4;
-  const int crow = 4 * q4 + jr, cunit = 4 * wave + a4;
-
-  u32x4 bu[KSTEPS];
-  {
-    const int col = lane & 15;
-    const long wrow = ((long)(col & 3) * W + u0 + 4 * wave + (col >> 2)) * W + (lane >> 4) * 8;
-#pragma unroll
-    for (int j = 0; j < KSTEPS; ++j) bu[j] = *reinterpret_cast<const u32x4*>(a.UT + wrow + j * 32);
-  }
-  float cst[NP], mkv[TAB ? 1 : NP];        // cell state / dropout keep-mask of this lane's cell per phase of a step (slot 0: next to be used)
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    const long row = (long)(rg + p * n_rg) * ROWS + crow;
-    cst[p] = a.C[row * W + u0 + cunit];
-    if (!TAB) mkv[p] = a.mask ? a.mask[row * W + u0 + cunit] : 1.f;
-  }
-  if (TAB) mkv[0] = 1.f;
-  const long BW = (long)B * W;
-  const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(a.H, (long)(T + 1) * BW * 2);
-  const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(a.C, (long)(T + 1) * BW * 4);
-  const __amdgpu_buffer_rsrc_t rs_cb = make_rsrc(a.Cb, a.Cb ? (long)(T + 1) * BW * 2 : 0);
-  const __amdgpu_buffer_rsrc_t rs_null = make_rsrc(a.C, 0);
-  const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.G, (long)T * BW * 4 * 2);
-  const __amdgpu_buffer_rsrc_t rs_hd = make_rsrc(a.Hd, a.Hd ? (long)T * BW * 2 : 0);
-  const __amdgpu_buffer_rsrc_t rs_ek = make_rsrc(a.EK, TAB ? (long)a.V * 4 * W * 4 : 0);
-  const __amdgpu_buffer_rsrc_t rs_ck = make_rsrc(a.CtxK[0], (TAB && a.n_ctx > 0) ? (long)a.ctx_vocab * 4 * W * 4 : 0);
-  const __amdgpu_buffer_rsrc_t rs_id = make_rsrc(a.ids_tm, TAB ? (long)(T + 1) * B * 8 : 0);
-  const bool has_ctx = TAB && a.n_ctx > 0;
-  unsigned* status = a.status;
-  bool alive = true;
-  if (tid == 0) ok_flag = 1;
-#pragma unroll
-  for (int j = 0; j < KSTEPS; ++j) asm volatile("" : "+v"(bu[j]));
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    asm volatile("" : "+v"(cst[p]));
-    if (!TAB) asm volatile("" : "+v"(mkv[p]));
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  SSTAMP_INIT(0);
-
-#define row0(n) ((rg + ((n) % NP) * n_rg) * ROWS)      /* first row of phase n (no lambdas: closures that capture closures stay in scratch) */
-#define step_of(n) ((n) / NP)
-
-  int vq = 0, seq_t0 = 0, seq_t1 = 0, seq_t2 = 0, seq_z = 0, seq_id = 0;      // (scalars: an indexed array would live in scratch)
-  const unsigned dma_lane = (unsigned)((lane ^ wave) * 16);
-  const unsigned frag_lane = (unsigned)((lane & 15) * 1024 + (((lane >> 4) ^ (lane & 3)) * 16) + 64 * ((lane >> 2) & 3));
-  auto issue_tile = [&](int n) __attribute__((always_inline)) {       // wave w fetches row w of the tile of phase n (XOR-swizzled: see lstm_scan_fwd_wide2_kernel)
-    const int buf = n % NBUF;
-    arm16(smem + (buf * 16 + wave) * 1024 + lane * 16);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    glds16_sc1_s(rs_h, dma_lane, (unsigned)((((long)step_of(n) * B + row0(n) + wave) * W) * 2),
-                 lds_base + (unsigned)((buf * 16 + wave) * 1024));
-    ++vq;
-    seq_t0 = buf == 0 ? vq : seq_t0;      // (selects of values: conditional stores through the closure become an indexed access, i.e. scratch)
-    seq_t1 = buf == 1 ? vq : seq_t1;
-    seq_t2 = buf == 2 ? vq : seq_t2;
-  };
-  const unsigned z_lane = (unsigned)((crow * 4 * W + (u0 + cunit) * 4) * 4);
-  const unsigned zb_lane = (unsigned)((crow * 4 * W + (u0 + (cunit & ~1)) * 4) * 2);
-  const unsigned tab_lane = (unsigned)((u0 + cunit) * 16);
-  auto issue_ids = [&](int n) __attribute__((always_inline)) {        // (wave 0) row offsets of phase n into slot n & 1
-    if (wave == 0) {
-      *reinterpret_cast<unsigned*>(ids_l + (n & 1) * 256 + lane * 4) = 0xFFFFFFFFu;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      glds4_plain_s(rs_id, (unsigned)(lane * 4), (unsigned)(((long)step_of(n) * B + row0(n)) * 8), lds_ids + (unsigned)((n & 1) * 256));
-      ++vq;
-      seq_id = vq;
-    }
-  };
-  auto issue_zin = [&](int n) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < NZ; ++i) arm16(const_cast<unsigned char*>(my_zin) + i * 1024);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (TAB) {
-      const uint2 idv = *reinterpret_cast<const uint2*>(ids_l + (n & 1) * 256 + crow * 8);
-      glds16_plain(rs_ek, idv.x + tab_lane, lds_zin);
-      ++vq;
-      if (has_ctx) {
-        glds16_plain(rs_ck, idv.y + tab_lane, lds_zin + 1024u);
-        ++vq;
-      }
-    } else if (a.p_bf16) {
-      const __amdgpu_buffer_rsrc_t rs_p = make_rsrc(reinterpret_cast<const bf16_t*>(a.P) + ((long)step_of(n) * B + row0(n)) * 4 * W, (long)16 * 4 * W * 2);
-      glds16_plain(rs_p, zb_lane, lds_zin);
-      ++vq;
-    } else {
-      const __amdgpu_buffer_rsrc_t rs_p = make_rsrc(a.P + ((long)step_of(n) * B + row0(n)) * 4 * W, (long)16 * 4 * W * 4);
-      glds16_plain(rs_p, z_lane, lds_zin);
-      ++vq;
-    }
-    seq_z = vq;
-  };
-  auto zin_landed = [&]() __attribute__((always_inline)) {
-    bool ok = false;
-    for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
-      bool v = landed16(my_zin);
-      if (has_ctx) v = v && landed16(my_zin + 1024);
-      if (__all(v)) { ok = true; break; }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    if (!ok) { __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok_flag = 0; }
-  };
-
-  // ---- prologue
-  const int la = a.pf_mode >= 2 ? 2 : 1;          // tiles are requested this many phases ahead
-  issue_tile(0);
-  if (la > 1 && n_ph > 1) issue_tile(1);
-  if (TAB) {
-    issue_ids(0);
-    if (n_ph > 1) issue_ids(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-  issue_zin(0);
-
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int hs = 0; hs < 2 * n_ph + 2; ++hs) {
-    const int m = hs >> 1;
-    SSTAMP(0);
-    if (!(hs & 1) && m < n_ph && alive) {
-      // ---- (even barrier) the tile of phase m must be complete behind it: every wave waits for its own row
-      const int buf = m % NBUF;
-      wait_vm(vq - (buf == 0 ? seq_t0 : buf == 1 ? seq_t1 : seq_t2));
-      SSTAMP(8);
-      bool ok = __all(piece_there(smem + (buf * 16 + wave) * 1024 + lane * 16));
-      if (!ok) {
-#ifdef KL_STAMP
-        if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[12] += 1;
-#endif
-        for (unsigned spin = 0; spin < SPIN_LIMIT && !ok; ++spin) {
-          if (spin > 0) {      // (first round: only wait until everything issued has landed)
-            glds16_sc1_s(rs_h, dma_lane, (unsigned)((((long)step_of(m) * B + row0(m) + wave) * W) * 2),
-                         lds_base + (unsigned)((buf * 16 + wave) * 1024));
-            ++vq;
-          }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          ok = __all(piece_there(smem + (buf * 16 + wave) * 1024 + lane * 16));
-          if (!ok) {
-            if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-            __builtin_amdgcn_s_sleep(2);
-          }
-        }
-        if (!ok) {
-          __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok_flag = 0;
-        }
-      }
-      SSTAMP(9);
-      if (TAB && wave == 0 && m + 1 < n_ph) {      // the ids the waves read in this and the next interval (phase m + 1) have landed
-        wait_vm(vq - seq_id);
-        bool idok = false;
-        for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
-          asm volatile("" ::: "memory");
-          const unsigned v = *reinterpret_cast<const unsigned*>(ids_l + ((m + 1) & 1) * 256 + lane * 4);
-          if (__all(v != 0xFFFFFFFFu || lane * 4 >= ROWS * 8)) { idok = true; break; }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if (!idok) { __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok_flag = 0; }
-      }
-    }
-    SSTAMP(1);
-    __syncthreads();
-    SSTAMP(2);
-    alive = __builtin_amdgcn_readfirstlane(ok_flag) != 0;
-    // (the buffer of phase m + la was last read by group 1 in the interval before this barrier)
-    if (!(hs & 1) && m + la < n_ph && alive && (la > 1 || m + 1 < n_ph)) issue_tile(m + la);
-    const int k = hs - grp;
-    if (k < 0) continue;
-    const int n = k >> 1;
-    if (!(k & 1)) {
-      // ================= contraction half-step of phase n (and the stores of this group's half of phase n - 1)
-      if (n >= 1 && n - 1 < n_ph) {
-        const int np = n - 1;
-        const unsigned trow = (unsigned)(step_of(np) * B + row0(np));
-        const int hoff = grp * 32;                               // this group's units inside the workgroup's 64
-        int sl = lane;
-        asm volatile("" : "+v"(sl));
-        if (wg == 0) {            // h -> H block t + 1: 16 rows x 4 pieces of 8 units
-          const int prow = sl >> 2, seg = sl & 3;
-          const uint4 v = *reinterpret_cast<const uint4*>(pub + prow * F2_H_LD + (hoff + seg * 8) * 2);
-          store16_sc1(alive ? rs_h : rs_null, (unsigned)((prow * W + hoff + seg * 8) * 2) + ((trow + B) * W + u0) * 2u, v);
-          ++vq;
-        } else if (wg <= 4) {     // gates: 16 rows x 16 pieces (2 units x 4 gates) = 256 pieces over 4 waves
-          const int q = (wg - 1) * 64 + sl;
-          const int prow = q >> 4, seg = q & 15;
-          store16(rs_g, (unsigned)((prow * W * 4 + (hoff + seg * 2) * 4) * 2), (trow * W + u0) * 8u,
-                  *reinterpret_cast<const uint4*>(st_g + prow * F2_G_LD + (hoff + seg * 2) * 8));
-          ++vq;
-        } else if (wg <= 6) {     // cell states: 16 rows x 8 pieces of 4 units = 128 pieces over 2 waves
-          const int q = (wg - 5) * 64 + sl;
-          const int prow = q >> 3, seg = q & 7;
-          const uint4 cv = *reinterpret_cast<const uint4*>(st_c + prow * F2_C_LD + (hoff + seg * 4) * 4);
-          if (a.Cb) {
-            uint2 cb;
-            cb.x = (unsigned)f2bf(u2f(cv.x)) | ((unsigned)f2bf(u2f(cv.y)) << 16);
-            cb.y = (unsigned)f2bf(u2f(cv.z)) | ((unsigned)f2bf(u2f(cv.w)) << 16);
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{cb.x, cb.y}, rs_cb, (int)((prow * W + hoff + seg * 4) * 2), (int)(((trow + B) * W + u0) * 2u), 0);
-            store16(step_of(np) == T - 1 ? rs_c : rs_null, (unsigned)((prow * W + hoff + seg * 4) * 4), ((trow + B) * W + u0) * 4u, cv);
-            vq += 2;
-          } else {
-            store16(rs_c, (unsigned)((prow * W + hoff + seg * 4) * 4), ((trow + B) * W + u0) * 4u, cv);
-            ++vq;
-          }
-        } else if (!TAB) {        // masked outputs: 16 rows x 4 pieces of 8 units
-          const int prow = sl >> 2, seg = sl & 3;
-          store16(rs_hd, (unsigned)((prow * W + hoff + seg * 8) * 2), (trow * W + u0) * 2u,
-                  *reinterpret_cast<const uint4*>(st_hd + prow * F2_H_LD + (hoff + seg * 8) * 2));
-          ++vq;
-        }
-      }
-      SSTAMP(3);
-      if (n < n_ph) {
-        // the gate inputs of phase n start the accumulators (MFMA layout); the next phase's are requested at once
-        wait_vm(vq - seq_z);
-        SSTAMP(7);
-#ifdef KL_STAMP
-        if (blockIdx.x == STAMP_WG && threadIdx.x == KL_STAMP_TID && !landed16(my_zin)) stamp_lds[13] += 1;
-#endif
-        zin_landed();
-        if (TAB) {
-          acc = *reinterpret_cast<const f32x4*>(my_zin);
-          if (has_ctx) acc += *reinterpret_cast<const f32x4*>(my_zin + 1024);
-        } else if (a.p_bf16) {
-          const uint2 pb = *reinterpret_cast<const uint2*>(my_zin + (cunit & 1) * 8);
-          acc = f32x4{u2f(pb.x << 16), u2f(pb.x & 0xffff0000u), u2f(pb.y << 16), u2f(pb.y & 0xffff0000u)};
-        } else {
-          acc = *reinterpret_cast<const f32x4*>(my_zin);
-        }
-        quad_transpose(acc, jr);
-        asm volatile("" : "+v"(acc));
-        if (n + 1 < n_ph) issue_zin(n + 1);
-        if (TAB && n + 2 < n_ph) issue_ids(n + 2);      // (slot of phase n: group 1 read it an interval ago)
-        SSTAMP(4);
-        const unsigned char* tb = smem + (n % NBUF) * 16 * 1024;
-        u32x4 fr[2];
-        fr[0] = *reinterpret_cast<const u32x4*>(tb + frag_lane);
-#pragma unroll
-        for (int q = 0; q < KSTEPS; ++q) {
-          if (q + 1 < KSTEPS) {
-            const int q1 = q + 1;
-            fr[q1 & 1] = *reinterpret_cast<const u32x4*>(tb + (frag_lane ^ (unsigned)(64 * (q1 >> 2))) + 256 * (q1 & 3));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          acc = mfma16(__builtin_bit_cast(bf16x8, fr[q & 1]), __builtin_bit_cast(bf16x8, bu[4 * (q & 3) + (q >> 2)]), acc);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      SSTAMP(5);
-    } else if (n < n_ph) {
-      // ================= cell update of phase n on the accumulators: lane = (row, unit), registers = gates
-      quad_transpose(acc, jr);
-      const float gi = fast_sigmoid(acc[0]), gf = fast_sigmoid(acc[1]), gg = fast_tanh(acc[2]), go = fast_sigmoid(acc[3]);
-      const float c = gf * cst[0] + gi * gg;
-      const float h = go * fast_tanh(c);
-      *reinterpret_cast<bf16_t*>(pub + crow * F2_H_LD + cunit * 2) = f2bf(h);
-      if (!TAB) *reinterpret_cast<bf16_t*>(st_hd + crow * F2_H_LD + cunit * 2) = f2bf(h * mkv[0]);
-      *reinterpret_cast<float*>(st_c + crow * F2_C_LD + cunit * 4) = c;
-      uint2 gp;
-      gp.x = (unsigned)f2bf(gi) | ((unsigned)f2bf(gf) << 16);
-      gp.y = (unsigned)f2bf(gg) | ((unsigned)f2bf(go) << 16);
-      *reinterpret_cast<uint2*>(st_g + crow * F2_G_LD + cunit * 8) = gp;
-      // the next phase's cell moves to slot 0
-#pragma unroll
-      for (int p = 0; p + 1 < NP; ++p) cst[p] = cst[p + 1];
-      cst[NP - 1] = c;
-      if (!TAB) {
-        const float m0 = mkv[0];
-#pragma unroll
-        for (int p = 0; p + 1 < NP; ++p) mkv[p] = mkv[p + 1];
-        mkv[NP - 1] = m0;
-      }
-      SSTAMP(6);
-    }
-  }
-  SSTAMP_FLUSH();
-#undef row0
-#undef step_of
-}
-
 // ---------------------------------------------------------------- backward
 // LDS map (bytes): tile [2][4*KSTEPS][1024] | zt [16 waves][16][17] f32 | pub [4 gates][16 rows][64 units] bf16 | flags
 constexpr int bwd2_lds_bytes(int ksteps) { return 2 * 4 * ksteps * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16; }
@@ -1347,44 +1018,6 @@ int kl_launch_scan_fwd_wide2(KlScanFwdWide a, int rows, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 
-
-// Staggered forward scan (16-row phases, the two halves of a workgroup one barrier apart): NP = phases per workgroup and step, 2..8
-int kl_launch_scan_fwd_wide3(KlScanFwdWide a, hipStream_t stream) {
-  const int W = a.W;
-  const int np = kl_scan_wide2_phases(a.B, a.T, W, 16, 8);
-  if (!np) return KL_ERR_SHAPE;
-  if (!a.sentinel || a.HT || a.HdT) return KL_ERR_SHAPE;
-  const bool tab = a.P == nullptr;
-  if (tab && (!a.EK || !a.ids_tm || a.n_ctx > 1)) return KL_ERR_ARG;
-  if (tab && a.mask) return KL_ERR_ARG;
-  a.n_rb = a.B / 16;
-  a.n_rg = a.n_rb / np;
-  dim3 grid(8 * (W / 64) * ((a.n_rg + 7) / 8)), block(1024);
-  const size_t lds = (size_t)fwd3_lds_bytes(tab);
-#define KL_F3_CASE(NP_, TAB_)                                                                                               \
-  do {                                                                                                                      \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_fwd_wide3_kernel<NP_, TAB_>),                         \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;     \
-    hipLaunchKernelGGL((lstm_scan_fwd_wide3_kernel<NP_, TAB_>), grid, block, lds, stream, a);                               \
-  } while (0)
-#define KL_F3_NP(TAB_)                                  \
-  do {                                                  \
-    switch (np) {                                       \
-      case 2: KL_F3_CASE(2, TAB_); break;               \
-      case 3: KL_F3_CASE(3, TAB_); break;               \
-      case 4: KL_F3_CASE(4, TAB_); break;               \
-      case 5: KL_F3_CASE(5, TAB_); break;               \
-      case 6: KL_F3_CASE(6, TAB_); break;               \
-      case 7: KL_F3_CASE(7, TAB_); break;               \
-      default: KL_F3_CASE(8, TAB_); break;              \
-    }                                                   \
-  } while (0)
-  if (tab) KL_F3_NP(true);
-  else KL_F3_NP(false);
-#undef KL_F3_NP
-#undef KL_F3_CASE
-  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
-}
 
 int kl_launch_scan_bwd_wide2(KlScanBwd a, hipStream_t stream) {
   const int W = a.W;

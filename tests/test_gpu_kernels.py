@@ -331,20 +331,6 @@ def test_train_window_scan2(monkeypatch, depth, width, voc, B, T, n_ctx, use_mas
     check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks, want_kernel="lstm_scan_fwd_wide2_kernel")
 
 
-@pytest.mark.parametrize("depth,width,voc,B,T,n_ctx,use_masks,env", [
-    (2, 512, 64, 1024, 4, 1, True, {}),                        # two phases per workgroup and step
-    (2, 512, 64, 2048, 5, 1, True, {}),                        # four
-    (3, 512, 40, 3072, 3, 1, True, {}),                        # six, tiles requested two phases ahead; three layers
-    (2, 512, 64, 1536, 5, 0, False, {}),                       # three; no context variable, no dropout
-    (2, 512, 64, 2560, 4, 1, True, {"KL_SCAN2_PF": "2"})])     # five; tiles requested too early (the re-fetch path)
-def test_train_window_scan3(monkeypatch, depth, width, voc, B, T, n_ctx, use_masks, env):
-    """Forward scans with the two halves of a workgroup one barrier apart (lstm_scan_fwd_wide3_kernel)."""
-    monkeypatch.setenv("KL_SCAN3", "1")
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks, want_kernel="lstm_scan_fwd_wide3_kernel")
-
-
 @pytest.mark.parametrize("depth,width,voc,B,T,n_ctx", [(6, 128, 30, 5, 7, 1), (2, 128, 40, 20, 9, 1)])
 def test_train_window_launch_per_step_path(monkeypatch, depth, width, voc, B, T, n_ctx):
     """KL_SCAN=0: the launch-per-step kernels (the fallback of every shape the scans do not cover), incl. more

@@ -14,10 +14,7 @@ from ocrd_keraslm_amd.lib.engine import HipLM
 
 lib = hipabi.load()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-rows = int(os.environ.get("KL_SCAN2_ROWS", "0")) or (32 if B // 32 // 32 >= 3 else 16)
-scan3 = os.environ.get("KL_SCAN3", "0") == "1"
-if scan3:
-    rows = 16
+rows = int(os.environ.get("KL_SCAN2_ROWS", "0")) or (32 if B // 32 // 32 >= 2 and B % 1024 == 0 else 16)
 L, W, V, T = 2, 512, 256, 256
 lm = HipLM(L, W, V, 1)
 lm.init_weights(seed=1)
@@ -41,10 +38,6 @@ np_f = B // rows // 32
 per_f = n * T * L * np_f
 names_f = ['loop top', 'tile wait+check', 'barrier 1', 'MFMA phase (+acc init, table mode)', 'transposes + gate-input wait + next pieces',
            'gate math + LDS staging', 'barrier 2', 'stores + rotate']
-if scan3:
-    names_f = ['loop top', 'ids wait (wave 0)', 'barriers (two per phase)', 'stores of the previous phase',
-               'gate inputs landed? + acc init + next requests', 'MFMA', 'cell update + LDS staging', 'gate inputs: counted wait',
-               'tile: counted wait', 'tile: validity check']
 v = np.array(st[:len(names_f)], dtype=np.float64) / per_f
 print(f"B={B}: forward scan, {rows}-row phases x {np_f} per step; cycles per phase of workgroup 0 thread 0; total {v.sum():.0f} = {v.sum() / rows:.0f} per row")
 for nm, x in zip(names_f, v):
