@@ -1,4 +1,6 @@
-"""Diagnostic: time kl_test_gemm_tn on the GEMM shapes of a cfg2 training window (B streams x 256 steps)."""
+"""Diagnostic: time of the activation x weight contractions at the training step's shapes (kl_test_gemm_tn hook)."""
+import ctypes as C
+import os
 import sys
 
 import torch
@@ -7,43 +9,32 @@ sys.path.insert(0, '.')
 from ocrd_keraslm_amd.lib import hipabi
 
 lib = hipabi.load()
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-BT, W, V = B * 256, 512, 256
-shapes = [  # name, M, N, K, out_mode, splits
-    ("P      = H . K^T    (f32 out)", BT, 4 * W, W, 0, 1),
-    ("dX     = dZ . Kn^T  (f32 out)", BT, W, 4 * W, 0, 1),
-    ("logits = H . E^T    (f32 out)", BT, V, W, 0, 1),
-    ("dH     = dl . ET^T  (f32 out)", BT, W, V, 0, 1),
-    ("dU     = HT . dZT^T (atomic)", W, 4 * W, BT, 2, 8),
-    ("dEKT   = dZT . OHT^T (atomic)", 4 * W, V, BT, 2, 8),
-    ("dE     = dlT . HT^T (atomic)", V, W, BT, 2, 8),
-]
-only = sys.argv[2] if len(sys.argv) > 2 else None
-s = torch.cuda.current_stream().cuda_stream
-for name, M, N, K, mode, splits in shapes:
-    if only and only not in name:
-        continue
-    A = (torch.rand((M, K), device='cuda') - 0.5).to(torch.bfloat16)
-    Bm = (torch.rand((N, K), device='cuda') - 0.5).to(torch.bfloat16)
-    Cm = torch.zeros((M, N), device='cuda', dtype=torch.float32)
+lib.kl_test_gemm_tn.restype = C.c_int
+lib.kl_test_gemm_tn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long,
+                                C.c_int, C.c_int, C.c_void_p]
 
-    def run():
-        rc = lib.kl_test_gemm_tn(A.data_ptr(), Bm.data_ptr(), Cm.data_ptr(), None, M, N, K, K, K, N, mode, splits, s)
-        assert rc == 0, rc
-    run()
+
+def run(M, N, K, out_mode, reps=5):
+    a = (torch.randn(M, K, device='cuda') * 0.1).to(torch.bfloat16)
+    b = (torch.randn(N, K, device='cuda') * 0.1).to(torch.bfloat16)
+    c = torch.empty(M, N, device='cuda', dtype=torch.bfloat16 if out_mode == 1 else torch.float32)
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        assert lib.kl_test_gemm_tn(a.data_ptr(), b.data_ptr(), c.data_ptr(), None, M, N, K, K, K, N, out_mode, 1, s) == 0
     torch.cuda.synchronize()
-    # correctness on a sample of rows
-    rows = torch.randint(0, M, (8,), device='cuda')
-    ref = A[rows].float() @ Bm.float().t()
-    err = (Cm[rows] - ref).abs().max().item() / (ref.abs().max().item() + 1e-9)
-    Cm.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 10
     e0.record()
-    for _ in range(n):
-        run()
+    for _ in range(reps):
+        lib.kl_test_gemm_tn(a.data_ptr(), b.data_ptr(), c.data_ptr(), None, M, N, K, K, K, N, out_mode, 1, s)
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
-    print(f"{name:32s} M={M:7d} N={N:5d} K={K:7d}: {ms * 1e3:8.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TF/s  "
-          f"out {M * N * 4 / ms / 1e6:6.0f} GB/s  relerr {err:.1e}")
+    ms = e0.elapsed_time(e1) / reps
+    ref = (a[:256].float() @ b.float().t())
+    err = (c[:256].float() - ref).abs().max().item() / ref.abs().max().item()
+    byt = M * K * 2 + N * K * 2 + M * N * (2 if out_mode == 1 else 4)
+    print(f"M={M} N={N} K={K} out={'bf16' if out_mode == 1 else 'f32'}: {ms:.3f} ms, {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s, {byt / ms / 1e9:.2f} TB/s, err {err:.1e}", flush=True)
+
+
+shapes = [tuple(int(x) for x in s.split(',')) for s in sys.argv[1:]] or [(262144, 2048, 512, 1), (786432, 2048, 512, 1)]
+for M, N, K, om in shapes:
+    run(M, N, K, om)
