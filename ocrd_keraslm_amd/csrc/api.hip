@@ -44,7 +44,6 @@ struct Carver {
   }
 };
 
-constexpr int KL_SCAN_FLAGS = 256 * 64;
 struct Derived {
   std::vector<bf16_t*> UT_hi, UT_lo, KT_hi, KT_lo, Un, Kn;   // per layer (KT/Kn of layer 0 = rows [0,W) of K0)
   bf16_t *E_hi = nullptr, *E_lo = nullptr, *ET = nullptr;
@@ -58,7 +57,6 @@ struct Derived {
   std::vector<float*> bp;        // [4W], l >= 1 (layer 0's bias is folded into EKp)
   float* EKp = nullptr;          // [V][4W] = EK + b_0
   float* CtxKp = nullptr;        // [ctx_vocab][4W] of context variable 0
-  unsigned* scan_flags = nullptr;   // lstm_scan_bwd_wide2_kernel's flags + epoch (zeroed once per bind: the numbers only grow)
 };
 
 struct WindowWs {
@@ -129,8 +127,6 @@ struct kl_handle {
   int scan2_rows = 0;           // KL_SCAN2_ROWS = 16 / 32: rows per forward phase (0: chosen by shape)
   int scan2_pf = -1;            // KL_SCAN2_PF: where the forward scan requests its next tile (0: top of a phase, 1: behind the MFMA phase, 2: two phases ahead; -1: by shape)
   bool scan2_bf16 = true;       // KL_SCAN2_BF16=0: f32 instead of bf16 for what the scans exchange with later kernels (P, dH, c for backward)
-  bool scan2_flags = true;      // KL_SCAN2_FLAGS = 0: the backward scan hands over by data sentinels at every size (else by flags from three blocks per step)
-  bool flags_zeroed = false;
   bool fuse_wg = true;          // KL_FUSE_WG = 0: one launch per weight-gradient product (else products over the same dZ share a pass)
   int scan2_pfb = -1;           // KL_SCAN2_PFB: the same for the backward scan (-1: by shape)
   int wide_fwd_min = 96;        // layer-sequential wide forward scans from this many 64-unit workgroups (KL_WIDE_FWD_MIN; 0 = never)
@@ -241,7 +237,6 @@ size_t carve_derived(const kl_handle* h, void* base, Derived* d) {
   }
   o.EKp = cv.take<float>(V * 4 * W);
   o.CtxKp = c.n_ctx > 0 ? cv.take<float>((size_t)c.ctx_vocab * 4 * W) : nullptr;
-  o.scan_flags = cv.take<unsigned>(KL_SCAN_FLAGS + 64);      // hand-off flags of the backward scan [256 row blocks][64] + the epoch word
   return align_up(cv.off, 256);
 }
 
@@ -328,13 +323,6 @@ int prepare_impl(kl_handle* h, int precision, hipStream_t s) {
   const float* P = h->params;
   Derived& d = h->d;
   const bool split = precision == KL_PREC_SPLIT;
-  if (!h->flags_zeroed) {      // once per bind, and not inside a capture (a replay must not turn the epoch back)
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
-      KL_TRY(kl_zero_async(d.scan_flags, (size_t)(KL_SCAN_FLAGS + 64) * sizeof(unsigned), s));
-      h->flags_zeroed = true;
-    }
-  }
   for (int l = 0; l < c.depth; ++l) {
     const float* K = P + h->off_K[l];   // layer 0: rows [0,W) are the char-embedding part
     const float* U = P + h->off_U[l];
@@ -802,9 +790,6 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   if (env8c) h->scan2_pf = atoi(env8c);
   const char* env8e = getenv("KL_SCAN2_BF16");
   if (env8e) h->scan2_bf16 = atoi(env8e) != 0;
-  const char* env8g = getenv("KL_SCAN2_FLAGS");
-  if (env8g) h->scan2_flags = atoi(env8g) != 0;
-  h->flags_zeroed = false;
   const char* env8f = getenv("KL_FUSE_WG");
   if (env8f) h->fuse_wg = atoi(env8f) != 0;
   const char* env8d = getenv("KL_SCAN2_PFB");
@@ -1047,13 +1032,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       a.pf_mode = h->scan2_pfb >= 0 ? h->scan2_pfb : 1;
       a.xcc_slots = (a.sentinel && h->xcd_local_bwd) ? w.scan_status + 4 : nullptr;
       a.gen = (unsigned)(1 + L + l);
-      const bool by_flags = w.scan2_bwd && h->scan2_flags && h->flags_zeroed && kl_scan_wide2_phases(B, T, W, 16, 6) >= 3;
-      if (by_flags) {
-        // hand-off by flags (lstm_scan_bwd_wide2_kernel): nothing to arm, the epoch moves on
-        a.flags = d.scan_flags;
-        a.epoch = d.scan_flags + KL_SCAN_FLAGS;
-        KL_TRY(kl_launch_scan_epoch(d.scan_flags, KL_SCAN_FLAGS, d.scan_flags + KL_SCAN_FLAGS, (unsigned)T + 2u, s));
-      } else if (a.sentinel && h->sentinel_roll && T >= 3) {
+      if (a.sentinel && h->sentinel_roll && T >= 3) {
         // rolling sentinels: the scan re-arms step t - 2 while it publishes step t; only the first two start armed
         a.sentinel = 2;
         KL_TRY(kl_fill_u32_async(w.dZ[l] + (size_t)(T - 2) * BW * 4, (size_t)2 * BW * 4 * sizeof(bf16_t), 0xFFFFFFFFu, s));
