@@ -91,7 +91,11 @@ def test_save_roundtrip_and_keras_layout():
 
 def test_cudnn_weight_conversion():
     """a file saved from CuDNNLSTM has bias [8W] and per-gate transposed kernels
-    (Keras 2.3 saving semantics); loading converts back"""
+    (Keras 2.3 saving semantics); loading converts back.
+    NOT pinned by a reference artefact: no CuDNN-saved file exists offline, so the CuDNN-arranged input is built here from
+    Keras' documented `convert_weights` rule (keras/engine/saving.py, `transform_kernels` with `from_cudnn=False`), written
+    down independently of the function under test -- the test shows the two directions are inverse, not that either
+    matches a real file."""
     rng = np.random.default_rng(0)
     W, D = 8, 12
     K, U, b = rng.standard_normal((D, 4 * W)), rng.standard_normal((W, 4 * W)), rng.standard_normal(4 * W)

@@ -34,6 +34,7 @@ for flag in ("0", "1"):
     for name, _o, _r, _c in lm.layout:
         got = grads[name].reshape(g_ref[name].shape)
         res.setdefault(name, []).append(np.abs(got - g_ref[name]).max() / (np.abs(g_ref[name]).max() + 1e-12))
+        res.setdefault(name + ' relL2', []).append(np.linalg.norm(got - g_ref[name]) / (np.linalg.norm(g_ref[name]) + 1e-30))
     st = lm.get_states()
     res.setdefault("states", []).append(max(np.abs(st[:, k] - ref_st[k]).max() for k in range(2 * depth)))
 for k, v in res.items():
