@@ -127,6 +127,7 @@ struct kl_handle {
   int scan2_rows = 0;           // KL_SCAN2_ROWS = 16 / 32: rows per forward phase (0: chosen by shape)
   int scan2_pf = -1;            // KL_SCAN2_PF: where the forward scan requests its next tile (0: top of a phase, 1: behind the MFMA phase, 2: two phases ahead; -1: by shape)
   bool scan2_bf16 = true;       // KL_SCAN2_BF16=0: f32 instead of bf16 for what the scans exchange with later kernels (P, dH, c for backward)
+  bool proj_ws = true;          // KL_PROJ_WS = 0: the ring GEMM for the gate inputs P of the second-generation scans too
   bool fuse_wg = true;          // KL_FUSE_WG = 0: one launch per weight-gradient product (else products over the same dZ share a pass)
   int scan2_pfb = -1;           // KL_SCAN2_PFB: the same for the backward scan (-1: by shape)
   int wide_fwd_min = 96;        // layer-sequential wide forward scans from this many 64-unit workgroups (KL_WIDE_FWD_MIN; 0 = never)
@@ -448,8 +449,14 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
         const bool masked_in = masks != nullptr && (l - 1) > 0;
         const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
         // (second generation: P in bf16, gate-interleaved -- half the bytes written here and read by the scan)
-        KL_TRY(kl_launch_gemm_tn(X, v2 ? d.KTp[l] : d.KT_hi[l], w.P1, v2 ? d.bp[l] : P + h->off_b[l], B * T, 4 * W, W, W, W, 4 * W,
-                                 v2 && h->scan2_bf16 ? 1 : 0, 1, 1.f, s));
+        // (weight-stationary kernel where it applies -- width 512, bf16 P -- else the ring GEMM)
+        int pe = KL_ERR_SHAPE;
+        if (v2 && h->scan2_bf16 && h->proj_ws)
+          pe = kl_launch_proj_ws(X, d.KTp[l], d.bp[l], reinterpret_cast<bf16_t*>(w.P1), (long)B * T, W, w.scan_status, s);
+        if (pe == KL_ERR_SHAPE)
+          pe = kl_launch_gemm_tn(X, v2 ? d.KTp[l] : d.KT_hi[l], w.P1, v2 ? d.bp[l] : P + h->off_b[l], B * T, 4 * W, W, W, W, 4 * W,
+                                 v2 && h->scan2_bf16 ? 1 : 0, 1, 1.f, s);
+        KL_TRY(pe);
         a.P = w.P1;
         a.p_bf16 = v2 && h->scan2_bf16 ? 1 : 0;
       } else if (v2) {
@@ -790,6 +797,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   if (env8c) h->scan2_pf = atoi(env8c);
   const char* env8e = getenv("KL_SCAN2_BF16");
   if (env8e) h->scan2_bf16 = atoi(env8e) != 0;
+  const char* env8h = getenv("KL_PROJ_WS");
+  if (env8h) h->proj_ws = atoi(env8h) != 0;
   const char* env8f = getenv("KL_FUSE_WG");
   if (env8f) h->fuse_wg = atoi(env8f) != 0;
   const char* env8d = getenv("KL_SCAN2_PFB");

@@ -189,7 +189,10 @@ int kl_launch_scan_bwd(KlScanBwd args, hipStream_t stream);
 bool kl_scan_bwd_wide_applicable(int B, int T, int W);
 int kl_scan_wide_blocks_per_wg(int B, int W);
 int kl_launch_scan_bwd_wide(KlScanBwd args, hipStream_t stream);   // one layer per launch, 64-unit workgroups
-int kl_launch_scan_bwd_wide2(KlScanBwd args, hipStream_t stream);  // second generation (lstm_scan2.hip): a.G gate-interleaved, rolling sentinels
+int kl_launch_scan_bwd_wide2(KlScanBwd args, hipStream_t stream);
+// weight-stationary P = X . KTp^T + bp for width 512 (lstm_scan2.hip: proj_ws_kernel); KL_ERR_SHAPE = not applicable
+int kl_launch_proj_ws(const bf16_t* X, const bf16_t* KTp, const float* bp, bf16_t* P, long M, int W, unsigned* status,
+                      hipStream_t stream);  // second generation (lstm_scan2.hip): a.G gate-interleaved, rolling sentinels
 
 // thin split-precision contraction C[M,N] = A[M,K] . WT[N,K]^T (+bias) for
 // small M (tables, inference logits)

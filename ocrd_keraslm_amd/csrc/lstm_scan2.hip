@@ -162,6 +162,16 @@ __device__ __forceinline__ void glds4_plain_s(__amdgpu_buffer_rsrc_t rsrc, unsig
       : "memory");
 }
 
+// ... of 16 bytes per lane from rsrc[voff + soff] (plain load: data of an earlier kernel); lane l lands at lds_addr + 16 l
+__device__ __forceinline__ void glds16_plain_s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+      : "memory");
+}
+
 // NB: row blocks of 16 per phase; NP: phases per workgroup and step (>= 2: while one phase computes, the other's
 // publish travels); TAB: layer 0, gate inputs from the look-up tables instead of P rows.
 // Nothing asynchronous ever lands in a register: tiles, gate-input pieces and table-row ids are all brought in by
@@ -608,6 +618,130 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide2_kernel(const KlSc
 
 namespace {
 
+// ---------------------------------------------------------------- gate inputs of the layers above the first
+// P[r][4 unit + gate] = X[r][:] . KTp[4 unit + gate][:] + bp  for all T*B rows (width 512), WEIGHT-STATIONARY: the
+// 2 MiB of KTp are spread over the register files exactly as the scans spread U (wave w of column group cg keeps its
+// 16 output columns for all of K in 64 VGPRs), and only X streams -- through a four-deep ring of 32-row tiles in LDS,
+// one coalesced 1 KiB row per LDS-DMA instruction, swizzled at the source like the scans' tiles.  The ring GEMM
+// (gemm.hip) pulls BOTH operands of every 256 x 128 tile from L2 again and again and is bound by that traffic at
+// K = 512 (0.65 PFLOP/s, 0.79 with its stores removed); here a CU reads 32 KiB per 8.4 MFLOP instead of 48 KiB per
+// 4.2, nothing depends on anything, and three tiles (96 KiB) are in flight per CU.
+// Grid as the scans': 8 column groups x n_rg row groups, block b on XCD b % 8 so that the eight workgroups reading the
+// same rows share an L2; row group rg takes the tiles rg, rg + n_rg, ...  One barrier per tile: behind it every wave's
+// rows of tile i have landed AND every wave has left tile i - 1, whose buffer takes the request for tile i + 3.
+struct KlProjWs {
+  const bf16_t* X;       // [M][512]
+  const bf16_t* KTp;     // [2048][512], rows in output-column order
+  const float* bp;       // [2048]
+  bf16_t* P;             // [M][2048]
+  int M;                 // rows, a multiple of 32
+  int n_rg;              // row groups (workgroups per column group)
+  unsigned* status;
+};
+
+__global__ __launch_bounds__(1024, 1) void proj_ws_kernel(const KlProjWs a) {
+  constexpr int KSTEPS = 16, W = 512, N = 4 * W, NCG = N / 256, ROWS = 32, NST = 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, yy = blockIdx.x >> 3;
+  const int cg = yy % NCG, rq = yy / NCG, rg = xcd * ((a.n_rg + 7) >> 3) + rq;
+  if (rg >= a.n_rg) return;
+  const int c0 = cg * 256;                                  // first output column of this workgroup
+  const int n_tiles_all = a.M / ROWS;
+  const int my_tiles = rg < n_tiles_all ? (n_tiles_all - rg + a.n_rg - 1) / a.n_rg : 0;
+  if (my_tiles == 0) return;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)smem;
+  int& ok_flag = *reinterpret_cast<int*>(smem + NST * ROWS * 1024);
+
+  u32x4 bu[KSTEPS];
+  {
+    const long wrow = (long)(c0 + 16 * wave + (lane & 15)) * W + (lane >> 4) * 8;
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j) bu[j] = *reinterpret_cast<const u32x4*>(a.KTp + wrow + j * 32);
+  }
+  const float bias = a.bp[c0 + 16 * wave + (lane & 15)];    // (accumulator layout: one column per lane)
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.X, (long)a.M * W * 2);
+  const __amdgpu_buffer_rsrc_t rs_p = make_rsrc(a.P, (long)a.M * N * 2);
+  if (tid == 0) ok_flag = 1;
+#pragma unroll
+  for (int j = 0; j < KSTEPS; ++j) asm volatile("" : "+v"(bu[j]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const unsigned frag_lane = (unsigned)((lane & 15) * 1024 + (((lane >> 4) ^ (lane & 3)) * 16) + 64 * ((lane >> 2) & 3));
+  const unsigned dma_lane = (unsigned)((lane ^ (wave & 15)) * 16);      // (rows w and w + 16: the same low four bits)
+  const int jr = lane & 3, a4 = (lane >> 2) & 3, q4 = lane >> 4;
+  int vq = 0;
+  auto issue_tile = [&](int i) __attribute__((always_inline)) {      // this wave's rows w and w + 16 of tile i
+    const int buf = i % NST;
+    const long row0 = (long)(rg + (long)i * a.n_rg) * ROWS;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) arm16(smem + (buf * ROWS + h * 16 + wave) * 1024 + lane * 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      glds16_plain_s(rs_x, dma_lane, (unsigned)((row0 + h * 16 + wave) * W * 2), lds_base + (unsigned)((buf * ROWS + h * 16 + wave) * 1024));
+    vq += 2;
+  };
+  for (int i = 0; i < NST - 1 && i < my_tiles; ++i) issue_tile(i);
+  bool alive = true;
+  for (int i = 0; i < my_tiles && alive; ++i) {
+    const int buf = i % NST;
+    // this wave's rows of tile i: requested three tiles ago, behind them 2 requests + 2 stores per tile since
+    {
+      const int younger = (min(i + NST - 1, my_tiles) - (i + 1)) * 2 + min(i, NST - 1) * 2;
+      wait_vm(younger);
+      bool ok = false;
+      for (unsigned spin = 0; spin < 4096u && !ok; ++spin) {
+        ok = __all(piece_there(smem + (buf * ROWS + wave) * 1024 + lane * 16) &&
+                   piece_there(smem + (buf * ROWS + 16 + wave) * 1024 + lane * 16));
+        if (!ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (!ok) {
+        __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok_flag = 0;
+      }
+    }
+    __syncthreads();
+    alive = __builtin_amdgcn_readfirstlane(ok_flag) != 0;
+    if (i + NST - 1 < my_tiles) issue_tile(i + NST - 1);      // (into the buffer of tile i - 1)
+    f32x4 acc[2] = {f32x4{bias, bias, bias, bias}, f32x4{bias, bias, bias, bias}};
+    {
+      const unsigned char* tb = smem + buf * ROWS * 1024;
+      u32x4 fr[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) fr[0][h] = *reinterpret_cast<const u32x4*>(tb + frag_lane + h * 16 * 1024);
+#pragma unroll
+      for (int q = 0; q < KSTEPS; ++q) {
+        if (q + 1 < KSTEPS) {
+          const int q1 = q + 1;
+          const unsigned char* ap = tb + (frag_lane ^ (unsigned)(64 * (q1 >> 2))) + 256 * (q1 & 3);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) fr[q1 & 1][h] = *reinterpret_cast<const u32x4*>(ap + h * 16 * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 fb = __builtin_bit_cast(bf16x8, bu[4 * (q & 3) + (q >> 2)]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc[h] = mfma16(__builtin_bit_cast(bf16x8, fr[q & 1][h]), fb, acc[h]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // out: after the quad transpose lane = (row 4 q4 + jr, columns 4 a4 .. 4 a4 + 3 of this wave's 16): 8 bytes per lane
+    const long row0 = (long)(rg + (long)i * a.n_rg) * ROWS;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 v = acc[h];
+      quad_transpose(v, jr);
+      const u32x2 pk = u32x2{(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
+      const unsigned off = (unsigned)(((h * 16 + 4 * q4 + jr) * N + c0 + 16 * wave + 4 * a4) * 2);
+      __builtin_amdgcn_raw_buffer_store_b64(pk, rs_p, (int)off, (int)(unsigned)(row0 * N * 2), 0);
+    }
+    vq += 2;
+  }
+}
+
 // ---------------------------------------------------------------- backward
 // LDS map (bytes): tile [2][4*KSTEPS][1024] | zt [16 waves][16][17] f32 | pub [4 gates][16 rows][64 units] bf16 | flags
 constexpr int bwd2_lds_bytes(int ksteps) { return 2 * 4 * ksteps * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16; }
@@ -1018,6 +1152,23 @@ int kl_launch_scan_fwd_wide2(KlScanFwdWide a, int rows, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 
+
+// gate inputs of a layer above the first for all rows at once (proj_ws_kernel); KL_ERR_SHAPE = not applicable
+int kl_launch_proj_ws(const bf16_t* X, const bf16_t* KTp, const float* bp, bf16_t* P, long M, int W, unsigned* status,
+                      hipStream_t stream) {
+  if (W != 512 || M < 32 * 32 || (M % 32) != 0 || M * 2048L * 2 > 0xfffffff0L) return KL_ERR_SHAPE;
+  KlProjWs a;
+  a.X = X; a.KTp = KTp; a.bp = bp; a.P = P; a.M = (int)M; a.n_rg = 32; a.status = status;
+  const size_t lds = (size_t)4 * 32 * 1024 + 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return KL_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(proj_ws_kernel, dim3(8 * 8 * ((a.n_rg + 7) / 8)), dim3(1024), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
 
 int kl_launch_scan_bwd_wide2(KlScanBwd a, hipStream_t stream) {
   const int W = a.W;
