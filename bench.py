@@ -374,7 +374,8 @@ def main():
 
     # ---- end to end: Rater.train over synthetic files (rank 0, one GPU): what the Python above the ABI costs
     end_to_end = None
-    if rank == 0 and not args.no_end_to_end:
+    # (N = 1 only: Rater.train would see the process group and start collectives the other ranks are not in)
+    if rank == 0 and world == 1 and not args.no_end_to_end:
         try:
             end_to_end = end_to_end_leg(B)
         except Exception as err:      # informative only
@@ -382,7 +383,7 @@ def main():
 
     cpu = None
     cpu_torch = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # (reported at N = 1 only)
         cpu = cpu_baseline()
         try:
             cpu_torch = cpu_baseline_torch()
