@@ -621,14 +621,13 @@ namespace {
 // ---------------------------------------------------------------- gate inputs of the layers above the first
 // P[r][4 unit + gate] = X[r][:] . KTp[4 unit + gate][:] + bp  for all T*B rows (width 512), WEIGHT-STATIONARY: the
 // 2 MiB of KTp are spread over the register files exactly as the scans spread U (wave w of column group cg keeps its
-// 16 output columns for all of K in 64 VGPRs), and only X streams -- through a four-deep ring of 32-row tiles in LDS,
-// one coalesced 1 KiB row per LDS-DMA instruction, swizzled at the source like the scans' tiles.  The ring GEMM
+// 16 output columns for all of K in 64 VGPRs), and only X streams -- 32-row tiles, double-buffered in LDS, fetched through
+// registers two tiles ahead (see the kernel).  The ring GEMM
 // (gemm.hip) pulls BOTH operands of every 256 x 128 tile from L2 again and again and is bound by that traffic at
 // K = 512 (0.65 PFLOP/s, 0.79 with its stores removed); here a CU reads 32 KiB per 8.4 MFLOP instead of 48 KiB per
-// 4.2, nothing depends on anything, and three tiles (96 KiB) are in flight per CU.
+// 4.2, and nothing depends on anything.
 // Grid as the scans': 8 column groups x n_rg row groups, block b on XCD b % 8 so that the eight workgroups reading the
-// same rows share an L2; row group rg takes the tiles rg, rg + n_rg, ...  One barrier per tile: behind it every wave's
-// rows of tile i have landed AND every wave has left tile i - 1, whose buffer takes the request for tile i + 3.
+// same rows share an L2; row group rg takes the tiles rg, rg + n_rg, ...  One barrier per tile.
 struct KlProjWs {
   const bf16_t* X;       // [M][512]
   const bf16_t* KTp;     // [2048][512], rows in output-column order
@@ -640,7 +639,7 @@ struct KlProjWs {
 };
 
 __global__ __launch_bounds__(1024, 1) void proj_ws_kernel(const KlProjWs a) {
-  constexpr int KSTEPS = 16, W = 512, N = 4 * W, NCG = N / 256, ROWS = 32, NST = 4;
+  constexpr int KSTEPS = 16, W = 512, N = 4 * W, NCG = N / 256, ROWS = 32;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xcd = blockIdx.x & 7, yy = blockIdx.x >> 3;
@@ -651,9 +650,7 @@ __global__ __launch_bounds__(1024, 1) void proj_ws_kernel(const KlProjWs a) {
   const int my_tiles = rg < n_tiles_all ? (n_tiles_all - rg + a.n_rg - 1) / a.n_rg : 0;
   if (my_tiles == 0) return;
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)smem;
-  int& ok_flag = *reinterpret_cast<int*>(smem + NST * ROWS * 1024);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // tile [2][32 rows][1024]
 
   u32x4 bu[KSTEPS];
   {
@@ -664,49 +661,37 @@ __global__ __launch_bounds__(1024, 1) void proj_ws_kernel(const KlProjWs a) {
   const float bias = a.bp[c0 + 16 * wave + (lane & 15)];    // (accumulator layout: one column per lane)
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.X, (long)a.M * W * 2);
   const __amdgpu_buffer_rsrc_t rs_p = make_rsrc(a.P, (long)a.M * N * 2);
-  if (tid == 0) ok_flag = 1;
-#pragma unroll
-  for (int j = 0; j < KSTEPS; ++j) asm volatile("" : "+v"(bu[j]));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
 
+  // X rows come through REGISTERS, two tiles ahead, and are laid into the LDS tile by the wave that fetched them (rows
+  // w and w + 16, their 16-byte chunks XOR-swizzled on the way in: chunk c of row r at position c ^ (r & 15), as in the
+  // scans).  An LDS-DMA piece costs the CU ~140 cycles of a resource all waves share (32 pieces per tile were 4,500 of this
+  // kernel's 4,800 cycles per tile, with or without the MFMAs); a 1 KiB register load passes the address unit in 16.
+  // Everything here is visible to the compiler (no hand-issued asynchronous operation), so its own waits are exact.
   const unsigned frag_lane = (unsigned)((lane & 15) * 1024 + (((lane >> 4) ^ (lane & 3)) * 16) + 64 * ((lane >> 2) & 3));
-  const unsigned dma_lane = (unsigned)((lane ^ (wave & 15)) * 16);      // (rows w and w + 16: the same low four bits)
+  const unsigned put_lane = (unsigned)(wave * 1024 + ((lane ^ wave) & 63) * 16);      // position of this lane's chunk in row w (and w + 16)
   const int jr = lane & 3, a4 = (lane >> 2) & 3, q4 = lane >> 4;
-  int vq = 0;
-  auto issue_tile = [&](int i) __attribute__((always_inline)) {      // this wave's rows w and w + 16 of tile i
-    const int buf = i % NST;
+  auto fetch = [&](int i, u32x4 (&r)[2]) __attribute__((always_inline)) {
     const long row0 = (long)(rg + (long)i * a.n_rg) * ROWS;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) arm16(smem + (buf * ROWS + h * 16 + wave) * 1024 + lane * 16);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
     for (int h = 0; h < 2; ++h)
-      glds16_plain_s(rs_x, dma_lane, (unsigned)((row0 + h * 16 + wave) * W * 2), lds_base + (unsigned)((buf * ROWS + h * 16 + wave) * 1024));
-    vq += 2;
+      r[h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, lane * 16, (int)(unsigned)((row0 + h * 16 + wave) * W * 2), 0));
   };
-  for (int i = 0; i < NST - 1 && i < my_tiles; ++i) issue_tile(i);
-  bool alive = true;
-  for (int i = 0; i < my_tiles && alive; ++i) {
-    const int buf = i % NST;
-    // this wave's rows of tile i: requested three tiles ago, behind them 2 requests + 2 stores per tile since
-    {
-      const int younger = (min(i + NST - 1, my_tiles) - (i + 1)) * 2 + min(i, NST - 1) * 2;
-      wait_vm(younger);
-      bool ok = false;
-      for (unsigned spin = 0; spin < 4096u && !ok; ++spin) {
-        ok = __all(piece_there(smem + (buf * ROWS + wave) * 1024 + lane * 16) &&
-                   piece_there(smem + (buf * ROWS + 16 + wave) * 1024 + lane * 16));
-        if (!ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      if (!ok) {
-        __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok_flag = 0;
-      }
-    }
-    __syncthreads();
-    alive = __builtin_amdgcn_readfirstlane(ok_flag) != 0;
-    if (i + NST - 1 < my_tiles) issue_tile(i + NST - 1);      // (into the buffer of tile i - 1)
+  auto put = [&](int buf, const u32x4 (&r)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) *reinterpret_cast<u32x4*>(smem + buf * ROWS * 1024 + h * 16 * 1024 + put_lane) = r[h];
+  };
+  u32x4 ra[2], rb[2];      // tile i + 1 and tile i + 2 on their way
+  fetch(0, ra);
+  put(0, ra);
+  if (my_tiles > 1) fetch(1, ra);
+  if (my_tiles > 2) fetch(2, rb);
+  // one tile: r1 holds tile i + 1 (fetched two tiles ago) and takes tile i + 3 once it has been laid into LDS; the two
+  // register sets swap roles from tile to tile (loop unrolled by two: no moves, which would wait for the younger load)
+  auto one_tile = [&](int i, u32x4 (&r1)[2]) __attribute__((always_inline)) {
+    const int buf = i & 1;
+    __syncthreads();                       // tile i is complete in LDS, and every wave has left tile i - 1
+    if (i + 1 < my_tiles) put(buf ^ 1, r1);
+    if (i + 3 < my_tiles) fetch(i + 3, r1);
     f32x4 acc[2] = {f32x4{bias, bias, bias, bias}, f32x4{bias, bias, bias, bias}};
     {
       const unsigned char* tb = smem + buf * ROWS * 1024;
@@ -738,7 +723,10 @@ __global__ __launch_bounds__(1024, 1) void proj_ws_kernel(const KlProjWs a) {
       const unsigned off = (unsigned)(((h * 16 + 4 * q4 + jr) * N + c0 + 16 * wave + 4 * a4) * 2);
       __builtin_amdgcn_raw_buffer_store_b64(pk, rs_p, (int)off, (int)(unsigned)(row0 * N * 2), 0);
     }
-    vq += 2;
+  };
+  for (int i = 0; i < my_tiles; i += 2) {
+    one_tile(i, ra);
+    if (i + 1 < my_tiles) one_tile(i + 1, rb);
   }
 }
 
@@ -1159,7 +1147,7 @@ int kl_launch_proj_ws(const bf16_t* X, const bf16_t* KTp, const float* bp, bf16_
   if (W != 512 || M < 32 * 32 || (M % 32) != 0 || M * 2048L * 2 > 0xfffffff0L) return KL_ERR_SHAPE;
   KlProjWs a;
   a.X = X; a.KTp = KTp; a.bp = bp; a.P = P; a.M = (int)M; a.n_rg = 32; a.status = status;
-  const size_t lds = (size_t)4 * 32 * 1024 + 16;
+  const size_t lds = (size_t)2 * 32 * 1024;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
