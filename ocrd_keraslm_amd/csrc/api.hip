@@ -964,14 +964,18 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       }
     } else {
       // layer 0 through the look-up tables: dEK^T = dZ^T . OneHot ; dCtxK_n^T likewise
-      KL_TRY(kl_zero_async(w.OHT, (size_t)Vp * BTp * sizeof(bf16_t), s));
-      KL_TRY(kl_launch_onehot_t(idx, B, T, V, 0, 1, w.OHT, BTp, s));
+      if (kl_launch_onehot_dense(idx, B, T, Vp, 0, 1, w.OHT, BTp, s) == KL_ERR_SHAPE) {
+        KL_TRY(kl_zero_async(w.OHT, (size_t)Vp * BTp * sizeof(bf16_t), s));
+        KL_TRY(kl_launch_onehot_t(idx, B, T, V, 0, 1, w.OHT, BTp, s));
+      }
       KL_TRY(kl_zero_async(w.dEKT, (size_t)4 * W * Vp * sizeof(float), s));
       // (the first context variable's one-hot product rides along with the characters': one pass over dZ for both)
       const bool pair_ctx = dz_km && h->fuse_wg && c.n_ctx >= 1 && (Vp % 128) == 0;
       if (pair_ctx) {
-        KL_TRY(kl_zero_async(w.OHC[0], (size_t)c.ctx_vocab * BTp * sizeof(bf16_t), s));
-        KL_TRY(kl_launch_onehot_t(ctx, B, T, c.ctx_vocab, 0, c.n_ctx, w.OHC[0], BTp, s));
+        if (kl_launch_onehot_dense(ctx, B, T, c.ctx_vocab, 0, c.n_ctx, w.OHC[0], BTp, s) == KL_ERR_SHAPE) {
+          KL_TRY(kl_zero_async(w.OHC[0], (size_t)c.ctx_vocab * BTp * sizeof(bf16_t), s));
+          KL_TRY(kl_launch_onehot_t(ctx, B, T, c.ctx_vocab, 0, c.n_ctx, w.OHC[0], BTp, s));
+        }
         KL_TRY(kl_zero_async(w.dCtxKT[0], (size_t)4 * W * c.ctx_vocab * sizeof(float), s));
         KL_TRY(kl_launch_gemm_an2(w.dZ[l], w.OHT, w.dEKT, 4 * W, Vp, BT, 4 * W, BTp, Vp, 0,
                                   w.OHC[0], w.dCtxKT[0], c.ctx_vocab, BTp, c.ctx_vocab, 0, s, 0));
@@ -985,8 +989,10 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       KL_TRY(kl_launch_gemm_tn(w.dEK_bf, d.Kn[0], grads + h->off_E, nullptr, V, W, 4 * W, 4 * W, 4 * W, W, 2, 1, 1.f, s));
       for (int n = 0; n < c.n_ctx; ++n) {
         if (!(pair_ctx && n == 0)) {
-          KL_TRY(kl_zero_async(w.OHC[n], (size_t)c.ctx_vocab * BTp * sizeof(bf16_t), s));
-          KL_TRY(kl_launch_onehot_t(ctx, B, T, c.ctx_vocab, n, c.n_ctx, w.OHC[n], BTp, s));
+          if (kl_launch_onehot_dense(ctx, B, T, c.ctx_vocab, n, c.n_ctx, w.OHC[n], BTp, s) == KL_ERR_SHAPE) {
+            KL_TRY(kl_zero_async(w.OHC[n], (size_t)c.ctx_vocab * BTp * sizeof(bf16_t), s));
+            KL_TRY(kl_launch_onehot_t(ctx, B, T, c.ctx_vocab, n, c.n_ctx, w.OHC[n], BTp, s));
+          }
           KL_TRY(kl_zero_async(w.dCtxKT[n], (size_t)4 * W * c.ctx_vocab * sizeof(float), s));
           if (dz_km) KL_TRY(kl_launch_gemm_an(w.dZ[l], w.OHC[n], w.dCtxKT[n], 4 * W, c.ctx_vocab, BT, 4 * W, BTp, c.ctx_vocab, 0, s));
           else KL_TRY(kl_launch_gemm_tn(w.dZT, w.OHC[n], w.dCtxKT[n], nullptr, 4 * W, c.ctx_vocab, BTp, BTp, BTp,

@@ -275,6 +275,35 @@ __global__ void onehot_t_kernel(const int* __restrict__ ids, int B, int T, int n
   }
 }
 
+// ... the same matrix written DENSE, zeros included: one pass of 16-byte stores over [n_rows][ld] instead of a zero fill
+// (400 MB at the bench shape) followed by the scatter.  Thread = eight consecutive columns r (streams b .. b + 7 of
+// one step t when B is a multiple of 8) x a tile of 32 class rows; columns from B*T up to ld are zero.
+__global__ void onehot_dense_kernel(const int* __restrict__ ids, int B, int T, int n_rows, int col, int n_cols,
+                                    bf16_t* __restrict__ out, long ld) {
+  const long r0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (r0 >= ld) return;
+  const long total = (long)B * T;
+  int id[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const long r = r0 + j;
+    id[j] = -1;
+    if (r < total) {
+      const int b = (int)(r % B), t = (int)(r / B);
+      id[j] = ids[((long)b * T + t) * n_cols + col];
+    }
+  }
+  const int v0 = blockIdx.y * 32;
+  for (int v = v0; v < v0 + 32 && v < n_rows; ++v) {
+    uint4 w;
+    w.x = (id[0] == v ? 0x3F80u : 0u) | (id[1] == v ? 0x3F800000u : 0u);
+    w.y = (id[2] == v ? 0x3F80u : 0u) | (id[3] == v ? 0x3F800000u : 0u);
+    w.z = (id[4] == v ? 0x3F80u : 0u) | (id[5] == v ? 0x3F800000u : 0u);
+    w.w = (id[6] == v ? 0x3F80u : 0u) | (id[7] == v ? 0x3F800000u : 0u);
+    *reinterpret_cast<uint4*>(out + (long)v * ld + r0) = w;
+  }
+}
+
 // ---- embedding regularisers: gradient (+=) and value ------------------------------
 // mode 0 = chars (rating.py:222-246), mode 1 = contexts (rating.py:187-220).
 // Two launches per table: table statistics (one block: column means / partial column
@@ -462,6 +491,15 @@ int kl_launch_onehot_t(const int* ids, int B, int T, int n_classes, int col, int
                        hipStream_t stream) {
   hipLaunchKernelGGL(onehot_t_kernel, dim3(grid_for((long)B * T, 256)), dim3(256), 0, stream, ids, B, T, n_classes,
                      col, n_cols, out, ld);
+  return ok();
+}
+
+// dense form: writes all n_rows x ld entries (ld a multiple of 8, out 16-byte aligned); KL_ERR_SHAPE otherwise
+int kl_launch_onehot_dense(const int* ids, int B, int T, int n_rows, int col, int n_cols, bf16_t* out, long ld,
+                           hipStream_t stream) {
+  if ((ld & 7) || ((size_t)out & 15) || ld < (long)B * T) return KL_ERR_SHAPE;
+  dim3 grid((unsigned)((ld / 8 + 255) / 256), (unsigned)((n_rows + 31) / 32));
+  hipLaunchKernelGGL(onehot_dense_kernel, grid, dim3(256), 0, stream, ids, B, T, n_rows, col, n_cols, out, ld);
   return ok();
 }
 

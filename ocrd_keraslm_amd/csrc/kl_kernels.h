@@ -214,6 +214,8 @@ int kl_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float
                    float eps, float clip, float grad_scale, hipStream_t stream);
 int kl_launch_onehot_t(const int* ids, int B, int T, int n_classes, int col, int n_cols, bf16_t* out, long ld,
                        hipStream_t stream);
+int kl_launch_onehot_dense(const int* ids, int B, int T, int n_rows, int col, int n_cols, bf16_t* out, long ld,
+                           hipStream_t stream);      // zeros included: no fill in front
 int kl_launch_regulariser_grads(const float* E, int V, int W, const float* const* ctx_tabs, int n_ctx, int ctx_vocab,
                                 int ctx_dim, float* gE, float* const* gCtx, float* loss_acc, float* scratch,
                                 hipStream_t stream);
