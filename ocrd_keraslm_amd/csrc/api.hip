@@ -127,6 +127,7 @@ struct kl_handle {
   int scan2_rows = 0;           // KL_SCAN2_ROWS = 16 / 32: rows per forward phase (0: chosen by shape)
   int scan2_pf = -1;            // KL_SCAN2_PF: where the forward scan requests its next tile (0: top of a phase, 1: behind the MFMA phase, 2: two phases ahead; -1: by shape)
   bool scan2_bf16 = true;       // KL_SCAN2_BF16=0: f32 instead of bf16 for what the scans exchange with later kernels (P, dH, c for backward)
+  bool logits_ws = true;        // KL_LOGITS_WS = 0: GEMM + softmax kernel for the training window's output layer instead of the fused kernel
   bool proj_ws = true;          // KL_PROJ_WS = 0: the ring GEMM for the gate inputs P of the second-generation scans too
   bool fuse_wg = true;          // KL_FUSE_WG = 0: one launch per weight-gradient product (else products over the same dZ share a pass)
   int scan2_pfb = -1;           // KL_SCAN2_PFB: the same for the backward scan (-1: by shape)
@@ -797,6 +798,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   if (env8c) h->scan2_pf = atoi(env8c);
   const char* env8e = getenv("KL_SCAN2_BF16");
   if (env8e) h->scan2_bf16 = atoi(env8e) != 0;
+  const char* env8i = getenv("KL_LOGITS_WS");
+  if (env8i) h->logits_ws = atoi(env8i) != 0;
   const char* env8h = getenv("KL_PROJ_WS");
   if (env8h) h->proj_ws = atoi(env8h) != 0;
   const char* env8f = getenv("KL_FUSE_WG");
@@ -896,9 +899,19 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   // F5/F6: logits over the (masked) top-layer outputs, softmax, CE, dlogits
   const bool top_masked = masks != nullptr && L > 1;
   const bf16_t* Htop = top_masked ? w.Hd[L - 1] : (const bf16_t*)w.H[L - 1] + BW;
-  KL_TRY(kl_launch_gemm_tn(Htop, d.E_hi, w.logits, nullptr, BT, V, W, W, W, V, 0, 1, 1.f, s));
-  KL_TRY(kl_launch_softmax_ce(w.logits, V, BT, V, tgt, B, T, 1.0f / (h->last_only ? (float)B : (float)BT), w.dlogits, Vp, loss_acc,
-                              w.rowstat, 1, s, h->last_only));
+  // (one kernel where it applies -- V = 256, width 512: the logits never reach memory --, else GEMM + softmax)
+  const float inv_count = 1.0f / (h->last_only ? (float)B : (float)BT);
+  int fe = KL_ERR_SHAPE;
+  if (h->logits_ws && loss_acc != nullptr && w.rowstat != nullptr && V == Vp)
+    fe = kl_launch_logits_ce_ws(Htop, d.E_hi, tgt, w.dlogits, w.rowstat, B, T, W, V, Vp, inv_count, h->last_only, s);
+  if (fe == 0) {
+    KL_TRY(kl_launch_rowstat_reduce(w.rowstat, BT, loss_acc, s));
+  } else if (fe == KL_ERR_SHAPE) {
+    KL_TRY(kl_launch_gemm_tn(Htop, d.E_hi, w.logits, nullptr, BT, V, W, W, W, V, 0, 1, 1.f, s));
+    KL_TRY(kl_launch_softmax_ce(w.logits, V, BT, V, tgt, B, T, inv_count, w.dlogits, Vp, loss_acc, w.rowstat, 1, s, h->last_only));
+  } else {
+    return fe;
+  }
   // B1: dH = dlogits . E ; dE += dlogits^T . Htop
   // (second-generation backward scan: dH travels as bf16)
   const int dh_mode = w.scan2_bwd ? 1 : 0;

@@ -480,6 +480,13 @@ int kl_launch_softmax_ce(float* logits, long ld, int rows, int V, const int* tgt
   return ok();
 }
 
+int kl_launch_rowstat_reduce(const float* rowstat, int rows, float* loss_acc, hipStream_t stream) {
+  int nb = (rows + 4095) / 4096;
+  if (nb > 64) nb = 64;
+  hipLaunchKernelGGL(rowstat_reduce_kernel, dim3(nb), dim3(256), 0, stream, rowstat, rows, loss_acc);
+  return ok();
+}
+
 int kl_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                    float eps, float clip, float grad_scale, hipStream_t stream) {
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for((long)n, 256)), dim3(256), 0, stream, p, g, m, v, n, lr_t, b1, b2,

@@ -190,6 +190,10 @@ bool kl_scan_bwd_wide_applicable(int B, int T, int W);
 int kl_scan_wide_blocks_per_wg(int B, int W);
 int kl_launch_scan_bwd_wide(KlScanBwd args, hipStream_t stream);   // one layer per launch, 64-unit workgroups
 int kl_launch_scan_bwd_wide2(KlScanBwd args, hipStream_t stream);
+// output projection + softmax + CE + dlogits of a training window in one pass (V = 256, width 512); KL_ERR_SHAPE = not applicable
+int kl_launch_logits_ce_ws(const bf16_t* X, const bf16_t* E, const int* tgt, bf16_t* dlogits, float* rowstat, int B, int T, int W,
+                           int V, long ld_dl, float inv_count, int last_only, hipStream_t stream);
+int kl_launch_rowstat_reduce(const float* rowstat, int rows, float* loss_acc, hipStream_t stream);
 // weight-stationary P = X . KTp^T + bp for width 512 (lstm_scan2.hip: proj_ws_kernel); KL_ERR_SHAPE = not applicable
 int kl_launch_proj_ws(const bf16_t* X, const bf16_t* KTp, const float* bp, bf16_t* P, long M, int W, unsigned* status,
                       hipStream_t stream);  // second generation (lstm_scan2.hip): a.G gate-interleaved, rolling sentinels

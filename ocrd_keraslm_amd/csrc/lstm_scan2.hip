@@ -730,6 +730,190 @@ __global__ __launch_bounds__(1024, 1) void proj_ws_kernel(const KlProjWs a) {
   }
 }
 
+// wave-wide reductions by DPP (no LDS crossbar: `__shfl_xor` is a ds_bpermute of ~100 cycles each, eighteen of them in a
+// dependent chain per softmax row).  Every step combines with a lane pattern inside the 16-lane rows, the last two carry the
+// row results across (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3); the result is lane 63's, broadcast
+// through a scalar.  Lanes a step does not write see the operation's identity.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float identity, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  const float ninf = -INFINITY;
+  v = fmaxf(v, dpp_f<0xB1, 0xF>(ninf, v));
+  v = fmaxf(v, dpp_f<0x4E, 0xF>(ninf, v));
+  v = fmaxf(v, dpp_f<0x141, 0xF>(ninf, v));
+  v = fmaxf(v, dpp_f<0x140, 0xF>(ninf, v));
+  v = fmaxf(v, dpp_f<0x142, 0xA>(ninf, v));
+  v = fmaxf(v, dpp_f<0x143, 0xC>(ninf, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_f<0xB1, 0xF>(0.f, v);
+  v += dpp_f<0x4E, 0xF>(0.f, v);
+  v += dpp_f<0x141, 0xF>(0.f, v);
+  v += dpp_f<0x140, 0xF>(0.f, v);
+  v += dpp_f<0x142, 0xA>(0.f, v);
+  v += dpp_f<0x143, 0xC>(0.f, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int wave_min_i(int v) {      // (non-negative values: compared as floats' bit patterns would be, done on ints)
+  const int big = 0x7fffffff;
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0xB1, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x4E, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x141, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x140, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x142, 0xA, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x143, 0xC, 0xF, false));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// ---------------------------------------------------------------- output projection + softmax + cross-entropy + its gradient
+// Training, V = 256, width 512: logits = X . E^T for 32 rows at a time with E (256 x 512 bf16 = the register files of one
+// workgroup) stationary as in proj_ws_kernel, the tile's logits turned through LDS so that each wave then owns two whole
+// rows (lane = four consecutive characters, as softmax_ce_v256_kernel), and out go only the bf16 gradient rows
+// dlogits = (p - onehot(target)) / count and the per-row (loss, hit) pair.  The logits never reach memory: the GEMM +
+// softmax pair wrote 0.8 GB of f32 and read it back at the bench shape.  Same rules as the kernel it replaces
+// (rating.py:255-258 through Keras: probabilities clipped to [1e-7, 1 - 1e-7] -- no gradient outside --, padded
+// positions count in the mean but carry no target, accuracy = first maximum equals the target).
+struct KlLogitsCe {
+  const bf16_t* X;       // [M][512] (masked) outputs of the top layer, time-major rows r = t B + b
+  const bf16_t* E;       // [256][512]
+  const int* tgt;        // [B][T]
+  bf16_t* dlogits;       // [M][256]
+  float* rowstat;        // [M][2]
+  int M, B, T, n_rg, last_only;
+  float inv_count;
+};
+
+__global__ __launch_bounds__(1024, 1) void logits_ce_ws_kernel(const KlLogitsCe a) {
+  constexpr int KSTEPS = 16, W = 512, V = 256, ROWS = 32, LDZ = V + 4, OFF_Z = 2 * ROWS * 1024;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = blockIdx.x;
+  const int n_tiles_all = a.M / ROWS;
+  const int my_tiles = rg < n_tiles_all ? (n_tiles_all - rg + a.n_rg - 1) / a.n_rg : 0;
+  if (my_tiles == 0) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // tile [2][32][1024] | logits [32][260] f32
+  float* zl = reinterpret_cast<float*>(smem + OFF_Z);
+
+  u32x4 bu[KSTEPS];
+  {
+    const long wrow = (long)(16 * wave + (lane & 15)) * W + (lane >> 4) * 8;
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j) bu[j] = *reinterpret_cast<const u32x4*>(a.E + wrow + j * 32);
+  }
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.X, (long)a.M * W * 2);
+  const __amdgpu_buffer_rsrc_t rs_dl = make_rsrc(a.dlogits, (long)a.M * V * 2);
+  const __amdgpu_buffer_rsrc_t rs_rs = make_rsrc(a.rowstat, (long)a.M * 8);
+  const unsigned frag_lane = (unsigned)((lane & 15) * 1024 + (((lane >> 4) ^ (lane & 3)) * 16) + 64 * ((lane >> 2) & 3));
+  const unsigned put_lane = (unsigned)(wave * 1024 + ((lane ^ wave) & 63) * 16);
+  auto fetch = [&](int i, u32x4 (&r)[2]) __attribute__((always_inline)) {
+    const long row0 = (long)(rg + (long)i * a.n_rg) * ROWS;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      r[h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, lane * 16, (int)(unsigned)((row0 + h * 16 + wave) * W * 2), 0));
+  };
+  auto put = [&](int buf, const u32x4 (&r)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) *reinterpret_cast<u32x4*>(smem + buf * ROWS * 1024 + h * 16 * 1024 + put_lane) = r[h];
+  };
+  // (ONE tile ahead in registers -- a second set would not fit beside the weights, the fragments and the softmax's
+  //  temporaries; the tile after next is asked for as soon as this one's rows are in LDS)
+  u32x4 ra[2];
+  fetch(0, ra);
+  put(0, ra);
+  if (my_tiles > 1) fetch(1, ra);
+  auto one_tile = [&](int i, u32x4 (&r1)[2]) __attribute__((always_inline)) {
+    const int buf = i & 1;
+    __syncthreads();                       // tile i is complete in LDS; every wave has left tile i - 1 and its logits
+    if (i + 1 < my_tiles) put(buf ^ 1, r1);
+    if (i + 2 < my_tiles) fetch(i + 2, r1);
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    {
+      const unsigned char* tb = smem + buf * ROWS * 1024;
+      u32x4 fr[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) fr[0][h] = *reinterpret_cast<const u32x4*>(tb + frag_lane + h * 16 * 1024);
+#pragma unroll
+      for (int q = 0; q < KSTEPS; ++q) {
+        if (q + 1 < KSTEPS) {
+          const int q1 = q + 1;
+          const unsigned char* ap = tb + (frag_lane ^ (unsigned)(64 * (q1 >> 2))) + 256 * (q1 & 3);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) fr[q1 & 1][h] = *reinterpret_cast<const u32x4*>(ap + h * 16 * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 fb = __builtin_bit_cast(bf16x8, bu[4 * (q & 3) + (q >> 2)]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc[h] = mfma16(__builtin_bit_cast(bf16x8, fr[q & 1][h]), fb, acc[h]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // accumulator layout (rows 4 (lane >> 4) + r, column 16 wave + (lane & 15)) -> the tile's logits in LDS
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zl[(h * 16 + 4 * (lane >> 4) + r) * LDZ + 16 * wave + (lane & 15)] = acc[h][r];
+    __syncthreads();
+    // rows 2 wave, 2 wave + 1: one row per pass, lane = characters 4 lane .. 4 lane + 3
+#pragma unroll 1
+    for (int k2 = 0; k2 < 2; ++k2) {
+      const int lr = 2 * wave + k2;
+      const long row = (long)(rg + (long)i * a.n_rg) * ROWS + lr;
+      const f32x4 z = *reinterpret_cast<const f32x4*>(zl + lr * LDZ + lane * 4);
+      float e[4] = {z[0], z[1], z[2], z[3]};
+      const int v0 = lane * 4;
+      const float mx = wave_max(fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3])));
+      // the first character that reaches the maximum (Keras' argmax)
+      const int first = e[0] == mx ? v0 : e[1] == mx ? v0 + 1 : e[2] == mx ? v0 + 2 : e[3] == mx ? v0 + 3 : 0x7fffffff;
+      const int amax = wave_min_i(first);
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        e[k] = __expf(e[k] - mx);      // (exp2-based: the arguments are <= 0)
+        sum += e[k];
+      }
+      const float inv = 1.f / wave_sum(sum);
+      const int b = (int)(row % a.B), tt = (int)(row / a.B);
+      int t = a.tgt[(long)b * a.T + tt];
+      bool counts = true;
+      if (a.last_only && tt != a.T - 1) { t = -1; counts = false; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] *= inv;
+      // the target's probability sits in lane t / 4, register t % 4 (t is uniform: one row per pass)
+      float pt = 0.f;
+      if (t >= 0) {
+        const int tl = t >> 2, tk = t & 3;
+        const float cand = tk == 0 ? e[0] : tk == 1 ? e[1] : tk == 2 ? e[2] : e[3];
+        pt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand), tl));
+      }
+      const bool valid = t >= 0;
+      const bool active = valid && pt >= 1e-7f && pt <= 1.f - 1e-7f;
+      unsigned short g[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float gk = active ? e[k] : 0.f;
+        if (active && v0 + k == t) gk -= 1.f;
+        g[k] = f2bf(gk * a.inv_count);
+      }
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{(unsigned)g[0] | ((unsigned)g[1] << 16), (unsigned)g[2] | ((unsigned)g[3] << 16)}, rs_dl, lane * 8,
+                                            (int)(unsigned)(row * V * 2), 0);
+      if (lane == 0) {
+        float l = 0.f;
+        if (valid) {
+          const float pc = fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f);
+          l = -__logf(pc) * a.inv_count;
+        }
+        const int tsafe = valid ? t : 0;
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, l), __builtin_bit_cast(unsigned, (counts && amax == tsafe) ? a.inv_count : 0.f)},
+                                              rs_rs, 0, (int)(unsigned)(row * 8), 0);
+      }
+    }
+  };
+  for (int i = 0; i < my_tiles; ++i) one_tile(i, ra);
+}
+
 // ---------------------------------------------------------------- backward
 // LDS map (bytes): tile [2][4*KSTEPS][1024] | zt [16 waves][16][17] f32 | pub [4 gates][16 rows][64 units] bf16 | flags
 constexpr int bwd2_lds_bytes(int ksteps) { return 2 * 4 * ksteps * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16; }
@@ -1155,6 +1339,26 @@ int kl_launch_proj_ws(const bf16_t* X, const bf16_t* KTp, const float* bp, bf16_
     attr_set = true;
   }
   hipLaunchKernelGGL(proj_ws_kernel, dim3(8 * 8 * ((a.n_rg + 7) / 8)), dim3(1024), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+// training only: logits, softmax, cross-entropy and its gradient in one pass (logits_ce_ws_kernel); KL_ERR_SHAPE = not applicable.
+// The caller still reduces rowstat into the loss accumulators (kl_launch_rowstat_reduce).
+int kl_launch_logits_ce_ws(const bf16_t* X, const bf16_t* E, const int* tgt, bf16_t* dlogits, float* rowstat, int B, int T, int W,
+                           int V, long ld_dl, float inv_count, int last_only, hipStream_t stream) {
+  const long M = (long)B * T;
+  if (W != 512 || V != 256 || ld_dl != 256 || M < 32 * 256 || (M % 32) != 0 || M * 512L * 2 > 0xfffffff0L) return KL_ERR_SHAPE;
+  KlLogitsCe a;
+  a.X = X; a.E = E; a.tgt = tgt; a.dlogits = dlogits; a.rowstat = rowstat;
+  a.M = (int)M; a.B = B; a.T = T; a.n_rg = 256; a.last_only = last_only; a.inv_count = inv_count;
+  const size_t lds = (size_t)2 * 32 * 1024 + 32 * (256 + 4) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&logits_ce_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return KL_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(logits_ce_ws_kernel, dim3(a.n_rg), dim3(1024), lds, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 
