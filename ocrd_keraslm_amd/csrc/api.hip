@@ -44,6 +44,7 @@ struct Carver {
   }
 };
 
+constexpr int KL_SCAN_FLAGS = 256 * 64;
 struct Derived {
   std::vector<bf16_t*> UT_hi, UT_lo, KT_hi, KT_lo, Un, Kn;   // per layer (KT/Kn of layer 0 = rows [0,W) of K0)
   bf16_t *E_hi = nullptr, *E_lo = nullptr, *ET = nullptr;
@@ -57,6 +58,7 @@ struct Derived {
   std::vector<float*> bp;        // [4W], l >= 1 (layer 0's bias is folded into EKp)
   float* EKp = nullptr;          // [V][4W] = EK + b_0
   float* CtxKp = nullptr;        // [ctx_vocab][4W] of context variable 0
+  unsigned* scan_flags = nullptr;   // lstm_scan_bwd_wide2_kernel's flags + epoch (zeroed once per bind: the numbers only grow)
 };
 
 struct WindowWs {
@@ -129,6 +131,8 @@ struct kl_handle {
   bool scan2_bf16 = true;       // KL_SCAN2_BF16=0: f32 instead of bf16 for what the scans exchange with later kernels (P, dH, c for backward)
   bool logits_ws = true;        // KL_LOGITS_WS = 0: GEMM + softmax kernel for the training window's output layer instead of the fused kernel
   bool proj_ws = true;          // KL_PROJ_WS = 0: the ring GEMM for the gate inputs P of the second-generation scans too
+  bool scan2_flags = true;      // KL_SCAN2_FLAGS = 0: the backward scan hands over by data sentinels at every size (else by flags from three blocks per step)
+  bool flags_zeroed = false;
   bool fuse_wg = true;          // KL_FUSE_WG = 0: one launch per weight-gradient product (else products over the same dZ share a pass)
   int scan2_pfb = -1;           // KL_SCAN2_PFB: the same for the backward scan (-1: by shape)
   int wide_fwd_min = 96;        // layer-sequential wide forward scans from this many 64-unit workgroups (KL_WIDE_FWD_MIN; 0 = never)
@@ -239,6 +243,7 @@ size_t carve_derived(const kl_handle* h, void* base, Derived* d) {
   }
   o.EKp = cv.take<float>(V * 4 * W);
   o.CtxKp = c.n_ctx > 0 ? cv.take<float>((size_t)c.ctx_vocab * 4 * W) : nullptr;
+  o.scan_flags = cv.take<unsigned>(KL_SCAN_FLAGS + 64);      // hand-off flags of the backward scan [256 row blocks][64] + the epoch word
   return align_up(cv.off, 256);
 }
 
@@ -325,6 +330,13 @@ int prepare_impl(kl_handle* h, int precision, hipStream_t s) {
   const float* P = h->params;
   Derived& d = h->d;
   const bool split = precision == KL_PREC_SPLIT;
+  if (!h->flags_zeroed) {      // once per bind, and not inside a capture (a replay must not turn the epoch back)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+      KL_TRY(kl_zero_async(d.scan_flags, (size_t)(KL_SCAN_FLAGS + 64) * sizeof(unsigned), s));
+      h->flags_zeroed = true;
+    }
+  }
   for (int l = 0; l < c.depth; ++l) {
     const float* K = P + h->off_K[l];   // layer 0: rows [0,W) are the char-embedding part
     const float* U = P + h->off_U[l];
@@ -802,6 +814,9 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   if (env8i) h->logits_ws = atoi(env8i) != 0;
   const char* env8h = getenv("KL_PROJ_WS");
   if (env8h) h->proj_ws = atoi(env8h) != 0;
+  const char* env8g = getenv("KL_SCAN2_FLAGS");
+  if (env8g) h->scan2_flags = atoi(env8g) != 0;
+  h->flags_zeroed = false;
   const char* env8f = getenv("KL_FUSE_WG");
   if (env8f) h->fuse_wg = atoi(env8f) != 0;
   const char* env8d = getenv("KL_SCAN2_PFB");
@@ -1060,7 +1075,13 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       a.pf_mode = h->scan2_pfb >= 0 ? h->scan2_pfb : 1;
       a.xcc_slots = (a.sentinel && h->xcd_local_bwd) ? w.scan_status + 4 : nullptr;
       a.gen = (unsigned)(1 + L + l);
-      if (a.sentinel && h->sentinel_roll && T >= 3) {
+      const bool by_flags = w.scan2_bwd && h->scan2_flags && h->flags_zeroed && kl_scan_wide2_phases(B, T, W, 16, 6) >= 3;
+      if (by_flags) {
+        // hand-off by flags (lstm_scan_bwd_wide2_kernel): nothing to arm, the epoch moves on
+        a.flags = d.scan_flags;
+        a.epoch = d.scan_flags + KL_SCAN_FLAGS;
+        KL_TRY(kl_launch_scan_epoch(d.scan_flags, KL_SCAN_FLAGS, d.scan_flags + KL_SCAN_FLAGS, (unsigned)T + 2u, s));
+      } else if (a.sentinel && h->sentinel_roll && T >= 3) {
         // rolling sentinels: the scan re-arms step t - 2 while it publishes step t; only the first two start armed
         a.sentinel = 2;
         KL_TRY(kl_fill_u32_async(w.dZ[l] + (size_t)(T - 2) * BW * 4, (size_t)2 * BW * 4 * sizeof(bf16_t), 0xFFFFFFFFu, s));

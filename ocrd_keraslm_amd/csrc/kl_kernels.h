@@ -184,7 +184,9 @@ struct KlScanBwd {
   int pf_mode;                         // second generation: as KlScanFwdWide
   const bf16_t* dHb;                   // second generation: the gradient from above as bf16 [T*B][W] (dH unused)
   const bf16_t* Cb;                    // second generation: cell states as bf16 [(T+1)B][W], blocks 1..T (null: C, f32)
+  unsigned* flags; const unsigned* epoch;   // second generation: hand-off by flags [n_rb][64] instead of sentinels (null: sentinels); *epoch: this launch's
 };
+int kl_launch_scan_epoch(unsigned* flags, int n_flags, unsigned* epoch, unsigned step, hipStream_t stream);   // epoch += step in front of a flag-mode scan
 int kl_launch_scan_bwd(KlScanBwd args, hipStream_t stream);
 bool kl_scan_bwd_wide_applicable(int B, int T, int W);
 int kl_scan_wide_blocks_per_wg(int B, int W);

@@ -172,6 +172,16 @@ __device__ __forceinline__ void glds16_plain_s(__amdgpu_buffer_rsrc_t rsrc, unsi
       : "memory");
 }
 
+// ... coherent across XCDs (hand-off flags)
+__device__ __forceinline__ void glds4_sc1_s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dword %1, %2, %3 offen sc1 lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+      : "memory");
+}
+
 // NB: row blocks of 16 per phase; NP: phases per workgroup and step (>= 2: while one phase computes, the other's
 // publish travels); TAB: layer 0, gate inputs from the look-up tables instead of P rows.
 // Nothing asynchronous ever lands in a register: tiles, gate-input pieces and table-row ids are all brought in by
@@ -915,8 +925,8 @@ __global__ __launch_bounds__(1024, 1) void logits_ce_ws_kernel(const KlLogitsCe 
 }
 
 // ---------------------------------------------------------------- backward
-// LDS map (bytes): tile [2][4*KSTEPS][1024] | zt [16 waves][16][17] f32 | pub [4 gates][16 rows][64 units] bf16 | flags
-constexpr int bwd2_lds_bytes(int ksteps) { return 2 * 4 * ksteps * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16; }
+// LDS map (bytes): tile [2][4*KSTEPS][1024] | zt [16 waves][16][17] f32 | pub [4 gates][16 rows][64 units] bf16 | flags | hand-off words [64]
+constexpr int bwd2_lds_bytes(int ksteps) { return 2 * 4 * ksteps * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16 + 256; }
 
 // One layer, 16-row blocks, NP blocks per workgroup and step (2..4).  Wave = (K quarter = gate kq4, unit group ug):
 // dh_rec[16 x 16] = dZ[t+1][16 x W(gate kq4)] . Un[W(gate kq4) x 16 units]; the four gate partials meet in LDS.
@@ -924,7 +934,7 @@ constexpr int bwd2_lds_bytes(int ksteps) { return 2 * 4 * ksteps * 1024 + 16 * 1
 // Rolling sentinels (a.sentinel == 2) as in the first generation: the publishing lanes re-arm step t - 2 while they store
 // step t.  The re-arming store has completed before the same lanes publish step t - 1: a whole step of NP >= 2 blocks
 // lies between them, and the counted tile wait at the top of the block after next covers every store of this one.
-template <int KSTEPS, int NP>
+template <int KSTEPS, int NP, bool FLAGS>
 __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlScanBwd a) {
   constexpr int W = KSTEPS * 32;
   constexpr int NWG_RB = W / 64;
@@ -943,6 +953,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
   float (*zt)[16][17] = reinterpret_cast<float (*)[16][17]>(smem + 2 * NPIECE * 1024);
   bf16_t* pub = reinterpret_cast<bf16_t*>(smem + 2 * NPIECE * 1024 + 16 * 16 * 17 * 4);
   int& ok_flag = *reinterpret_cast<int*>(smem + 2 * NPIECE * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2);
+  unsigned* const fl_l = reinterpret_cast<unsigned*>(smem + 2 * NPIECE * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16);
   const unsigned lds_tile = (unsigned)(size_t)(lds_void_t*)smem;
 
   u32x4 bu[KSTEPS];
@@ -972,6 +983,15 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
   float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
   const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(dZl, (long)T * BW * 4 * 2);
   const __amdgpu_buffer_rsrc_t rs_null = make_rsrc(dZl, 0);
+  // Hand-off by flags (a.flags; NP >= 3): each publishing wave posts "my rows of step t are in memory" as the number
+  // epoch - t in its own word, flags[row block][column group * 8 + wave], once its stores have completed -- which it
+  // learns for free half a block later, where it waits for its epilogue inputs anyway.  A consumer looks at the 64
+  // words of a row block before it requests the tile.  The numbers only grow (the epoch advances by T + 2 per launch,
+  // bumped by a one-block kernel in front: a replayed hipGraph must not see last launch's flags as this one's), so
+  // nothing is re-armed: no second 4W-wide store per row and step, which is 8 of the scan's 36 bytes per cell.
+  unsigned* const flags = FLAGS ? a.flags : nullptr;
+  const unsigned epoch = FLAGS ? *a.epoch : 0u;
+  const __amdgpu_buffer_rsrc_t rs_fl = make_rsrc(flags, FLAGS ? (long)a.n_rb * 64 * 4 : 0);
   bool alive = true;
   if (tid == 0) ok_flag = 1;
 #pragma unroll
@@ -981,7 +1001,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   bool local = false;      // XCD-local hand-off (opt-in), as in the forward scan
-  if (a.xcc_slots)
+  if (!FLAGS && a.xcc_slots)
     local = __builtin_amdgcn_readfirstlane(
                 xcd_local_group(a.xcc_slots, a.gen, NWG_RB, [&](int j) { return xcd + 8 * (rq * NWG_RB + j); }, &ok_flag + 1, status) ? 1 : 0) != 0;
   SSTAMP_INIT(0);
@@ -1043,7 +1063,15 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
         }
         seq_in = vq;
       }
-      if (a.pf_mode == 0 && alive && t1 >= 0 && t1 < T - 1) issue_tile(t1, r1, buf ^ 1);       // (a.pf_mode: see the forward scan)
+      // (flags: the 64 words of the next block's rows come into LDS -- armed with 0 = "not yet" -- and are looked at behind
+      //  the MFMAs; the last wave fetches them, it publishes nothing)
+      if (FLAGS && wave == 15 && t1 >= 0 && t1 < T - 1) {
+        fl_l[lane] = 0u;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        glds4_sc1_s(rs_fl, (unsigned)(lane * 4), (unsigned)((r1 >> 4) * 256), lds_tile + (unsigned)(2 * NPIECE * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16));
+        ++vq;
+      }
+      if (!FLAGS && a.pf_mode == 0 && alive && t1 >= 0 && t1 < T - 1) issue_tile(t1, r1, buf ^ 1);       // (a.pf_mode: see the forward scan)
       if (alive && t < T - 1) {
         wait_vm(vq - seq_tile[buf]);
         SSTAMP(25);
@@ -1109,8 +1137,44 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
       SSTAMP(19);
       __syncthreads();
       SSTAMP(20);
+      if (FLAGS) {
+        // the publishing waves post the block before this one: behind this wait (their epilogue inputs, needed in a moment
+        // anyway) nothing of theirs is in flight, so that block's stores are in memory
+        if (wave < 8 && n > 0) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          int tp = t, ipp = ip - 1;
+          if (ipp < 0) { ipp = NP - 1; tp = t + 1; }
+          const int rbp = rg + ipp * n_rg;
+          if (lane == 0)
+            __builtin_amdgcn_raw_buffer_store_b32(epoch - (unsigned)tp, alive ? rs_fl : rs_null, (rbp * 64 + cg * 8 + wave) * 4, 0, 16);
+          ++vq;
+        }
+        if (alive && t1 >= 0 && t1 < T - 1) {
+          // (unsigned distance: a word of this launch is at most T - 1 behind the epoch, one of an earlier launch at least T + 2)
+          const unsigned far = (unsigned)(t1 + 1);
+          bool ready = __all(epoch - *reinterpret_cast<const volatile unsigned*>(fl_l + lane) <= far);
+          if (!ready) {      // not posted when the words were fetched, or the fetch itself still on its way: ask memory
+#ifdef KL_STAMP
+            if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[28] += 1;
+#endif
+            for (unsigned spin = 0; spin < SPIN_LIMIT && !ready; ++spin) {
+              const unsigned now = __hip_atomic_load(flags + (long)(r1 >> 4) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ready = __all(epoch - now <= far);
+              if (!ready) {
+                if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                __builtin_amdgcn_s_sleep(2);
+              }
+            }
+            if (!ready) {
+              __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ok_flag = 0;
+            }
+          }
+          if (ready) issue_tile(t1, r1, buf ^ 1);
+        }
+      } else
       if (a.pf_mode == 1 && alive && t1 >= 0 && t1 < T - 1) issue_tile(t1, r1, buf ^ 1);     // (its buffer was last read a block ago)
-      if (a.pf_mode == 2 && alive && t2 >= 0 && t2 < T - 1) issue_tile(t2, r2, buf);         // (every wave has finished this block's MFMAs)
+      if (!FLAGS && a.pf_mode == 2 && alive && t2 >= 0 && t2 < T - 1) issue_tile(t2, r2, buf);         // (every wave has finished this block's MFMAs)
       // ---- epilogue: thread = (row er, unit eu)
       // (loads and stores retire independently, so the count is an estimate: the armed registers are checked)
       wait_vm(vq - seq_in);
@@ -1161,7 +1225,10 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
         const unsigned off = (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2);
         const unsigned soff = off - (unsigned)((long)2 * B * 4 * W * 2);
         const uint4 ones = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (local) {      // plain stores: they stay in this XCD's L2, where all their readers are
+        if (FLAGS) {
+          store16_sc1(alive ? rs_own : rs_null, off, v);
+          --vq;      // (one store, not two)
+        } else if (local) {      // plain stores: they stay in this XCD's L2, where all their readers are
           store16(alive ? rs_own : rs_null, off, 0u, v);
           store16((alive && t >= 2) ? rs_own : rs_null, soff, 0u, ones);
         } else {
@@ -1362,20 +1429,43 @@ int kl_launch_logits_ce_ws(const bf16_t* X, const bf16_t* E, const int* tgt, bf1
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 
+// In front of a flag-mode backward scan: the epoch moves on by `step` (> the scan's T + 1, so that no word a former
+// launch left can pass for one of this launch); near the end of the 32-bit range everything starts over.
+__global__ void scan_epoch_kernel(unsigned* flags, int n_flags, unsigned* epoch, unsigned step) {
+  __shared__ unsigned old;
+  if (threadIdx.x == 0) old = *epoch;
+  __syncthreads();
+  const bool wrap = old > 0xF0000000u;
+  if (wrap)
+    for (int i = threadIdx.x; i < n_flags; i += blockDim.x) flags[i] = 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) *epoch = (wrap ? 0u : old) + step;
+}
+int kl_launch_scan_epoch(unsigned* flags, int n_flags, unsigned* epoch, unsigned step, hipStream_t stream) {
+  hipLaunchKernelGGL(scan_epoch_kernel, dim3(1), dim3(1024), 0, stream, flags, n_flags, epoch, step);
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
 int kl_launch_scan_bwd_wide2(KlScanBwd a, hipStream_t stream) {
   const int W = a.W;
   const int np = kl_scan_wide2_phases(a.B, a.T, W, 16, 6);
-  if (!np || a.L != 1 || a.sentinel != 2 || a.dZT || a.T < 3) return KL_ERR_SHAPE;
+  if (!np || a.L != 1 || a.dZT || a.T < 3) return KL_ERR_SHAPE;
+  if (a.flags ? (np < 3 || !a.epoch) : a.sentinel != 2) return KL_ERR_SHAPE;      // (flags: see the kernel; two blocks per step leave them no time)
   a.n_rb = a.B / 16;
   a.n_rg = a.n_rb / np;
   const int col_groups = W / 64;
   dim3 grid(8 * col_groups * ((a.n_rg + 7) / 8)), block(1024);
   const size_t lds = (size_t)bwd2_lds_bytes(W / 32);
-#define KL_B2_CASE(KS, NP_)                                                                                                \
+#define KL_B2_CASE1(KS, NP_, FL_)                                                                                          \
   do {                                                                                                                      \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_bwd_wide2_kernel<KS, NP_>),                           \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_bwd_wide2_kernel<KS, NP_, FL_>),                      \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;     \
-    hipLaunchKernelGGL((lstm_scan_bwd_wide2_kernel<KS, NP_>), grid, block, lds, stream, a);                                 \
+    hipLaunchKernelGGL((lstm_scan_bwd_wide2_kernel<KS, NP_, FL_>), grid, block, lds, stream, a);                            \
+  } while (0)
+#define KL_B2_CASE(KS, NP_)                   \
+  do {                                        \
+    if (a.flags) KL_B2_CASE1(KS, NP_, true);  \
+    else KL_B2_CASE1(KS, NP_, false);         \
   } while (0)
 #define KL_B2_NP(KS)                                                                             \
   do {                                                                                          \
@@ -1390,6 +1480,7 @@ int kl_launch_scan_bwd_wide2(KlScanBwd a, hipStream_t stream) {
   KL_B2_NP(16);
 #undef KL_B2_NP
 #undef KL_B2_CASE
+#undef KL_B2_CASE1
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 
