@@ -384,6 +384,38 @@ def test_train_window_scan2(monkeypatch, depth, width, voc, B, T, n_ctx, use_mas
     check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks, want_kernel="lstm_scan_fwd_wide2_kernel")
 
 
+def test_flag_handoff_survives_changing_shapes():
+    """The backward scan's flag hand-off keeps ONE set of flag words and an epoch per engine: windows of changing size and
+    length on the same engine (hipGraph replays in between) must give what a fresh engine gives for the same inputs --
+    a word left by an earlier, longer window must never pass for one of the current launch."""
+    from ocrd_keraslm_amd.lib import hipabi
+    depth, width, voc = 2, 512, 64
+    cfg, w, lm = make_model(depth, width, voc, 1, emb_std=0.3)
+    lm.set_weights(w, hipabi.KL_PREC_BF16)
+    rng = np.random.default_rng(33)
+    for B, T in [(1536, 6), (2048, 3), (1536, 3), (3072, 4), (1536, 6)]:
+        idx = rng.integers(0, voc, (B, T))
+        ctx = rng.integers(0, 200, (B, 1, 1)).repeat(T, axis=1)
+        tgt = rng.integers(0, voc, (B, T))
+        states = (rng.standard_normal((B, 2 * depth, width)) * 0.1).astype(np.float32)
+        got = []
+        for engine in (lm, None):
+            if engine is None:
+                _cfg, _w, engine = make_model(depth, width, voc, 1, emb_std=0.3)
+                engine.set_weights(w, hipabi.KL_PREC_BF16)
+            for _rep in range(2):                      # (the second pass replays the captured graph)
+                engine.reset_states(B)
+                engine.set_states(states)
+                engine.loss_acc.zero_()
+                engine.train_window(idx, ctx, tgt, None)
+            got.append((engine.read_loss(), engine.get_grads()))
+        (l0, g0), (l1, g1) = got
+        assert abs(l0[0] - l1[0]) < 1e-4 * max(1.0, abs(l1[0])), (B, T, l0, l1)
+        for name in g1:
+            scale = np.abs(g1[name]).max() + 1e-12
+            assert np.abs(g0[name] - g1[name]).max() / scale < 2e-3, (B, T, name)
+
+
 @pytest.mark.parametrize("depth,width,voc,B,T,n_ctx", [(6, 128, 30, 5, 7, 1), (2, 128, 40, 20, 9, 1)])
 def test_train_window_launch_per_step_path(monkeypatch, depth, width, voc, B, T, n_ctx):
     """KL_SCAN=0: the launch-per-step kernels (the fallback of every shape the scans do not cover), incl. more
