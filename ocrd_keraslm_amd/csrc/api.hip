@@ -1080,6 +1080,10 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
         // hand-off by flags (lstm_scan_bwd_wide2_kernel): nothing to arm, the epoch moves on
         a.flags = d.scan_flags;
         a.epoch = d.scan_flags + KL_SCAN_FLAGS;
+        // (flags tell before the request whether a tile is there, so it can be asked for TWO blocks ahead, behind the epilogue,
+        //  without the re-fetches that cost the sentinel form -- once five or more blocks lie between a publish and its use)
+        if (h->scan2_pfb < 0) a.pf_mode = kl_scan_wide2_phases(B, T, W, 16, 6) >= 5 ? 2 : 1;
+        else if (a.pf_mode == 0) a.pf_mode = 1;
         KL_TRY(kl_launch_scan_epoch(d.scan_flags, KL_SCAN_FLAGS, d.scan_flags + KL_SCAN_FLAGS, (unsigned)T + 2u, s));
       } else if (a.sentinel && h->sentinel_roll && T >= 3) {
         // rolling sentinels: the scan re-arms step t - 2 while it publishes step t; only the first two start armed

@@ -1065,10 +1065,15 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
       }
       // (flags: the 64 words of the next block's rows come into LDS -- armed with 0 = "not yet" -- and are looked at behind
       //  the MFMAs; the last wave fetches them, it publishes nothing)
-      if (FLAGS && wave == 15 && t1 >= 0 && t1 < T - 1) {
+      // (a.pf_mode 2: the tile of the block after next is asked for -- into the buffer this block's MFMAs leave --, a block and
+      //  a half before it is needed, and only BEHIND the epilogue: the request costs its wave ~170 cycles per piece, which
+      //  then no longer stand between the MFMA phase and the publish)
+      const bool pf2 = FLAGS && a.pf_mode == 2;
+      const int tF = pf2 ? t2 : t1, rF = pf2 ? r2 : r1;
+      if (FLAGS && wave == 15 && tF >= 0 && tF < T - 1) {
         fl_l[lane] = 0u;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        glds4_sc1_s(rs_fl, (unsigned)(lane * 4), (unsigned)((r1 >> 4) * 256), lds_tile + (unsigned)(2 * NPIECE * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16));
+        glds4_sc1_s(rs_fl, (unsigned)(lane * 4), (unsigned)((rF >> 4) * 256), lds_tile + (unsigned)(2 * NPIECE * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16));
         ++vq;
       }
       if (!FLAGS && a.pf_mode == 0 && alive && t1 >= 0 && t1 < T - 1) issue_tile(t1, r1, buf ^ 1);       // (a.pf_mode: see the forward scan)
@@ -1137,6 +1142,31 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
       SSTAMP(19);
       __syncthreads();
       SSTAMP(20);
+      auto request_next = [&]() __attribute__((always_inline)) {
+        if (alive && tF >= 0 && tF < T - 1) {
+          // (unsigned distance: a word of this launch is at most T - 1 behind the epoch, one of an earlier launch at least T + 2)
+          const unsigned far = (unsigned)(tF + 1);
+          bool ready = __all(epoch - *reinterpret_cast<const volatile unsigned*>(fl_l + lane) <= far);
+          if (!ready) {      // not posted when the words were fetched, or the fetch itself still on its way: ask memory
+#ifdef KL_STAMP
+            if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[28] += 1;
+#endif
+            for (unsigned spin = 0; spin < SPIN_LIMIT && !ready; ++spin) {
+              const unsigned now = __hip_atomic_load(flags + (long)(rF >> 4) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ready = __all(epoch - now <= far);
+              if (!ready) {
+                if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                __builtin_amdgcn_s_sleep(2);
+              }
+            }
+            if (!ready) {
+              __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ok_flag = 0;
+            }
+          }
+          if (ready) issue_tile(tF, rF, pf2 ? buf : buf ^ 1);
+        }
+      };
       if (FLAGS) {
         // the publishing waves post the block before this one: behind this wait (their epilogue inputs, needed in a moment
         // anyway) nothing of theirs is in flight, so that block's stores are in memory
@@ -1149,29 +1179,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
             __builtin_amdgcn_raw_buffer_store_b32(epoch - (unsigned)tp, alive ? rs_fl : rs_null, (rbp * 64 + cg * 8 + wave) * 4, 0, 16);
           ++vq;
         }
-        if (alive && t1 >= 0 && t1 < T - 1) {
-          // (unsigned distance: a word of this launch is at most T - 1 behind the epoch, one of an earlier launch at least T + 2)
-          const unsigned far = (unsigned)(t1 + 1);
-          bool ready = __all(epoch - *reinterpret_cast<const volatile unsigned*>(fl_l + lane) <= far);
-          if (!ready) {      // not posted when the words were fetched, or the fetch itself still on its way: ask memory
-#ifdef KL_STAMP
-            if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[28] += 1;
-#endif
-            for (unsigned spin = 0; spin < SPIN_LIMIT && !ready; ++spin) {
-              const unsigned now = __hip_atomic_load(flags + (long)(r1 >> 4) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              ready = __all(epoch - now <= far);
-              if (!ready) {
-                if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                __builtin_amdgcn_s_sleep(2);
-              }
-            }
-            if (!ready) {
-              __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              ok_flag = 0;
-            }
-          }
-          if (ready) issue_tile(t1, r1, buf ^ 1);
-        }
+        if (!pf2) request_next();
       } else
       if (a.pf_mode == 1 && alive && t1 >= 0 && t1 < T - 1) issue_tile(t1, r1, buf ^ 1);     // (its buffer was last read a block ago)
       if (!FLAGS && a.pf_mode == 2 && alive && t2 >= 0 && t2 < T - 1) issue_tile(t2, r2, buf);         // (every wave has finished this block's MFMAs)
@@ -1213,6 +1221,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
       pub[(1 * 16 + er) * 64 + eu] = (bf16_t)z1;
       pub[(2 * 16 + er) * 64 + eu] = (bf16_t)z2;
       pub[(3 * 16 + er) * 64 + eu] = (bf16_t)z3;
+      if (FLAGS && pf2) request_next();
       SSTAMP(22);
       __syncthreads();
       SSTAMP(23);
