@@ -930,7 +930,10 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   // B1: dH = dlogits . E ; dE += dlogits^T . Htop
   // (second-generation backward scan: dH travels as bf16)
   const int dh_mode = w.scan2_bwd ? 1 : 0;
-  KL_TRY(kl_launch_gemm_tn(w.dlogits, d.ET, w.dH, nullptr, BT, W, Vp, Vp, Vp, W, dh_mode, 1, 1.f, s));
+  int de = KL_ERR_SHAPE;
+  if (dh_mode == 1 && h->logits_ws) de = kl_launch_dh_ws(w.dlogits, d.ET, reinterpret_cast<bf16_t*>(w.dH), BT, W, Vp, s);
+  if (de == KL_ERR_SHAPE) de = kl_launch_gemm_tn(w.dlogits, d.ET, w.dH, nullptr, BT, W, Vp, Vp, Vp, W, dh_mode, 1, 1.f, s);
+  KL_TRY(de);
   if (BTp != BT) {
     KL_TRY(kl_zero_async(w.dlogitsT, (size_t)Vp * BTp * sizeof(bf16_t), s));
     KL_TRY(kl_zero_async(w.HT, (size_t)W * BTp * sizeof(bf16_t), s));

@@ -778,6 +778,89 @@ __device__ __forceinline__ int wave_min_i(int v) {      // (non-negative values:
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+// ---------------------------------------------------------------- gradient into the top layer: dH = dlogits . E
+// dH[r][:] = dlogits[r][:256] . ET[:][:256]^T as bf16, weight-stationary like proj_ws_kernel: ET (512 x 256 bf16) lies in the
+// registers of two column groups (wave w: 16 output columns, K = 256 in 32 VGPRs), dlogits rows (512 bytes) stream through
+// a double-buffered 32-row tile, fetched through registers two tiles ahead -- one 1 KiB load per wave and tile covers two
+// rows.  Chunk c (16 bytes) of tile row r sits at position c ^ (r & 15) of the row, so that the sixteen rows a fragment
+// read touches fall on different bank groups.
+struct KlDhWs {
+  const bf16_t* X;       // [M][256] dlogits
+  const bf16_t* ET;      // [512][256]
+  bf16_t* dH;            // [M][512]
+  int M, n_rg;
+};
+
+__global__ __launch_bounds__(1024, 1) void dh_ws_kernel(const KlDhWs a) {
+  constexpr int KSTEPS = 8, K = 256, N = 512, NCG = N / 256, ROWS = 32, RB = K * 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, yy = blockIdx.x >> 3;
+  const int cg = yy % NCG, rq = yy / NCG, rg = xcd * ((a.n_rg + 7) >> 3) + rq;
+  if (rg >= a.n_rg) return;
+  const int c0 = cg * 256;
+  const int n_tiles_all = a.M / ROWS;
+  const int my_tiles = rg < n_tiles_all ? (n_tiles_all - rg + a.n_rg - 1) / a.n_rg : 0;
+  if (my_tiles == 0) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // tile [2][32 rows][512]
+
+  u32x4 bu[KSTEPS];
+  {
+    const long wrow = (long)(c0 + 16 * wave + (lane & 15)) * K + (lane >> 4) * 8;
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j) bu[j] = *reinterpret_cast<const u32x4*>(a.ET + wrow + j * 32);
+  }
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.X, (long)a.M * K * 2);
+  const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(a.dH, (long)a.M * N * 2);
+  // this wave's load covers rows 2 w and 2 w + 1 of a tile: lane -> (row, chunk)
+  const int prow = 2 * wave + (lane >> 5), pchunk = lane & 31;
+  const unsigned put_lane = (unsigned)(prow * RB + ((pchunk ^ (prow & 15)) * 16));
+  const int frow = lane & 15, kg = lane >> 4;      // fragment row (+ 16 h) and k group of this lane
+  const int jr = lane & 3, a4 = (lane >> 2) & 3, q4 = lane >> 4;
+  auto fetch = [&](int i, u32x4& r) __attribute__((always_inline)) {
+    const long row0 = (long)(rg + (long)i * a.n_rg) * ROWS;
+    r = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, lane * 16, (int)(unsigned)((row0 + 2 * wave) * RB), 0));
+  };
+  auto put = [&](int buf, const u32x4& r) __attribute__((always_inline)) {
+    *reinterpret_cast<u32x4*>(smem + buf * ROWS * RB + put_lane) = r;
+  };
+  u32x4 ra, rb;
+  fetch(0, ra);
+  put(0, ra);
+  if (my_tiles > 1) fetch(1, ra);
+  if (my_tiles > 2) fetch(2, rb);
+  auto one_tile = [&](int i, u32x4& r1) __attribute__((always_inline)) {
+    const int buf = i & 1;
+    __syncthreads();
+    if (i + 1 < my_tiles) put(buf ^ 1, r1);
+    if (i + 3 < my_tiles) fetch(i + 3, r1);
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const unsigned char* tb = smem + buf * ROWS * RB;
+#pragma unroll
+    for (int q = 0; q < KSTEPS; ++q) {
+      u32x4 fr[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) fr[h] = *reinterpret_cast<const u32x4*>(tb + (frow + 16 * h) * RB + (((4 * q + kg) ^ frow) * 16));
+      const bf16x8 fb = __builtin_bit_cast(bf16x8, bu[q]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) acc[h] = mfma16(__builtin_bit_cast(bf16x8, fr[h]), fb, acc[h]);
+    }
+    const long row0 = (long)(rg + (long)i * a.n_rg) * ROWS;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 v = acc[h];
+      quad_transpose(v, jr);
+      const u32x2 pk = u32x2{(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
+      const unsigned off = (unsigned)(((h * 16 + 4 * q4 + jr) * N + c0 + 16 * wave + 4 * a4) * 2);
+      __builtin_amdgcn_raw_buffer_store_b64(pk, rs_o, (int)off, (int)(unsigned)(row0 * N * 2), 0);
+    }
+  };
+  for (int i = 0; i < my_tiles; i += 2) {
+    one_tile(i, ra);
+    if (i + 1 < my_tiles) one_tile(i + 1, rb);
+  }
+}
+
 // ---------------------------------------------------------------- output projection + softmax + cross-entropy + its gradient
 // Training, V = 256, width 512: logits = X . E^T for 32 rows at a time with E (256 x 512 bf16 = the register files of one
 // workgroup) stationary as in proj_ws_kernel, the tile's logits turned through LDS so that each wave then owns two whole
@@ -1452,6 +1535,16 @@ __global__ void scan_epoch_kernel(unsigned* flags, int n_flags, unsigned* epoch,
 }
 int kl_launch_scan_epoch(unsigned* flags, int n_flags, unsigned* epoch, unsigned step, hipStream_t stream) {
   hipLaunchKernelGGL(scan_epoch_kernel, dim3(1), dim3(1024), 0, stream, flags, n_flags, epoch, step);
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+// dH = dlogits . E as bf16 for a training window (dh_ws_kernel: V padded to 256, width 512); KL_ERR_SHAPE = not applicable
+int kl_launch_dh_ws(const bf16_t* dlogits, const bf16_t* ET, bf16_t* dH, long M, int W, int Vp, hipStream_t stream) {
+  if (W != 512 || Vp != 256 || M < 32 * 128 || (M % 32) != 0 || M * 512L * 2 > 0xfffffff0L) return KL_ERR_SHAPE;
+  KlDhWs a;
+  a.X = dlogits; a.ET = ET; a.dH = dH; a.M = (int)M; a.n_rg = 128;
+  const size_t lds = (size_t)2 * 32 * 512;
+  hipLaunchKernelGGL(dh_ws_kernel, dim3(8 * 2 * ((a.n_rg + 7) / 8)), dim3(1024), lds, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 
