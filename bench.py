@@ -29,6 +29,7 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
                 precision): cfg3 (1024 hypotheses x 512 chars) and the reference's own batch cap
                 (128 hypotheses, rating.py:49, 809); wall and GPU-only time per step, algorithmic
                 HBM bytes per step; under N > 1 every rank runs it and the values are summed
+  rating_window chars/s and ms per stateful 256-char window of the rating forward (1 and 64 streams, split precision)
   end_to_end    chars/s of Rater.train itself (file reading, window generation, vocabulary look-up,
                 dropout masks, loss read-backs, one validation pass) over synthetic text files of the
                 same topology and stream count, rank 0 only -- what the host side costs
@@ -372,6 +373,36 @@ def main():
                                 "hbm_frac": legs[128]["hbm_frac"], "mfma_frac": legs[128]["mfma_frac"],
                                 "note": "the reference's batch cap (rating.py:49, 809)"}}
 
+    # ---- rating windows (rate / rate2 / test): the stateful windowed forward in split precision with probabilities out,
+    # at the reference's batching (1 stream x 256 chars, rating.py:490) and at 64 streams; rank 0 reports its own GPU
+    rating = None
+    if not args.no_incremental:
+        lm.prepare(hipabi.KL_PREC_SPLIT)
+        rating = {}
+        for Br in (1, 64):
+            lm.reset_states(Br)
+            r4 = np.random.default_rng(11)
+            xi = torch.from_numpy(r4.integers(1, VOC, size=(Br, LENGTH)).astype(np.int32)).to(device)
+            ci = torch.from_numpy(r4.integers(0, 200, size=(Br, 1, N_CTX)).repeat(LENGTH, axis=1).astype(np.int32)).to(device)
+            for _ in range(5):
+                lm.forward_window(xi, ci)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 50
+            t1 = time.perf_counter()
+            e0.record()
+            for _ in range(reps):
+                lm.forward_window(xi, ci)
+            e1.record()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t1
+            gpu_ms = e0.elapsed_time(e1) / reps
+            rating["streams_%d" % Br] = {"value": Br * LENGTH * reps / el, "unit": "chars/s", "ms_per_window": el / reps * 1e3,
+                                         "gpu_ms_per_window": gpu_ms,
+                                         "mfma_frac": Br * LENGTH * flops_fwd_per_char() / (gpu_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+        rating["precision"] = "split-bf16 (3 MFMA passes)"
+        rating["note"] = "stateful window of 256 chars, probabilities copied to the host as Rater.rate needs them (16.8 MB per window at 64 streams); 1 stream = the reference's batching"
+
     # ---- end to end: Rater.train over synthetic files (rank 0, one GPU): what the Python above the ABI costs
     end_to_end = None
     # (N = 1 only: Rater.train would see the process group and start collectives the other ranks are not in)
@@ -401,7 +432,7 @@ def main():
                        "streams_per_gpu": B, "global_batch": B * world, "seq_len": T,
                        "parallelism": "dp%d" % world, "final_ce": ce / max(args.steps, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_torch": cpu_torch, "incremental": incremental,
-            "end_to_end": end_to_end,
+            "rating_window": rating, "end_to_end": end_to_end,
         }
         print(json.dumps(line))
     if world > 1:

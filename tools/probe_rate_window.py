@@ -1,0 +1,31 @@
+"""Diagnostic: the rating window (Rater.rate: stateful windowed forward, split precision, probabilities out) for the
+rocprofv3 kernel stats committed under profiles/ (tools/profile_round.sh)."""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, '.')
+from ocrd_keraslm_amd.lib import hipabi
+from ocrd_keraslm_amd.lib.engine import HipLM
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+L, W, V, T = 2, 512, 256, 256
+lm = HipLM(L, W, V, 1)
+lm.init_weights(seed=1)
+lm.prepare(hipabi.KL_PREC_SPLIT)
+rng = np.random.default_rng(0)
+idx = torch.from_numpy(rng.integers(1, V, (B, T)).astype(np.int32)).cuda()
+ctx = torch.from_numpy(rng.integers(0, 200, (B, 1, 1)).repeat(T, axis=1).astype(np.int32)).cuda()
+lm.reset_states(B)
+for _ in range(5):
+    lm.forward_window(idx, ctx)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 100
+for _ in range(n):
+    lm.forward_window(idx, ctx)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / n
+print("rating window B=%d T=%d split precision: %.3f ms/window, %.1f k chars/s" % (B, T, dt * 1e3, B * T / dt / 1e3))

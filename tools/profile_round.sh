@@ -21,4 +21,8 @@ KL_PROBE_PREC=3 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-form
 cp $OUT/${TAG}_inc_stats/*/*_kernel_stats.csv $OUT/${TAG}_incremental_n1024_kernel_stats.csv
 KL_PROBE_PREC=3 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_inc128_stats -- python3 tools/probe_incremental.py 128 > $OUT/${TAG}_inc128.log 2>&1
 cp $OUT/${TAG}_inc128_stats/*/*_kernel_stats.csv $OUT/${TAG}_incremental_n128_kernel_stats.csv
+# the rating window (Rater.rate): 1 stream x 256 chars, split precision
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_rate_stats -- python3 tools/probe_rate_window.py 1 > $OUT/${TAG}_rate1.log 2>&1
+cp $OUT/${TAG}_rate_stats/*/*_kernel_stats.csv $OUT/${TAG}_rating_window_B1_kernel_stats.csv
 grep "us/step" $OUT/${TAG}_inc1024.log $OUT/${TAG}_inc128.log
+grep "rating window" $OUT/${TAG}_rate1.log
