@@ -565,7 +565,9 @@ def test_handoff_flavours_agree_bitwise(B, windows, env):
     assert g < (3e-2 if env.get("KL_SCAN2") == "1" else 1e-3) and c < 5e-2, (g, c)
 
 
-@pytest.mark.parametrize("depth,width,voc,B,T", [(2, 128, 50, 6, 12), (2, 512, 64, 128, 9), (1, 64, 30, 3, 5)])
+@pytest.mark.parametrize("depth,width,voc,B,T", [(2, 128, 50, 6, 12), (2, 512, 64, 128, 9), (1, 64, 30, 3, 5),
+                                                 # big enough for the fused output layer (V = 256, width 512, B*T >= 8192)
+                                                 (2, 512, 256, 1024, 8)])
 def test_stateless_window_mode(depth, width, voc, B, T):
     """kl_set_window_mode(1): the reference's stateless graph (rating.py:126-129, 1123-1126) -- windows start
     from zero state, ONE target per window at its last position, loss / accuracy are means over the B
