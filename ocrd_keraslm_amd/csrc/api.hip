@@ -497,7 +497,11 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       a.sentinel = h->sentinel ? 1 : 0;
       a.xcc_slots = (a.sentinel && h->xcd_local) ? w.scan_status + 4 : nullptr;
       a.gen = (unsigned)(1 + l);                   // (the posts are zeroed once per window: a token per launch)
-      if (a.sentinel)   // hand-off by data: the blocks the scan is going to publish start out as sentinels
+      if (a.sentinel && v2 && h->sentinel_roll && T >= 3) {
+        // rolling sentinels: the scan arms block t + 3 while it publishes block t + 1; only the first two start armed
+        a.sentinel = 2;
+        KL_TRY(kl_fill_u32_async((bf16_t*)w.H[l] + BW, (size_t)2 * BW * sizeof(bf16_t), 0xFFFFFFFFu, s));
+      } else if (a.sentinel)   // hand-off by data: the blocks the scan is going to publish start out as sentinels
         KL_TRY(kl_fill_u32_async((bf16_t*)w.H[l] + BW, (size_t)T * BW * sizeof(bf16_t), 0xFFFFFFFFu, s));
       else
         KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)n_rb * T, s));

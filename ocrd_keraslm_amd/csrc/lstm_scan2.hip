@@ -569,6 +569,18 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide2_kernel(const KlSc
           else if (local) store16(rs_h, off, 0u, v);        // stays in this XCD's L2, where all its readers are
           else store16_sc1(rs_h, off, v);
           ++vq;
+          if (a.sentinel == 2) {
+            // rolling sentinels (as the backward scan's): the same lanes arm block t + 3 while they publish block t + 1, so only
+            // blocks 1 and 2 are pre-filled in front of the launch instead of all T (0.8 GB per layer at the bench shape).
+            // The arming store and the publish of block t + 3 two steps later come from the same lanes to the same
+            // addresses, i.e. in order; nobody reads block t + 3 before it has been published.
+            const uint4 ones = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            const unsigned off3 = off + (unsigned)((long)2 * B * W * 2);
+            if (!alive || t + 3 > T) store16(make_rsrc(a.H, 0), 0u, 0u, ones);
+            else if (local) store16(rs_h, off3, 0u, ones);
+            else store16_sc1(rs_h, off3, ones);
+            ++vq;
+          }
         }
         if (NB == 2 || wave >= 2) {
           // gates: ROWS x 32 pieces (2 units x 4 gates); NB == 1: waves 2..9
