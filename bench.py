@@ -193,6 +193,89 @@ def end_to_end_leg(B, windows_per_file=48):
                 "note": "Rater.train, one epoch + validation, wall time of the whole call"}
 
 
+def training_leg(device, depth, width, length, n_ctx, B, steps, warmup, corpus, seed=1):
+    """cfg-style stateful training on ONE GPU (no collective): B streams x `length` characters per step, forward + backward +
+    clip/Adam, dropout on, inputs resident in HBM.  Returns chars/s, ms per step and the fraction of the bf16 MFMA roof
+    over the whole step (3 F_fwd per character)."""
+    import torch
+    from ocrd_keraslm_amd.lib import hipabi
+    from ocrd_keraslm_amd.lib.engine import HipLM
+    lm = HipLM(depth, width, VOC, n_ctx, device=device)
+    lm.init_weights(seed=seed)
+    lm.prepare(hipabi.KL_PREC_BF16)
+    lm.ensure_training_buffers()
+    T = length
+    per = len(corpus) // B
+    mine = np.stack([corpus[s * per:(s + 1) * per] for s in range(B)])
+    streams = torch.from_numpy(mine).to(device)
+    rng = np.random.default_rng(7)
+    ctx_ids = torch.from_numpy(rng.integers(0, 200, size=(B, n_ctx)).astype(np.int32)).to(device)
+    ctx = ctx_ids[:, None, :].expand(B, T, n_ctx).contiguous()
+    n_windows = (per - 1) // T
+    gen = torch.Generator(device=device)
+    gen.manual_seed(2)
+    lm.reset_states(B)
+
+    def step(w):
+        w = w % n_windows
+        idx = streams[:, w * T:(w + 1) * T].contiguous()
+        tgt = streams[:, w * T + 1:(w + 1) * T + 1].contiguous()
+        keep = torch.rand((depth, B, width), device=device, generator=gen) >= 0.1
+        lm.train_window(idx, ctx, tgt, keep.to(torch.float32) / 0.9)
+        lm.adam_step()
+
+    for w in range(warmup):
+        step(w)
+    lm.read_loss()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(warmup + k)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    lm.read_loss()      # (raises if a persistent scan's hand-off timed out)
+    value = steps * B * T / el
+    out = {"value": value, "unit": "chars/s", "streams": B, "seq_len": T, "steps": steps, "warmup": warmup,
+           "ms_per_step": el / steps * 1e3,
+           "mfma_frac": value * 3 * flops_fwd_per_char(depth, width, VOC, n_ctx) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+    return out, lm
+
+
+def incremental_leg(lm, device, depth, width, n_ctx, N, S, seed=3):
+    """N hypotheses x S chained incremental steps through the state pool (split precision), the first fifth untimed."""
+    import torch
+    lm.ensure_pool(2 * N)
+    r3 = np.random.default_rng(seed)
+    ids = torch.from_numpy(r3.integers(1, VOC, size=(S, N)).astype(np.int32)).to(device)
+    cc = torch.from_numpy(r3.integers(0, 200, size=(N, n_ctx)).astype(np.int32)).to(device)
+    a = torch.arange(N, dtype=torch.int32, device=device)
+    b = a + N
+    lm.pool.zero_()
+    warm = S // 5
+    for s in range(warm):
+        lm.step_slots(ids[s], cc, a, b)
+        a, b = b, a
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t1 = time.perf_counter()
+    e0.record()
+    for s in range(warm, S):
+        lm.step_slots(ids[s], cc, a, b)
+        a, b = b, a
+    e1.record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t1
+    gpu_us = e0.elapsed_time(e1) * 1e3 / (S - warm)
+    # algorithmic HBM bytes per step (SURVEY.md 8d): states read + written, probabilities, indices; the bf16
+    # hi+lo weights of all layers are read once per step (L2/MALL-resident between steps or not)
+    state_bytes = N * (2 * (2 * depth * width * 4) + VOC * 4 + 4 * (1 + n_ctx))
+    weight_bytes = sum(((width + 10 * n_ctx if l == 0 else width) + width) * 4 * width * 2 for l in range(depth)) * 2
+    return {"value": N * (S - warm) / el, "hypotheses": N, "chars": S, "us_per_step": el / (S - warm) * 1e6, "gpu_us_per_step": gpu_us,
+            "algorithmic_bytes_per_step": state_bytes + weight_bytes,
+            "hbm_frac": (state_bytes + weight_bytes) / (gpu_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "mfma_frac": N * flops_fwd_per_char(depth, width, VOC, n_ctx) / (gpu_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,6 +286,7 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-incremental", action="store_true")
+    ap.add_argument("--no-extra-shapes", action="store_true", help="skip the small_batch (cfg2 at 1 and 64 streams) and cfg5 blocks")
     args = ap.parse_args()
 
     import torch
@@ -302,7 +386,7 @@ def main():
         # HBM bytes per launch: NOT measured here (counters need their own rocprofv3 --pmc passes, tools/profile_round.sh);
         # taken from the committed summary of the same command at the same stream count, and labelled as such
         traffic, traffic_source = None, None
-        for tag in ("r02", "r01"):
+        for tag in ("r03", "r02", "r01"):
             fn = os.path.join("profiles", "%s_pmc_hbm_traffic_B%d.json" % (tag, B))
             try:
                 pmc = json.load(open(os.path.join(ROOT, fn)))
@@ -328,36 +412,7 @@ def main():
         lm.prepare(hipabi.KL_PREC_SPLIT)
         legs = {}
         for N, S in ((1024, 512), (128, 512)):
-            lm.ensure_pool(2 * N)
-            r3 = np.random.default_rng(3 + rank)
-            ids = torch.from_numpy(r3.integers(1, VOC, size=(S, N)).astype(np.int32)).to(device)
-            cc = torch.from_numpy(r3.integers(0, 200, size=(N, 1)).astype(np.int32)).to(device)
-            a = torch.arange(N, dtype=torch.int32, device=device)
-            b = a + N
-            lm.pool.zero_()
-            warm = S // 5
-            for s in range(warm):
-                lm.step_slots(ids[s], cc, a, b)
-                a, b = b, a
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t1 = time.perf_counter()
-            e0.record()
-            for s in range(warm, S):
-                lm.step_slots(ids[s], cc, a, b)
-                a, b = b, a
-            e1.record()
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t1
-            gpu_us = e0.elapsed_time(e1) * 1e3 / (S - warm)
-            # algorithmic HBM bytes per step: states read + written, probabilities, indices; the bf16
-            # hi+lo weights of all layers are read once per step (L2/MALL-resident between steps or not)
-            state_bytes = N * (2 * (2 * DEPTH * WIDTH * 4) + VOC * 4 + 4 * (1 + N_CTX))
-            weight_bytes = sum(((WIDTH + 10 * N_CTX if l == 0 else WIDTH) + WIDTH) * 4 * WIDTH * 2 for l in range(DEPTH)) * 2
-            legs[N] = {"value": N * (S - warm) / el, "us_per_step": el / (S - warm) * 1e6, "gpu_us_per_step": gpu_us,
-                       "algorithmic_bytes_per_step": state_bytes + weight_bytes,
-                       "hbm_frac": (state_bytes + weight_bytes) / (gpu_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                       "mfma_frac": N * flops_fwd_per_char() / (gpu_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+            legs[N] = incremental_leg(lm, device, DEPTH, WIDTH, N_CTX, N, S, seed=3 + rank)
         if world > 1:
             t = torch.tensor([legs[1024]["value"], legs[128]["value"]], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -403,6 +458,41 @@ def main():
         rating["precision"] = "split-bf16 (3 MFMA passes)"
         rating["note"] = "stateful window of 256 chars, probabilities copied to the host as Rater.rate needs them (16.8 MB per window at 64 streams); 1 stream = the reference's batching"
 
+    # ---- the other shapes SURVEY.md 8(d) asks for, one GPU each (N = 1 runs only: no collective in them)
+    small_batch = None
+    cfg5 = None
+    if rank == 0 and world == 1 and not args.no_extra_shapes:
+        lm._ws = None                      # (the 3072-stream workspace goes back to the allocator first)
+        lm._ws_key = None
+        torch.cuda.empty_cache()
+        # cfg2 at the reference's own batching (one stateful stream per step, rating.py:90-92) and at 64 streams
+        small_batch = {}
+        for Bs, st in ((1, 200), (64, 100)):
+            try:
+                leg, lms = training_leg(device, DEPTH, WIDTH, LENGTH, N_CTX, Bs, st, 10, corpus[:Bs * (CORPUS // 64)])
+                del lms
+                small_batch["streams_%d" % Bs] = leg
+            except Exception as err:
+                small_batch["streams_%d" % Bs] = {"error": repr(err)}
+        small_batch["note"] = "cfg2 topology, B = 1 is the reference's batching (rating.py:90-92), B = 64 SURVEY.md 8(d)'s second point"
+        torch.cuda.empty_cache()
+        # cfg5: depth 4, width 1024, length 512, two context variables -- training at 512 streams, incremental at 1024 hypotheses
+        try:
+            D5, W5, T5, C5 = 4, 1024, 512, 2
+            leg, lm5 = training_leg(device, D5, W5, T5, C5, 512, 10, 3, corpus)
+            cfg5 = {"training": leg, "workload": "cfg5: depth=4 width=1024 length=512 V=256 2 contexts, stateful training, 512 streams, one GPU"}
+            lm5._ws = None
+            lm5._ws_key = None
+            torch.cuda.empty_cache()
+            lm5.prepare(hipabi.KL_PREC_SPLIT)
+            cfg5["incremental"] = dict(incremental_leg(lm5, device, D5, W5, C5, 1024, 128), unit="hypotheses*chars/s",
+                                       precision="split-bf16 (3 MFMA passes)")
+            cfg5["incremental_n128"] = dict(incremental_leg(lm5, device, D5, W5, C5, 128, 128), unit="hypotheses*chars/s")
+            del lm5
+        except Exception as err:
+            cfg5 = dict(cfg5 or {}, error=repr(err))
+        torch.cuda.empty_cache()
+
     # ---- end to end: Rater.train over synthetic files (rank 0, one GPU): what the Python above the ABI costs
     end_to_end = None
     # (N = 1 only: Rater.train would see the process group and start collectives the other ranks are not in)
@@ -430,9 +520,11 @@ def main():
             "config": {"workload": "cfg2: depth=2 width=512 length=256 V=256 1 context, stateful training, "
                                    "%d streams/GPU, synthetic 10M-char corpus (SURVEY.md 8d)" % B,
                        "streams_per_gpu": B, "global_batch": B * world, "seq_len": T,
-                       "parallelism": "dp%d" % world, "final_ce": ce / max(args.steps, 1)},
+                       "parallelism": "dp%d" % world,
+                       # (a throughput run: the timed steps pass over each stream's windows several times, the loss means nothing)
+                       "corpus_passes": (args.warmup + args.steps) / max(n_windows, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_torch": cpu_torch, "incremental": incremental,
-            "rating_window": rating, "end_to_end": end_to_end,
+            "rating_window": rating, "small_batch": small_batch, "cfg5": cfg5, "end_to_end": end_to_end,
         }
         print(json.dumps(line))
     if world > 1:

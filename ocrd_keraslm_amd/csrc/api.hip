@@ -967,12 +967,19 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
     if (!dzt_ready && !dz_km) KL_TRY(kl_launch_transpose_bf16(w.dZ[l], 4 * W, w.dZT, BTp, BT, 4 * W, s));
     // dU_l = Hprev^T . dZ   (Hprev = H blocks 0..T-1)
     // (dz_km: every product over the layer's dZ rows in as few passes over them as possible -- KlGemmSecond, gemm.hip)
-    const bool pair_uk = dz_km && l > 0 && h->fuse_wg && (W % 128) == 0;
+    // (a pair has twice the column tiles of a single product; where the launcher does not take it -- KL_ERR_SHAPE -- the
+    //  products go out one by one, as km_plan has checked they can)
+    bool pair_uk = dz_km && l > 0 && h->fuse_wg && (W % 128) == 0 && kl_gemm_an_applicable(4 * W, 2 * W, BT, 4 * W);
     if (pair_uk) {
       const bool masked_in = masks != nullptr && (l - 1) > 0;
       const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
-      KL_TRY(kl_launch_gemm_an2(w.dZ[l], (const bf16_t*)w.H[l], grads + h->off_U[l], 4 * W, W, BT, 4 * W, W, 4 * W, 1,
-                                X, grads + h->off_K[l], W, W, 4 * W, 1, s, 1));
+      const int pe = kl_launch_gemm_an2(w.dZ[l], (const bf16_t*)w.H[l], grads + h->off_U[l], 4 * W, W, BT, 4 * W, W, 4 * W, 1,
+                                        X, grads + h->off_K[l], W, W, 4 * W, 1, s, 1);
+      if (pe == KL_ERR_SHAPE) pair_uk = false;
+      else KL_TRY(pe);
+    }
+    if (pair_uk) {
+      // (dU and dK done in one pass)
     } else if (dz_km) {
       KL_TRY(kl_launch_gemm_an(w.dZ[l], (const bf16_t*)w.H[l], grads + h->off_U[l], 4 * W, W, BT, 4 * W, W, 4 * W, 1, s, 1));
     } else if (w.ht_ready) {
@@ -1005,15 +1012,21 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       }
       KL_TRY(kl_zero_async(w.dEKT, (size_t)4 * W * Vp * sizeof(float), s));
       // (the first context variable's one-hot product rides along with the characters': one pass over dZ for both)
-      const bool pair_ctx = dz_km && h->fuse_wg && c.n_ctx >= 1 && (Vp % 128) == 0;
+      bool pair_ctx = dz_km && h->fuse_wg && c.n_ctx >= 1 && (Vp % 128) == 0 &&
+                      kl_gemm_an_applicable(4 * W, Vp + c.ctx_vocab, BT, 4 * W);
       if (pair_ctx) {
         if (kl_launch_onehot_dense(ctx, B, T, c.ctx_vocab, 0, c.n_ctx, w.OHC[0], BTp, s) == KL_ERR_SHAPE) {
           KL_TRY(kl_zero_async(w.OHC[0], (size_t)c.ctx_vocab * BTp * sizeof(bf16_t), s));
           KL_TRY(kl_launch_onehot_t(ctx, B, T, c.ctx_vocab, 0, c.n_ctx, w.OHC[0], BTp, s));
         }
         KL_TRY(kl_zero_async(w.dCtxKT[0], (size_t)4 * W * c.ctx_vocab * sizeof(float), s));
-        KL_TRY(kl_launch_gemm_an2(w.dZ[l], w.OHT, w.dEKT, 4 * W, Vp, BT, 4 * W, BTp, Vp, 0,
-                                  w.OHC[0], w.dCtxKT[0], c.ctx_vocab, BTp, c.ctx_vocab, 0, s, 0));
+        const int pe = kl_launch_gemm_an2(w.dZ[l], w.OHT, w.dEKT, 4 * W, Vp, BT, 4 * W, BTp, Vp, 0,
+                                          w.OHC[0], w.dCtxKT[0], c.ctx_vocab, BTp, c.ctx_vocab, 0, s, 0);
+        if (pe == KL_ERR_SHAPE) pair_ctx = false;      // (nothing was launched: both products follow one by one)
+        else KL_TRY(pe);
+      }
+      if (pair_ctx) {
+        // (characters and first context variable done in one pass)
       } else if (dz_km) KL_TRY(kl_launch_gemm_an(w.dZ[l], w.OHT, w.dEKT, 4 * W, Vp, BT, 4 * W, BTp, Vp, 0, s));
       else KL_TRY(kl_launch_gemm_tn(w.dZT, w.OHT, w.dEKT, nullptr, 4 * W, Vp, BTp, BTp, BTp, Vp, 2, ksplit, 1.f, s));
       KL_TRY(kl_launch_f32_to_bf16_t(w.dEKT, Vp, 4 * W, Vp, w.dEKT_bf, nullptr, Vp, 0, s));

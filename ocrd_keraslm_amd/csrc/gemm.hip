@@ -865,15 +865,28 @@ int kl_launch_gemm_tn(const bf16_t* A, const bf16_t* B, void* C, const float* bi
 // stride ldc.  This is the weight-gradient contraction over the T*B rows taken straight from the backward
 // scan's row-major dZ.  KL_ERR_SHAPE = not applicable (the caller transposes and uses kl_launch_gemm_tn).
 // shapes kl_launch_gemm_an serves (N, ldb: any the tn kernel takes)
-bool kl_gemm_an_applicable(int M, int N, int K, long lda_km) {
-  if (M <= 0 || N <= 0 || K <= 0 || (M % LBM) || (K % BK) || (lda_km & 7)) return false;
-  const int tiles = (M / LBM) * ((N + LBN - 1) / LBN);
-  int sp = (256 + tiles - 1) / tiles;
+// K split of the K-major products: about one workgroup per CU, at least 16 k-steps per workgroup, and -- the kernels
+// address one split with 32-bit byte offsets -- more splits where a split's rows would not fit in 2 GiB (the paired
+// launches have twice the column tiles, so half the splits and twice the rows per split: depth 4 / width 1024 /
+// T*B = 262144 fits as a single product and did not as a pair).  Returns the rows per split, 0 = not applicable.
+static int an_rows_per_split(int M, int n_all, int K, long ld_max) {
+  if (M <= 0 || n_all <= 0 || K <= 0 || (M % LBM) || (K % BK)) return 0;
+  const int tiles = (M / LBM) * ((n_all + LBN - 1) / LBN);
+  int sp = (256 + tiles - 1) / tiles;          // ~ one workgroup per CU
   const int nk = K / BK;
-  if (sp > nk / 16) sp = nk / 16;
+  if (sp > nk / 16) sp = nk / 16;              // at least 16 k-steps per workgroup
   if (sp < 1) sp = 1;
-  const int kps = ((nk + sp - 1) / sp) * BK;
-  return (long)kps * lda_km * 2 < 0x7fffffffL;
+  int kps = ((nk + sp - 1) / sp) * BK;
+  while ((long)kps * ld_max * 2 >= 0x7fffffffL && kps > BK) {      // 32-bit offsets inside one split
+    ++sp;
+    kps = ((nk + sp - 1) / sp) * BK;
+  }
+  return (long)kps * ld_max * 2 < 0x7fffffffL ? kps : 0;
+}
+
+bool kl_gemm_an_applicable(int M, int N, int K, long lda_km) {
+  if (lda_km & 7) return false;
+  return an_rows_per_split(M, N, K, lda_km) > 0;
 }
 
 int kl_launch_gemm_an2(const bf16_t* A_km, const bf16_t* B, float* C, int M, int N, int K, long lda_km, long ldb, long ldc,
@@ -882,16 +895,13 @@ int kl_launch_gemm_an2(const bf16_t* A_km, const bf16_t* B, float* C, int M, int
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if (B2 != nullptr && ((N % LBN) || N2 <= 0 || (ldb2 & 7) || (!b_km && ldb2 >= (1L << 22)))) return KL_ERR_SHAPE;
   const int n_all = B2 != nullptr ? N + N2 : N;
-  if (!kl_gemm_an_applicable(M, n_all, K, lda_km) || (ldb & 7) || (!b_km && ldb >= (1L << 22))) return KL_ERR_SHAPE;
-  const int tiles = (M / LBM) * ((n_all + LBN - 1) / LBN);
-  int sp = (256 + tiles - 1) / tiles;          // ~ one workgroup per CU
-  const int nk = K / BK;
-  if (sp > nk / 16) sp = nk / 16;              // at least 16 k-steps per workgroup
-  if (sp < 1) sp = 1;
-  const int kps = ((nk + sp - 1) / sp) * BK;
-  sp = (K + kps - 1) / kps;
-  if ((long)kps * lda_km * 2 >= 0x7fffffffL) return KL_ERR_SHAPE;     // 32-bit offsets inside one split
-  if (b_km && ((long)kps * ldb * 2 >= 0x7fffffffL || (B2 != nullptr && (long)kps * ldb2 * 2 >= 0x7fffffffL))) return KL_ERR_SHAPE;
+  if ((lda_km & 7) || (ldb & 7) || (!b_km && ldb >= (1L << 22))) return KL_ERR_SHAPE;
+  long ld_max = lda_km;
+  if (b_km && ldb > ld_max) ld_max = ldb;
+  if (b_km && B2 != nullptr && ldb2 > ld_max) ld_max = ldb2;
+  const int kps = an_rows_per_split(M, n_all, K, ld_max);
+  if (kps <= 0) return KL_ERR_SHAPE;
+  const int sp = (K + kps - 1) / kps;
   dim3 grid((n_all + LBN - 1) / LBN, M / LBM, sp);
   KlGateEpi epi;
   memset(&epi, 0, sizeof(epi));

@@ -22,7 +22,7 @@ def all_regs(line):
     return out
 
 
-def audit(path):
+def audit(path, min_checked=40):
     lines = open(path).read().split("\n")
     bad = 0
     kernel = None
@@ -43,7 +43,7 @@ def audit(path):
             continue
         if not s or s.startswith(";") or s.startswith("."):
             continue
-        if in_asm and s.startswith("global_load_dword") and " lds" not in s:
+        if in_asm and re.match(r"(global|buffer)_load_", s) and " lds" not in s:      # (dword*, ushort, ubyte ...: every register form)
             dst = s.split()[1].rstrip(",")
             for r in regs_of(dst):
                 pending[r] = i + 1
@@ -66,6 +66,10 @@ def audit(path):
             for r in hit:
                 pending.pop(r, None)
     print(f"{checked} asm register loads checked, {bad} premature uses")
+    if checked < min_checked:
+        # (the audit must not pass vacuously when the mnemonics or the build change)
+        print(f"audit: expected at least {min_checked} hand-issued register loads, found {checked}")
+        return bad + 1
     return bad
 
 

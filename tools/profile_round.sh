@@ -10,10 +10,10 @@ OUT=gpurun_out
 mkdir -p $OUT
 timeout -k 10 700 python bench.py --streams $B > $OUT/${TAG}_bench_B${B}.json 2> $OUT/${TAG}_bench.err
 tail -c 1500 $OUT/${TAG}_bench_B${B}.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 bench.py --streams $B --steps 10 --warmup 3 --no-cpu-baseline --no-incremental --no-end-to-end > $OUT/${TAG}_bench_B${B}_under_rocprof.json 2> $OUT/${TAG}_rp.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 bench.py --streams $B --steps 10 --warmup 3 --no-cpu-baseline --no-incremental --no-end-to-end --no-extra-shapes > $OUT/${TAG}_bench_B${B}_under_rocprof.json 2> $OUT/${TAG}_rp.err
 cp $OUT/${TAG}_stats/*/*_kernel_stats.csv $OUT/${TAG}_bench_B${B}_kernel_stats.csv
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 bench.py --streams $B --steps 3 --warmup 1 --no-cpu-baseline --no-incremental --no-end-to-end > $OUT/${TAG}_pmc_f.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -- python3 bench.py --streams $B --steps 3 --warmup 1 --no-cpu-baseline --no-incremental --no-end-to-end > $OUT/${TAG}_pmc_w.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 bench.py --streams $B --steps 3 --warmup 1 --no-cpu-baseline --no-incremental --no-end-to-end --no-extra-shapes > $OUT/${TAG}_pmc_f.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -- python3 bench.py --streams $B --steps 3 --warmup 1 --no-cpu-baseline --no-incremental --no-end-to-end --no-extra-shapes > $OUT/${TAG}_pmc_w.log 2>&1
 python tools/pmc_summary.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_hbm_traffic_B${B}.json "cfg2 B=$B T=256"
 head -8 $OUT/${TAG}_bench_B${B}_kernel_stats.csv | cut -c1-160
 # the incremental step (cfg3 and the reference's 128-hypothesis cap): per-kernel times

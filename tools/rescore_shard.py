@@ -90,20 +90,32 @@ def main():
         return worker(args)
     procs = []
     t0 = time.perf_counter()
-    for g in range(args.gpus):
-        env = dict(os.environ, HIP_VISIBLE_DEVICES=str(g), CUDA_VISIBLE_DEVICES=str(g))
-        if os.environ.get("KL_RESCORE_SAME_GPU") == "1":        # rehearsal of N workers on a one-GPU box
-            env["HIP_VISIBLE_DEVICES"] = env["CUDA_VISIBLE_DEVICES"] = "0"
-        cmd = [sys.executable, os.path.abspath(__file__), "--model", args.model, "--gpus", str(args.gpus), "--mode", args.mode,
-               "--out", args.out, "--worker", str(g)] + args.data
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True))
+    same_gpu = os.environ.get("KL_RESCORE_SAME_GPU") == "1"       # rehearsal of N workers on a one-GPU box
     reports, failed = [], 0
-    for p in procs:
+
+    def collect(p):
+        nonlocal failed
         out, _ = p.communicate()
         if p.returncode != 0:
             failed += 1
-            continue
-        reports.append(json.loads(out.strip().splitlines()[-1]))
+        else:
+            reports.append(json.loads(out.strip().splitlines()[-1]))
+
+    for g in range(args.gpus):
+        env = dict(os.environ, HIP_VISIBLE_DEVICES=str(g), CUDA_VISIBLE_DEVICES=str(g))
+        if same_gpu:
+            env["HIP_VISIBLE_DEVICES"] = env["CUDA_VISIBLE_DEVICES"] = "0"
+        cmd = [sys.executable, os.path.abspath(__file__), "--model", args.model, "--gpus", str(args.gpus), "--mode", args.mode,
+               "--out", args.out, "--worker", str(g)] + args.data
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        if same_gpu:
+            # one after the other: the persistent scans assume the GPU to themselves (co-resident workgroups), two
+            # processes launching them at once on ONE card break the hand-offs (see tests/ddp_hip_worker.py)
+            collect(p)
+        else:
+            procs.append(p)
+    for p in procs:
+        collect(p)
     el = time.perf_counter() - t0
     chars = sum(r["chars"] for r in reports)
     print(json.dumps({"gpus": args.gpus, "documents": sum(r["documents"] for r in reports), "chars": chars,
