@@ -487,7 +487,7 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
         a.bias = P + h->off_b[0];
       }
       a.H = (bf16_t*)w.H[l]; a.C = w.C[l]; a.G = w.G[l];
-      a.Cb = (v2 && w.scan2_bwd && h->scan2_bf16) ? w.Cb[l] : nullptr;
+      a.Cb = (v2 && w.scan2_bwd) ? w.Cb[l] : nullptr;      // (the backward scan reads every cell state as bf16, blocks 0..T)
       a.Hd = masked ? w.Hd[l] : nullptr;
       a.mask = masked ? masks + (size_t)l * BW : nullptr;
       a.HT = w.km_plan ? nullptr : w.HTf[l]; a.ldt = (long)(T + 1) * B;       // (K-major GEMMs: no transposed outputs)
@@ -1084,7 +1084,11 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       a.mask[0] = (masks != nullptr && l > 0) ? masks + (size_t)l * BW : nullptr;
       a.dH = w.dH;
       a.dHb = reinterpret_cast<const bf16_t*>(w.dH);
-      a.Cb = (w.scan2_bwd && h->scan2_bf16) ? w.Cb[l] : nullptr;
+      a.Cb = w.scan2_bwd ? w.Cb[l] : nullptr;
+      if (w.scan2_bwd) {      // the running dc of every cell between two steps lives in memory (lstm_scan_bwd_wide2_kernel): starts at zero
+        a.dc_state = w.dc0[l];
+        KL_TRY(kl_zero_async(w.dc0[l], (size_t)B * W * sizeof(float), s));
+      }
       a.counters = w.scan_cnt;
       a.status = w.scan_status + 1;
       // (sentinels pay with several row blocks per workgroup, where the next tile is prefetched; with one

@@ -185,6 +185,7 @@ struct KlScanBwd {
   const bf16_t* dHb;                   // second generation: the gradient from above as bf16 [T*B][W] (dH unused)
   const bf16_t* Cb;                    // second generation: cell states as bf16 [(T+1)B][W], blocks 1..T (null: C, f32)
   unsigned* flags; const unsigned* epoch;   // second generation: hand-off by flags [n_rb][64] instead of sentinels (null: sentinels); *epoch: this launch's
+  float* dc_state;                     // second generation: the running dc of every cell between two steps, [B][W] f32, ZEROED in front of the launch
 };
 int kl_launch_scan_epoch(unsigned* flags, int n_flags, unsigned* epoch, unsigned step, hipStream_t stream);   // epoch += step in front of a flag-mode scan
 int kl_launch_scan_bwd(KlScanBwd args, hipStream_t stream);

@@ -237,6 +237,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide2_kernel(const KlSc
     for (int s = 0; s < NB; ++s) {
       const long row = (long)(rg + p * n_rg) * ROWS + s * 16 + crow;
       cst[p][s] = a.C[row * W + u0 + cunit];
+      if (a.Cb) a.Cb[row * W + u0 + cunit] = f2bf(cst[p][s]);      // (block 0: the backward scan reads every c_{t-1} as bf16)
     }
   const long BW = (long)B * W;
   const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(a.H, (long)(T + 1) * BW * 2);
@@ -1020,8 +1021,47 @@ __global__ __launch_bounds__(1024, 1) void logits_ce_ws_kernel(const KlLogitsCe 
 }
 
 // ---------------------------------------------------------------- backward
-// LDS map (bytes): tile [2][4*KSTEPS][1024] | zt [16 waves][16][17] f32 | pub [4 gates][16 rows][64 units] bf16 | flags | hand-off words [64]
-constexpr int bwd2_lds_bytes(int ksteps) { return 2 * 4 * ksteps * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16 + 256; }
+// Epilogue inputs of the backward scan, a whole block ahead: they land in the ACCUMULATOR registers a0..a5.  These kernels
+// are built with 8 accumulator registers (function attribute "amdgpu-agpr-alloc"="8,8", set on the device IR by
+// tools/build_scan2.sh: HIP has no spelling for it, and without it the compiler halves the register budget as soon as an
+// AGPR is named).  The six are register variables of the kernel (`register unsigned x asm("a0")`) and every statement
+// that touches them takes them as operands, so the compiler sees them live from the request to the read-out a block later,
+// keeps its own temporaries (the MFMA accumulator included) out of them and never copies them: a load can stay in flight
+// around the loop's back-edge, which a compiler-chosen VGPR destination cannot (it was copied at the loop head before its
+// data had landed).  tools/audit_async_regs.py checks on the generated ISA that no compiler
+// instruction names a0..a5.
+//   a[0:1] the four gates of this thread's cell (bf16)     a2 c_{t-1} (low half) | dH (high half), two 16-bit loads
+//   a3 c_t (low half)     a4 the running dc of this cell, kept in a [B][W] f32 array between the steps     a5 dropout mask
+// With the per-block state (dc, c_t) in memory instead of 2 x NP registers, and the bias gradient summed by LDS atomics
+// instead of four accumulators, the kernel fits its 120 VGPRs at every NP without scratch.
+// Armed with all-ones before the request (no bf16 datum is 0xFFFF, no f32 datum here is that NaN pattern), checked after the wait.
+#define KL_BWD_INPUTS_DECL                                                                                                         \
+  register unsigned la0_ asm("a0"), la1_ asm("a1"), la2_ asm("a2"), la3_ asm("a3"), la4_ asm("a4"), la5_ asm("a5")
+// (s_nop: the scalar ALU may have written a base a cycle ago, and nothing pads inside or in front of an asm statement)
+#define KL_BWD_INPUTS_REQUEST(g_base, g_off, c_base, c1_base, dh_base, h_off, dc_base, m_base, m_off)                               \
+  do {                                                                                                                             \
+    asm volatile("v_accvgpr_write_b32 a0, -1\n\tv_accvgpr_write_b32 a1, -1\n\tv_accvgpr_write_b32 a2, -1\n\t"                       \
+                 "v_accvgpr_write_b32 a3, -1\n\tv_accvgpr_write_b32 a4, -1\n\tv_accvgpr_write_b32 a5, -1\n\ts_nop 4\n\t"            \
+                 "global_load_dwordx2 a[0:1], %6, %7"                                                                              \
+                 : "=a"(la0_), "=a"(la1_), "=a"(la2_), "=a"(la3_), "=a"(la4_), "=a"(la5_) : "v"(g_off), "s"(g_base) : "memory");   \
+    asm volatile("s_nop 4\n\tglobal_load_short_d16 a2, %1, %2" : "+a"(la2_) : "v"(h_off), "s"(c_base) : "memory");                  \
+    asm volatile("s_nop 4\n\tglobal_load_short_d16_hi a2, %1, %2" : "+a"(la2_) : "v"(h_off), "s"(dh_base) : "memory");              \
+    asm volatile("s_nop 4\n\tglobal_load_short_d16 a3, %1, %2" : "+a"(la3_) : "v"(h_off), "s"(c1_base) : "memory");                 \
+    asm volatile("s_nop 4\n\tglobal_load_dword a4, %1, %2 sc1" : "+a"(la4_) : "v"(m_off), "s"(dc_base) : "memory");                 \
+    asm volatile("s_nop 4\n\tglobal_load_dword a5, %1, %2" : "+a"(la5_) : "v"(m_off), "s"(m_base) : "memory");                      \
+  } while (0)
+#define KL_BWD_INPUTS_READ(g0, g1, cd, c1, dc, mk)                                                                                 \
+  asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\t"                            \
+               "v_accvgpr_read_b32 %3, a3\n\tv_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5"                               \
+               : "=v"(g0), "=v"(g1), "=v"(cd), "=v"(c1), "=v"(dc), "=v"(mk)                                                        \
+               : "a"(la0_), "a"(la1_), "a"(la2_), "a"(la3_), "a"(la4_), "a"(la5_) : "memory")
+__device__ __forceinline__ bool bwd_inputs_missing(unsigned g0, unsigned g1, unsigned cd, unsigned c1, unsigned dc, unsigned mk) {
+  return max(max(g0, g1), max(dc, mk)) == 0xFFFFFFFFu || (cd & 0xFFFFu) == 0xFFFFu || (cd >> 16) == 0xFFFFu || (c1 & 0xFFFFu) == 0xFFFFu;
+}
+
+// LDS map (bytes): tile [2][4*KSTEPS][1024] | zt [16 waves][16][17] f32 | pub [4 gates][16 rows][64 units] bf16 | flags | hand-off words [64] |
+// bias-gradient sums [4 gates][64 units] f32
+constexpr int bwd2_lds_bytes(int ksteps) { return 2 * 4 * ksteps * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16 + 256 + 4 * 64 * 4; }
 
 // One layer, 16-row blocks, NP blocks per workgroup and step (2..4).  Wave = (K quarter = gate kq4, unit group ug):
 // dh_rec[16 x 16] = dZ[t+1][16 x W(gate kq4)] . Un[W(gate kq4) x 16 units]; the four gate partials meet in LDS.
@@ -1066,18 +1106,16 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
   const bf16_t* Cb = a.Cb;
   const float* maskl = a.mask[0];
   unsigned* status = a.status;
-  // per block of this workgroup (slot 0 = the current one: rotated): running dc, the cell state c_t of the step
-  // being processed (the c_{t-1} loaded for step t is the c_t of step t-1), the dropout mask on dH
-  float dcr[NP], ccur[NP];
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    const long row = (long)(rg + p * n_rg) * 16 + er;
-    dcr[p] = 0.f;
-    ccur[p] = Cl[(long)T * BW + row * W + u0 + eu];
-  }
-  float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+  // Per-cell state between the steps lives in memory, not in 2 x NP registers: the running dc in a.dc_state [B][W] f32
+  // (zeroed in front of the launch; read back NP blocks after it was written, by the thread that wrote it), c_t from the
+  // bf16 cell states the forward scan left (block t + 1).  The bias gradient is summed by LDS atomics (db_l).
+  float* const db_l = reinterpret_cast<float*>(smem + 2 * NPIECE * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16 + 256);
+  if (tid < 256) db_l[tid] = 0.f;
+  float* const dcs = a.dc_state;
+  (void)Cl;
   const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(dZl, (long)T * BW * 4 * 2);
   const __amdgpu_buffer_rsrc_t rs_null = make_rsrc(dZl, 0);
+  const __amdgpu_buffer_rsrc_t rs_dc = make_rsrc(dcs, (long)B * W * 4);
   // Hand-off by flags (a.flags; NP >= 3): each publishing wave posts "my rows of step t are in memory" as the number
   // epoch - t in its own word, flags[row block][column group * 8 + wave], once its stores have completed -- which it
   // learns for free half a block later, where it waits for its epilogue inputs anyway.  A consumer looks at the 64
@@ -1091,8 +1129,6 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
   if (tid == 0) ok_flag = 1;
 #pragma unroll
   for (int j = 0; j < KSTEPS; ++j) asm volatile("" : "+v"(bu[j]));
-#pragma unroll
-  for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(ccur[p]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   bool local = false;      // XCD-local hand-off (opt-in), as in the forward scan
@@ -1126,6 +1162,21 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
   // the top of the block they belong to and consumed behind its MFMA phase.  They are NOT carried around the loop:
   // a loop-carried asm destination was copied by the compiler at the loop head before its data had landed.
   const unsigned in_lane4 = (unsigned)((u0 + eu) * 4);
+  KL_BWD_INPUTS_DECL;
+  // (of the block (t_, r0_): this thread's row er, unit u0 + eu; a macro because a register variable cannot be captured.
+  //  Without a dropout mask the sixth load reads the thread's own dc word again and the value is ignored: every statement
+  //  runs on every path, so the landing registers have ONE definition per block and the compiler has nothing to merge.)
+#define KL_REQUEST_INPUTS(t_, r0_)                                                                                                  \
+  do {                                                                                                                             \
+    const long trow_ = (long)(t_) * B + (r0_) + er;                                                                                \
+    const float* dcrow_ = dcs + (long)((r0_) + er) * W;                                                                            \
+    const float* mrow_ = maskl ? maskl + (long)((r0_) + er) * W : dcrow_;                                                          \
+    KL_BWD_INPUTS_REQUEST(Gl + trow_ * W * 4, in_lane4 * 2, Cb + trow_ * W, Cb + (trow_ + B) * W, dHb + trow_ * W, in_lane4 >> 1,  \
+                          dcrow_, mrow_, in_lane4);                                                                                \
+    vq += 6;                                                                                                                       \
+    seq_in = vq;                                                                                                                   \
+  } while (0)
+  KL_REQUEST_INPUTS(T - 1, rg * 16);
   int n = 0;
   for (int t = T - 1; t >= 0; --t) {
 #pragma unroll 1
@@ -1138,26 +1189,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
       if (ip2 >= NP) { ip2 = 0; t2 = t1 - 1; }
       const int r1 = (rg + ip1 * n_rg) * 16, r2 = (rg + ip2 * n_rg) * 16;
       SSTAMP(16);
-      // Epilogue inputs of this block (gates 8 bytes, c_{t-1} and dh as bf16 or f32, the dropout mask on dH): asm loads of THIS
-      // iteration into compiler registers armed with all-ones (which no valid datum is: a 16-bit load zero-extends),
-      // consumed behind the MFMA phase.  They are not carried around the loop -- a loop-carried asm destination was copied
-      // by the compiler at the loop head before its data had landed -- and not kept in registers "reserved" from the
-      // compiler either: hipcc honoured neither amdgpu_num_vgpr nor asm clobbers once a variant needed the registers.
-      u32x2 gin = u32x2{0xFFFFFFFFu, 0xFFFFFFFFu};
-      unsigned cpin = 0xFFFFFFFFu, dhin = 0xFFFFFFFFu, mkin = maskl ? 0xFFFFFFFFu : 0x3f800000u;      // (no mask: 1.0f)
-      {
-        const long trow = (long)t * B + r0 + er;
-        aload8_glb(gin, Gl + trow * W * 4, in_lane4 * 2);
-        if (Cb && t > 0) aload2_glb(cpin, Cb + trow * W, in_lane4 >> 1);
-        else aload4_glb(cpin, Cl + trow * W, in_lane4);
-        aload2_glb(dhin, dHb + trow * W, in_lane4 >> 1);
-        vq += 3;
-        if (maskl) {
-          aload4_glb(mkin, maskl + (long)(r0 + er) * W, in_lane4);
-          ++vq;
-        }
-        seq_in = vq;
-      }
+      // (the epilogue inputs of this block were requested a block ago, into a4..a7: bwd_inputs_request)
       // (flags: the 64 words of the next block's rows come into LDS -- armed with 0 = "not yet" -- and are looked at behind
       //  the MFMAs; the last wave fetches them, it publishes nothing)
       // (a.pf_mode 2: the tile of the block after next is asked for -- into the buffer this block's MFMAs leave --, a block and
@@ -1281,36 +1313,44 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
       // ---- epilogue: thread = (row er, unit eu)
       // (loads and stores retire independently, so the count is an estimate: the armed registers are checked)
       wait_vm(vq - seq_in);
-      use_regs(gin);
-      use_regs(cpin);
-      use_regs(dhin);
-      use_regs(mkin);
-      if (__any(max(max(gin.x, gin.y), max(cpin, max(dhin, mkin))) == 0xFFFFFFFFu)) {
+      unsigned gin0, gin1, cdin, c1in, dcin, mkin;
+      KL_BWD_INPUTS_READ(gin0, gin1, cdin, c1in, dcin, mkin);
+      if (__any(bwd_inputs_missing(gin0, gin1, cdin, c1in, dcin, mkin))) {
 #ifdef KL_STAMP
         if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[29] += 1;
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        use_regs(gin);
-        use_regs(cpin);
-        use_regs(dhin);
-        use_regs(mkin);
+        KL_BWD_INPUTS_READ(gin0, gin1, cdin, c1in, dcin, mkin);
+        if (__any(bwd_inputs_missing(gin0, gin1, cdin, c1in, dcin, mkin))) {      // (nothing in flight any more: the data itself is bad)
+          __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok_flag = 0;
+        }
       }
-      const float gi = bf2f((bf16_t)(gin.x & 0xffffu)), gf = bf2f((bf16_t)(gin.x >> 16));
-      const float gg = bf2f((bf16_t)(gin.y & 0xffffu)), go = bf2f((bf16_t)(gin.y >> 16));
-      const float cp = (Cb && t > 0) ? u2f(cpin << 16) : u2f(cpin);
-      float dh = u2f(dhin << 16);
+      // ... and the next block's go out at once: a whole block of latency cover
+      if (t1 >= 0) KL_REQUEST_INPUTS(t1, r1);
+      const float gi = bf2f((bf16_t)(gin0 & 0xffffu)), gf = bf2f((bf16_t)(gin0 >> 16));
+      const float gg = bf2f((bf16_t)(gin1 & 0xffffu)), go = bf2f((bf16_t)(gin1 >> 16));
+      const float cp = u2f(cdin << 16);
+      float dh = u2f(cdin & 0xffff0000u);
+      const float ct = u2f(c1in << 16), dc_run = u2f(dcin);
+      const float mk = maskl ? u2f(mkin) : 1.f;
       SSTAMP(21);
       const int wz = (eu >> 4) * 4;      // the four K-quarter waves of this unit group
-      dh = dh * u2f(mkin) + (zt[wz][er][eu & 15] + zt[wz + 1][er][eu & 15] + zt[wz + 2][er][eu & 15] + zt[wz + 3][er][eu & 15]);
-      const float tc = fast_tanh(ccur[0]);
-      const float dc = dh * go * (1.f - tc * tc) + dcr[0];
-      dcr[0] = dc * gf;
-      ccur[0] = cp;
+      dh = dh * mk + (zt[wz][er][eu & 15] + zt[wz + 1][er][eu & 15] + zt[wz + 2][er][eu & 15] + zt[wz + 3][er][eu & 15]);
+      const float tc = fast_tanh(ct);
+      const float dc = dh * go * (1.f - tc * tc) + dc_run;
+      // the running dc of this cell for the step before: read back a whole step (NP blocks) from now
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dc * gf), alive ? rs_dc : rs_null, (int)(in_lane4 + (unsigned)(er * W * 4)),
+                                            (int)(unsigned)(r0 * W * 4), 0);
+      ++vq;
       const float d_o = dh * tc, d_i = dc * gg, d_g = dc * gi, d_f = dc * cp;
       const unsigned z0 = f2bf(d_i * gi * (1.f - gi)), z1 = f2bf(d_f * gf * (1.f - gf));
       const unsigned z2 = f2bf(d_g * (1.f - gg * gg)), z3 = f2bf(d_o * go * (1.f - go));
-      if (alive) {
-        dbacc[0] += bf2f((bf16_t)z0); dbacc[1] += bf2f((bf16_t)z1); dbacc[2] += bf2f((bf16_t)z2); dbacc[3] += bf2f((bf16_t)z3);
+      if (alive) {      // (one address per lane: no conflict inside the instruction; the sixteen rows meet in the LDS adder)
+        __hip_atomic_fetch_add(db_l + 0 * 64 + eu, bf2f((bf16_t)z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(db_l + 1 * 64 + eu, bf2f((bf16_t)z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(db_l + 2 * 64 + eu, bf2f((bf16_t)z2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(db_l + 3 * 64 + eu, bf2f((bf16_t)z3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       pub[(0 * 16 + er) * 64 + eu] = (bf16_t)z0;
       pub[(1 * 16 + er) * 64 + eu] = (bf16_t)z1;
@@ -1342,30 +1382,13 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
         vq += 2;
       }
       SSTAMP(24);
-      if (NP > 1) {
-        const float d0 = dcr[0], c0 = ccur[0];
-#pragma unroll
-        for (int p = 0; p + 1 < NP; ++p) { dcr[p] = dcr[p + 1]; ccur[p] = ccur[p + 1]; }
-        dcr[NP - 1] = d0;
-        ccur[NP - 1] = c0;
-      }
     }
   }
   SSTAMP_FLUSH();
-  // db[g*W + u] += sum over this workgroup's rows and all steps (16 partials per column meet in LDS)
+  // db[g*W + u] += sum over this workgroup's rows and all steps
   if (a.db) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);     // [4 gates][16 rows][64 units]
-#pragma unroll
-    for (int g = 0; g < 4; ++g) red[(g * 16 + er) * 64 + eu] = dbacc[g];
-    __syncthreads();
-    if (tid < 256) {
-      const int g = tid >> 6, u = tid & 63;
-      float sum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sum += red[(g * 16 + r) * 64 + u];
-      atomicAdd(a.db + (long)g * W + u0 + u, sum);
-    }
+    if (tid < 256) atomicAdd(a.db + (long)(tid >> 6) * W + u0 + (tid & 63), db_l[tid]);
   }
 }
 
@@ -1564,6 +1587,7 @@ int kl_launch_scan_bwd_wide2(KlScanBwd a, hipStream_t stream) {
   const int W = a.W;
   const int np = kl_scan_wide2_phases(a.B, a.T, W, 16, 6);
   if (!np || a.L != 1 || a.dZT || a.T < 3) return KL_ERR_SHAPE;
+  if (!a.Cb || !a.dc_state || !a.dHb) return KL_ERR_ARG;      // (bf16 cell states incl. block 0, the dc array, bf16 gradient from above)
   if (a.flags ? (np < 3 || !a.epoch) : a.sentinel != 2) return KL_ERR_SHAPE;      // (flags: see the kernel; two blocks per step leave them no time)
   a.n_rb = a.B / 16;
   a.n_rg = a.n_rb / np;

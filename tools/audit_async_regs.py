@@ -22,7 +22,7 @@ def all_regs(line):
     return out
 
 
-def audit(path, min_checked=40):
+def audit(path, min_checked=20):
     lines = open(path).read().split("\n")
     bad = 0
     kernel = None
@@ -73,9 +73,57 @@ def audit(path, min_checked=40):
     return bad
 
 
+def audit_agprs(path, kernel_substr="bwd_wide2", min_kernels=10):
+    """The backward scan's epilogue inputs land in accumulator registers while the compiler's code runs (lstm_scan2.hip,
+    KL_BWD_INPUTS_*): NO compiler-generated instruction of those kernels may name an AGPR -- not as an MFMA accumulator,
+    not as a spill slot, not as a copy of one of the pinned register variables -- and every one of them must have been
+    built with the 8 accumulator registers the hand-written statements use (a0..a5)."""
+    text = open(path).read()
+    lines = text.split("\n")
+    kernel = None
+    in_asm = False
+    bad = checked = 0
+    seen = set()
+    for i, ln in enumerate(lines):
+        s = ln.strip()
+        m = re.match(r"^(_Z\w+):", s)
+        if m:
+            kernel = m.group(1)
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if s.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not kernel or kernel_substr not in kernel or not s or s[0] in ";.":
+            continue
+        seen.add(kernel)
+        if in_asm:
+            continue
+        checked += 1
+        if re.search(r"\ba\d+\b|\ba\[\d+:\d+\]", s):
+            bad += 1
+            print(f"{kernel}: line {i + 1} names an accumulator register outside the hand-written statements: {s}")
+    # (kernel descriptors: VGPRs up to the accumulator offset + the accumulator registers must fit the 128 registers a wave of
+    #  a 1024-thread workgroup gets -- a build without the "amdgpu-agpr-alloc" attribute shows up here, or as a 64 / 64 split)
+    for kname, body in re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, flags=re.S):
+        if kernel_substr not in kname:
+            continue
+        nfree = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        acc = int(re.search(r"\.amdhsa_accum_offset (\d+)", body).group(1))
+        if nfree > 128 or nfree - acc < 6 or acc < 100:
+            bad += 1
+            print(f"{kname}: next_free_vgpr {nfree}, accum_offset {acc}: expected <= 128 registers with >= 6 accumulator registers behind >= 100 VGPRs")
+    print(f"{checked} compiler instructions of {len(seen)} *{kernel_substr}* kernels checked, {bad} problems with accumulator registers")
+    if len(seen) < min_kernels:
+        print(f"audit: expected at least {min_kernels} *{kernel_substr}* kernels, found {len(seen)}")
+        bad += 1
+    return bad
+
+
 def audit_reserved(path, kernel_substr="bwd_wide2", reserved=range(124, 128)):
-    """The backward scan keeps v124..v127 for loads that land while the compiler's code runs: no compiler-generated
-    instruction of those kernels may name them."""
+    """(historic) registers kept from the compiler by convention: no compiler-generated instruction of those kernels
+    may name them."""
     lines = open(path).read().split("\n")
     kernel = None
     in_asm = False
@@ -104,4 +152,4 @@ def audit_reserved(path, kernel_substr="bwd_wide2", reserved=range(124, 128)):
 
 
 if __name__ == "__main__":
-    sys.exit(1 if audit(sys.argv[1]) else 0)
+    sys.exit(1 if (audit(sys.argv[1]) + audit_agprs(sys.argv[1])) else 0)
