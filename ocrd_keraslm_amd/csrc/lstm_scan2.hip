@@ -1021,42 +1021,44 @@ __global__ __launch_bounds__(1024, 1) void logits_ce_ws_kernel(const KlLogitsCe 
 }
 
 // ---------------------------------------------------------------- backward
-// Epilogue inputs of the backward scan, a whole block ahead: they land in the ACCUMULATOR registers a0..a5.  These kernels
+// Epilogue inputs of the backward scan, a whole block ahead: they land in the ACCUMULATOR registers a0..a6.  These kernels
 // are built with 8 accumulator registers (function attribute "amdgpu-agpr-alloc"="8,8", set on the device IR by
 // tools/build_scan2.sh: HIP has no spelling for it, and without it the compiler halves the register budget as soon as an
 // AGPR is named).  The six are register variables of the kernel (`register unsigned x asm("a0")`) and every statement
 // that touches them takes them as operands, so the compiler sees them live from the request to the read-out a block later,
-// keeps its own temporaries (the MFMA accumulator included) out of them and never copies them: a load can stay in flight
+// keeps its own temporaries out of them and never copies them (with -amdgpu-mfma-vgpr-form the MFMA accumulator stays in VGPRs): a load can stay in flight
 // around the loop's back-edge, which a compiler-chosen VGPR destination cannot (it was copied at the loop head before its
 // data had landed).  tools/audit_async_regs.py checks on the generated ISA that no compiler
-// instruction names a0..a5.
-//   a[0:1] the four gates of this thread's cell (bf16)     a2 c_{t-1} (low half) | dH (high half), two 16-bit loads
-//   a3 c_t (low half)     a4 the running dc of this cell, kept in a [B][W] f32 array between the steps     a5 dropout mask
+// instruction names an accumulator register.
+//   a[0:1] the four gates of this thread's cell (bf16)     a2 c_{t-1}, a3 c_t, a6 dH: zero-extended 16-bit loads, one register each
+//   (NOT two halves of one register by d16 loads: with SRAM ECC on -- gfx950's default -- a d16 load rewrites the whole register)
+//   a4 the running dc of this cell, kept in a [B][W] f32 array between the steps     a5 dropout mask
 // With the per-block state (dc, c_t) in memory instead of 2 x NP registers, and the bias gradient summed by LDS atomics
 // instead of four accumulators, the kernel fits its 120 VGPRs at every NP without scratch.
-// Armed with all-ones before the request (no bf16 datum is 0xFFFF, no f32 datum here is that NaN pattern), checked after the wait.
+// Armed with all-ones before the request (no zero-extended halfword, no f32 datum here is that pattern), checked after the wait.
 #define KL_BWD_INPUTS_DECL                                                                                                         \
-  register unsigned la0_ asm("a0"), la1_ asm("a1"), la2_ asm("a2"), la3_ asm("a3"), la4_ asm("a4"), la5_ asm("a5")
+  register unsigned la0_ asm("a0"), la1_ asm("a1"), la2_ asm("a2"), la3_ asm("a3"), la4_ asm("a4"), la5_ asm("a5"), la6_ asm("a6")
 // (s_nop: the scalar ALU may have written a base a cycle ago, and nothing pads inside or in front of an asm statement)
 #define KL_BWD_INPUTS_REQUEST(g_base, g_off, c_base, c1_base, dh_base, h_off, dc_base, m_base, m_off)                               \
   do {                                                                                                                             \
     asm volatile("v_accvgpr_write_b32 a0, -1\n\tv_accvgpr_write_b32 a1, -1\n\tv_accvgpr_write_b32 a2, -1\n\t"                       \
-                 "v_accvgpr_write_b32 a3, -1\n\tv_accvgpr_write_b32 a4, -1\n\tv_accvgpr_write_b32 a5, -1\n\ts_nop 4\n\t"            \
-                 "global_load_dwordx2 a[0:1], %6, %7"                                                                              \
-                 : "=a"(la0_), "=a"(la1_), "=a"(la2_), "=a"(la3_), "=a"(la4_), "=a"(la5_) : "v"(g_off), "s"(g_base) : "memory");   \
-    asm volatile("s_nop 4\n\tglobal_load_short_d16 a2, %1, %2" : "+a"(la2_) : "v"(h_off), "s"(c_base) : "memory");                  \
-    asm volatile("s_nop 4\n\tglobal_load_short_d16_hi a2, %1, %2" : "+a"(la2_) : "v"(h_off), "s"(dh_base) : "memory");              \
-    asm volatile("s_nop 4\n\tglobal_load_short_d16 a3, %1, %2" : "+a"(la3_) : "v"(h_off), "s"(c1_base) : "memory");                 \
+                 "v_accvgpr_write_b32 a3, -1\n\tv_accvgpr_write_b32 a4, -1\n\tv_accvgpr_write_b32 a5, -1\n\t"                       \
+                 "v_accvgpr_write_b32 a6, -1\n\ts_nop 4\n\tglobal_load_dwordx2 a[0:1], %7, %8"                                       \
+                 : "=a"(la0_), "=a"(la1_), "=a"(la2_), "=a"(la3_), "=a"(la4_), "=a"(la5_), "=a"(la6_)                              \
+                 : "v"(g_off), "s"(g_base) : "memory");                                                                            \
+    asm volatile("s_nop 4\n\tglobal_load_ushort a2, %1, %2" : "+a"(la2_) : "v"(h_off), "s"(c_base) : "memory");                     \
+    asm volatile("s_nop 4\n\tglobal_load_ushort a6, %1, %2" : "+a"(la6_) : "v"(h_off), "s"(dh_base) : "memory");                    \
+    asm volatile("s_nop 4\n\tglobal_load_ushort a3, %1, %2" : "+a"(la3_) : "v"(h_off), "s"(c1_base) : "memory");                    \
     asm volatile("s_nop 4\n\tglobal_load_dword a4, %1, %2 sc1" : "+a"(la4_) : "v"(m_off), "s"(dc_base) : "memory");                 \
     asm volatile("s_nop 4\n\tglobal_load_dword a5, %1, %2" : "+a"(la5_) : "v"(m_off), "s"(m_base) : "memory");                      \
   } while (0)
-#define KL_BWD_INPUTS_READ(g0, g1, cd, c1, dc, mk)                                                                                 \
+#define KL_BWD_INPUTS_READ(g0, g1, cp, c1, dh, dc, mk)                                                                             \
   asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\t"                            \
-               "v_accvgpr_read_b32 %3, a3\n\tv_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5"                               \
-               : "=v"(g0), "=v"(g1), "=v"(cd), "=v"(c1), "=v"(dc), "=v"(mk)                                                        \
-               : "a"(la0_), "a"(la1_), "a"(la2_), "a"(la3_), "a"(la4_), "a"(la5_) : "memory")
-__device__ __forceinline__ bool bwd_inputs_missing(unsigned g0, unsigned g1, unsigned cd, unsigned c1, unsigned dc, unsigned mk) {
-  return max(max(g0, g1), max(dc, mk)) == 0xFFFFFFFFu || (cd & 0xFFFFu) == 0xFFFFu || (cd >> 16) == 0xFFFFu || (c1 & 0xFFFFu) == 0xFFFFu;
+               "v_accvgpr_read_b32 %3, a3\n\tv_accvgpr_read_b32 %4, a6\n\tv_accvgpr_read_b32 %5, a4\n\tv_accvgpr_read_b32 %6, a5"   \
+               : "=v"(g0), "=v"(g1), "=v"(cp), "=v"(c1), "=v"(dh), "=v"(dc), "=v"(mk)                                              \
+               : "a"(la0_), "a"(la1_), "a"(la2_), "a"(la3_), "a"(la4_), "a"(la5_), "a"(la6_) : "memory")
+__device__ __forceinline__ bool bwd_inputs_missing(unsigned g0, unsigned g1, unsigned cp, unsigned c1, unsigned dh, unsigned dc, unsigned mk) {
+  return max(max(max(g0, g1), max(dc, mk)), max(max(cp, c1), dh)) == 0xFFFFFFFFu;
 }
 
 // LDS map (bytes): tile [2][4*KSTEPS][1024] | zt [16 waves][16][17] f32 | pub [4 gates][16 rows][64 units] bf16 | flags | hand-off words [64] |
@@ -1313,15 +1315,15 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
       // ---- epilogue: thread = (row er, unit eu)
       // (loads and stores retire independently, so the count is an estimate: the armed registers are checked)
       wait_vm(vq - seq_in);
-      unsigned gin0, gin1, cdin, c1in, dcin, mkin;
-      KL_BWD_INPUTS_READ(gin0, gin1, cdin, c1in, dcin, mkin);
-      if (__any(bwd_inputs_missing(gin0, gin1, cdin, c1in, dcin, mkin))) {
+      unsigned gin0, gin1, cpin, c1in, dhin, dcin, mkin;
+      KL_BWD_INPUTS_READ(gin0, gin1, cpin, c1in, dhin, dcin, mkin);
+      if (__any(bwd_inputs_missing(gin0, gin1, cpin, c1in, dhin, dcin, mkin))) {
 #ifdef KL_STAMP
         if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[29] += 1;
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        KL_BWD_INPUTS_READ(gin0, gin1, cdin, c1in, dcin, mkin);
-        if (__any(bwd_inputs_missing(gin0, gin1, cdin, c1in, dcin, mkin))) {      // (nothing in flight any more: the data itself is bad)
+        KL_BWD_INPUTS_READ(gin0, gin1, cpin, c1in, dhin, dcin, mkin);
+        if (__any(bwd_inputs_missing(gin0, gin1, cpin, c1in, dhin, dcin, mkin))) {      // (nothing in flight any more: the data itself is bad)
           __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ok_flag = 0;
         }
@@ -1330,8 +1332,8 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
       if (t1 >= 0) KL_REQUEST_INPUTS(t1, r1);
       const float gi = bf2f((bf16_t)(gin0 & 0xffffu)), gf = bf2f((bf16_t)(gin0 >> 16));
       const float gg = bf2f((bf16_t)(gin1 & 0xffffu)), go = bf2f((bf16_t)(gin1 >> 16));
-      const float cp = u2f(cdin << 16);
-      float dh = u2f(cdin & 0xffff0000u);
+      const float cp = u2f(cpin << 16);
+      float dh = u2f(dhin << 16);
       const float ct = u2f(c1in << 16), dc_run = u2f(dcin);
       const float mk = maskl ? u2f(mkin) : 1.f;
       SSTAMP(21);
