@@ -1033,9 +1033,17 @@ __global__ __launch_bounds__(1024, 1) void logits_ce_ws_kernel(const KlLogitsCe 
 //   a[0:1] the four gates of this thread's cell (bf16)     a2 c_{t-1}, a3 c_t, a6 dH: zero-extended 16-bit loads, one register each
 //   (NOT two halves of one register by d16 loads: with SRAM ECC on -- gfx950's default -- a d16 load rewrites the whole register)
 //   a4 the running dc of this cell, kept in a [B][W] f32 array between the steps     a5 dropout mask
-// With the per-block state (dc, c_t) in memory instead of 2 x NP registers, and the bias gradient summed by LDS atomics
-// instead of four accumulators, the kernel fits its 120 VGPRs at every NP without scratch.
+// With the per-block state (dc, c_t) in memory instead of 2 x NP registers, and the bias gradient in one accumulator
+// instead of four, the kernel fits its 120 VGPRs at every NP without scratch.
 // Armed with all-ones before the request (no zero-extended halfword, no f32 datum here is that pattern), checked after the wait.
+#ifndef KL_BWD_VAR
+#define KL_BWD_VAR 0      /* timing experiments only (tools/gpu_variants.sh): 1 no bias-gradient atomics, 2 dc read without sc1, 4 no dc store */
+#endif
+#if KL_BWD_VAR & 2
+#define KL_BWD_DC_SC ""
+#else
+#define KL_BWD_DC_SC " sc1"
+#endif
 #define KL_BWD_INPUTS_DECL                                                                                                         \
   register unsigned la0_ asm("a0"), la1_ asm("a1"), la2_ asm("a2"), la3_ asm("a3"), la4_ asm("a4"), la5_ asm("a5"), la6_ asm("a6")
 // (s_nop: the scalar ALU may have written a base a cycle ago, and nothing pads inside or in front of an asm statement)
@@ -1049,7 +1057,7 @@ __global__ __launch_bounds__(1024, 1) void logits_ce_ws_kernel(const KlLogitsCe 
     asm volatile("s_nop 4\n\tglobal_load_ushort a2, %1, %2" : "+a"(la2_) : "v"(h_off), "s"(c_base) : "memory");                     \
     asm volatile("s_nop 4\n\tglobal_load_ushort a6, %1, %2" : "+a"(la6_) : "v"(h_off), "s"(dh_base) : "memory");                    \
     asm volatile("s_nop 4\n\tglobal_load_ushort a3, %1, %2" : "+a"(la3_) : "v"(h_off), "s"(c1_base) : "memory");                    \
-    asm volatile("s_nop 4\n\tglobal_load_dword a4, %1, %2 sc1" : "+a"(la4_) : "v"(m_off), "s"(dc_base) : "memory");                 \
+    asm volatile("s_nop 4\n\tglobal_load_dword a4, %1, %2" KL_BWD_DC_SC : "+a"(la4_) : "v"(m_off), "s"(dc_base) : "memory");          \
     asm volatile("s_nop 4\n\tglobal_load_dword a5, %1, %2" : "+a"(la5_) : "v"(m_off), "s"(m_base) : "memory");                      \
   } while (0)
 #define KL_BWD_INPUTS_READ(g0, g1, cp, c1, dh, dc, mk)                                                                             \
@@ -1061,9 +1069,8 @@ __device__ __forceinline__ bool bwd_inputs_missing(unsigned g0, unsigned g1, uns
   return max(max(max(g0, g1), max(dc, mk)), max(max(cp, c1), dh)) == 0xFFFFFFFFu;
 }
 
-// LDS map (bytes): tile [2][4*KSTEPS][1024] | zt [16 waves][16][17] f32 | pub [4 gates][16 rows][64 units] bf16 | flags | hand-off words [64] |
-// bias-gradient sums [4 gates][64 units] f32
-constexpr int bwd2_lds_bytes(int ksteps) { return 2 * 4 * ksteps * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16 + 256 + 4 * 64 * 4; }
+// LDS map (bytes): tile [2][4*KSTEPS][1024] | zt [16 waves][16][17] f32 | pub [4 gates][16 rows][64 units] bf16 | flags | hand-off words [64]
+constexpr int bwd2_lds_bytes(int ksteps) { return 2 * 4 * ksteps * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16 + 256; }
 
 // One layer, 16-row blocks, NP blocks per workgroup and step (2..4).  Wave = (K quarter = gate kq4, unit group ug):
 // dh_rec[16 x 16] = dZ[t+1][16 x W(gate kq4)] . Un[W(gate kq4) x 16 units]; the four gate partials meet in LDS.
@@ -1110,9 +1117,9 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
   unsigned* status = a.status;
   // Per-cell state between the steps lives in memory, not in 2 x NP registers: the running dc in a.dc_state [B][W] f32
   // (zeroed in front of the launch; read back NP blocks after it was written, by the thread that wrote it), c_t from the
-  // bf16 cell states the forward scan left (block t + 1).  The bias gradient is summed by LDS atomics (db_l).
-  float* const db_l = reinterpret_cast<float*>(smem + 2 * NPIECE * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16 + 256);
-  if (tid < 256) db_l[tid] = 0.f;
+  // bf16 cell states the forward scan left (block t + 1).  The bias gradient is summed by four otherwise idle waves from the
+  // staged tile (below).
+  float dbsum = 0.f;      // (waves 8..11: the bias gradient of column (gate, unit) = tid - 512)
   float* const dcs = a.dc_state;
   (void)Cl;
   const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(dZl, (long)T * BW * 4 * 2);
@@ -1342,18 +1349,12 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
       const float tc = fast_tanh(ct);
       const float dc = dh * go * (1.f - tc * tc) + dc_run;
       // the running dc of this cell for the step before: read back a whole step (NP blocks) from now
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dc * gf), alive ? rs_dc : rs_null, (int)(in_lane4 + (unsigned)(er * W * 4)),
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dc * gf), (alive && !(KL_BWD_VAR & 4)) ? rs_dc : rs_null, (int)(in_lane4 + (unsigned)(er * W * 4)),
                                             (int)(unsigned)(r0 * W * 4), 0);
       ++vq;
       const float d_o = dh * tc, d_i = dc * gg, d_g = dc * gi, d_f = dc * cp;
       const unsigned z0 = f2bf(d_i * gi * (1.f - gi)), z1 = f2bf(d_f * gf * (1.f - gf));
       const unsigned z2 = f2bf(d_g * (1.f - gg * gg)), z3 = f2bf(d_o * go * (1.f - go));
-      if (alive) {      // (one address per lane: no conflict inside the instruction; the sixteen rows meet in the LDS adder)
-        __hip_atomic_fetch_add(db_l + 0 * 64 + eu, bf2f((bf16_t)z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(db_l + 1 * 64 + eu, bf2f((bf16_t)z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(db_l + 2 * 64 + eu, bf2f((bf16_t)z2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(db_l + 3 * 64 + eu, bf2f((bf16_t)z3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
       pub[(0 * 16 + er) * 64 + eu] = (bf16_t)z0;
       pub[(1 * 16 + er) * 64 + eu] = (bf16_t)z1;
       pub[(2 * 16 + er) * 64 + eu] = (bf16_t)z2;
@@ -1383,15 +1384,22 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
         }
         vq += 2;
       }
+      // ---- bias gradient: waves 8..11 (idle while waves 0..7 publish) sum the staged tile's columns over its sixteen rows;
+      // thread = (gate, unit), ONE accumulator register (four per thread when every thread kept its own cell's; LDS float
+      // atomics from all sixteen waves onto the same 256 words cost 7000 cycles per block)
+      if (wave >= 8 && wave < 12 && alive && !(KL_BWD_VAR & 1)) {
+        const bf16_t* col = pub + (tid - 512 + ((tid - 512) >> 6) * 15 * 64);      // pub[(g * 16 + r) * 64 + u], g = (tid - 512) >> 6, u = tid & 63
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += bf2f(col[r * 64]);
+        dbsum += sum;
+      }
       SSTAMP(24);
     }
   }
   SSTAMP_FLUSH();
   // db[g*W + u] += sum over this workgroup's rows and all steps
-  if (a.db) {
-    __syncthreads();
-    if (tid < 256) atomicAdd(a.db + (long)(tid >> 6) * W + u0 + (tid & 63), db_l[tid]);
-  }
+  if (a.db && wave >= 8 && wave < 12) atomicAdd(a.db + (long)((tid - 512) >> 6) * W + u0 + (tid & 63), dbsum);
 }
 
 }  // namespace

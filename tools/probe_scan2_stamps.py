@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, '.')
 from ocrd_keraslm_amd.lib import hipabi
-hipabi.LIB_PATH = os.path.join(os.path.dirname(hipabi.LIB_PATH), os.environ.get('KL_STAMPS_LIB', 'libkeraslm_hip_stamps.so'))
+if not os.environ.get('KL_LIB'): hipabi.LIB_PATH = os.path.join(os.path.dirname(hipabi.LIB_PATH), os.environ.get('KL_STAMPS_LIB', 'libkeraslm_hip_stamps.so'))
 from ocrd_keraslm_amd.lib.engine import HipLM
 
 lib = hipabi.load()
