@@ -1047,19 +1047,19 @@ __global__ __launch_bounds__(1024, 1) void logits_ce_ws_kernel(const KlLogitsCe 
 #define KL_BWD_INPUTS_DECL                                                                                                         \
   register unsigned la0_ asm("a0"), la1_ asm("a1"), la2_ asm("a2"), la3_ asm("a3"), la4_ asm("a4"), la5_ asm("a5"), la6_ asm("a6")
 // (s_nop: the scalar ALU may have written a base a cycle ago, and nothing pads inside or in front of an asm statement)
-#define KL_BWD_INPUTS_REQUEST(g_base, g_off, c_base, c1_base, dh_base, h_off, dc_base, m_base, m_off)                               \
-  do {                                                                                                                             \
-    asm volatile("v_accvgpr_write_b32 a0, -1\n\tv_accvgpr_write_b32 a1, -1\n\tv_accvgpr_write_b32 a2, -1\n\t"                       \
-                 "v_accvgpr_write_b32 a3, -1\n\tv_accvgpr_write_b32 a4, -1\n\tv_accvgpr_write_b32 a5, -1\n\t"                       \
-                 "v_accvgpr_write_b32 a6, -1\n\ts_nop 4\n\tglobal_load_dwordx2 a[0:1], %7, %8"                                       \
-                 : "=a"(la0_), "=a"(la1_), "=a"(la2_), "=a"(la3_), "=a"(la4_), "=a"(la5_), "=a"(la6_)                              \
-                 : "v"(g_off), "s"(g_base) : "memory");                                                                            \
-    asm volatile("s_nop 4\n\tglobal_load_ushort a2, %1, %2" : "+a"(la2_) : "v"(h_off), "s"(c_base) : "memory");                     \
-    asm volatile("s_nop 4\n\tglobal_load_ushort a6, %1, %2" : "+a"(la6_) : "v"(h_off), "s"(dh_base) : "memory");                    \
-    asm volatile("s_nop 4\n\tglobal_load_ushort a3, %1, %2" : "+a"(la3_) : "v"(h_off), "s"(c1_base) : "memory");                    \
-    asm volatile("s_nop 4\n\tglobal_load_dword a4, %1, %2" KL_BWD_DC_SC : "+a"(la4_) : "v"(m_off), "s"(dc_base) : "memory");          \
-    asm volatile("s_nop 4\n\tglobal_load_dword a5, %1, %2" : "+a"(la5_) : "v"(m_off), "s"(m_base) : "memory");                      \
-  } while (0)
+// (six statements, so that the kernel can spread them over its MFMA phase: the address unit takes ~16 cycles per wave
+//  instruction whatever its width, and sixteen waves issuing six loads each in one burst stood still for ~2000 cycles)
+#define KL_BWD_REQ_G(g_base, g_off)                                                                                                \
+  asm volatile("v_accvgpr_write_b32 a0, -1\n\tv_accvgpr_write_b32 a1, -1\n\tv_accvgpr_write_b32 a2, -1\n\t"                         \
+               "v_accvgpr_write_b32 a3, -1\n\tv_accvgpr_write_b32 a4, -1\n\tv_accvgpr_write_b32 a5, -1\n\t"                         \
+               "v_accvgpr_write_b32 a6, -1\n\ts_nop 4\n\tglobal_load_dwordx2 a[0:1], %7, %8"                                         \
+               : "=a"(la0_), "=a"(la1_), "=a"(la2_), "=a"(la3_), "=a"(la4_), "=a"(la5_), "=a"(la6_)                                \
+               : "v"(g_off), "s"(g_base) : "memory")
+#define KL_BWD_REQ_CP(c_base, h_off) asm volatile("s_nop 4\n\tglobal_load_ushort a2, %1, %2" : "+a"(la2_) : "v"(h_off), "s"(c_base) : "memory")
+#define KL_BWD_REQ_DH(dh_base, h_off) asm volatile("s_nop 4\n\tglobal_load_ushort a6, %1, %2" : "+a"(la6_) : "v"(h_off), "s"(dh_base) : "memory")
+#define KL_BWD_REQ_CT(c1_base, h_off) asm volatile("s_nop 4\n\tglobal_load_ushort a3, %1, %2" : "+a"(la3_) : "v"(h_off), "s"(c1_base) : "memory")
+#define KL_BWD_REQ_DC(dc_base, m_off) asm volatile("s_nop 4\n\tglobal_load_dword a4, %1, %2" KL_BWD_DC_SC : "+a"(la4_) : "v"(m_off), "s"(dc_base) : "memory")
+#define KL_BWD_REQ_MK(m_base, m_off) asm volatile("s_nop 4\n\tglobal_load_dword a5, %1, %2" : "+a"(la5_) : "v"(m_off), "s"(m_base) : "memory")
 #define KL_BWD_INPUTS_READ(g0, g1, cp, c1, dh, dc, mk)                                                                             \
   asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\t"                            \
                "v_accvgpr_read_b32 %3, a3\n\tv_accvgpr_read_b32 %4, a6\n\tv_accvgpr_read_b32 %5, a4\n\tv_accvgpr_read_b32 %6, a5"   \
@@ -1175,15 +1175,23 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
   // (of the block (t_, r0_): this thread's row er, unit u0 + eu; a macro because a register variable cannot be captured.
   //  Without a dropout mask the sixth load reads the thread's own dc word again and the value is ignored: every statement
   //  runs on every path, so the landing registers have ONE definition per block and the compiler has nothing to merge.)
-#define KL_REQUEST_INPUTS(t_, r0_)                                                                                                  \
+#define KL_REQUEST_INPUT(k_, t_, r0_)                                                                                                \
   do {                                                                                                                             \
     const long trow_ = (long)(t_) * B + (r0_) + er;                                                                                \
     const float* dcrow_ = dcs + (long)((r0_) + er) * W;                                                                            \
-    const float* mrow_ = maskl ? maskl + (long)((r0_) + er) * W : dcrow_;                                                          \
-    KL_BWD_INPUTS_REQUEST(Gl + trow_ * W * 4, in_lane4 * 2, Cb + trow_ * W, Cb + (trow_ + B) * W, dHb + trow_ * W, in_lane4 >> 1,  \
-                          dcrow_, mrow_, in_lane4);                                                                                \
-    vq += 6;                                                                                                                       \
-    seq_in = vq;                                                                                                                   \
+    if (k_ == 0) KL_BWD_REQ_G(Gl + trow_ * W * 4, in_lane4 * 2);                                                                   \
+    if (k_ == 1) KL_BWD_REQ_CP(Cb + trow_ * W, in_lane4 >> 1);                                                                     \
+    if (k_ == 2) KL_BWD_REQ_DH(dHb + trow_ * W, in_lane4 >> 1);                                                                    \
+    if (k_ == 3) KL_BWD_REQ_CT(Cb + (trow_ + B) * W, in_lane4 >> 1);                                                               \
+    if (k_ == 4) KL_BWD_REQ_DC(dcrow_, in_lane4);                                                                                  \
+    if (k_ == 5) KL_BWD_REQ_MK(maskl ? maskl + (long)((r0_) + er) * W : dcrow_, in_lane4);                                         \
+    ++vq;                                                                                                                          \
+    if (k_ == 5) seq_in = vq;                                                                                                      \
+  } while (0)
+#define KL_REQUEST_INPUTS(t_, r0_)                                                                                                  \
+  do {                                                                                                                             \
+    KL_REQUEST_INPUT(0, t_, r0_); KL_REQUEST_INPUT(1, t_, r0_); KL_REQUEST_INPUT(2, t_, r0_);                                      \
+    KL_REQUEST_INPUT(3, t_, r0_); KL_REQUEST_INPUT(4, t_, r0_); KL_REQUEST_INPUT(5, t_, r0_);                                      \
   } while (0)
   KL_REQUEST_INPUTS(T - 1, rg * 16);
   int n = 0;
@@ -1256,6 +1264,24 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
       __syncthreads();
       SSTAMP(18);
       alive = __builtin_amdgcn_readfirstlane(ok_flag) != 0;
+      // ---- this block's epilogue inputs out of their landing registers (requested during the MFMA phase of the block before),
+      // and the next block's requests spread over this block's MFMAs (the very last block asks for its own rows again: every
+      // statement runs on every path, the landing registers never see a conditional definition)
+      wait_vm(vq - seq_in);
+      unsigned gin0, gin1, cpin, c1in, dhin, dcin, mkin;
+      KL_BWD_INPUTS_READ(gin0, gin1, cpin, c1in, dhin, dcin, mkin);
+      if (__any(bwd_inputs_missing(gin0, gin1, cpin, c1in, dhin, dcin, mkin))) {
+#ifdef KL_STAMP
+        if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[29] += 1;
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KL_BWD_INPUTS_READ(gin0, gin1, cpin, c1in, dhin, dcin, mkin);
+        if (__any(bwd_inputs_missing(gin0, gin1, cpin, c1in, dhin, dcin, mkin))) {      // (nothing in flight any more: the data itself is bad)
+          __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok_flag = 0;
+        }
+      }
+      const int tn = t1 >= 0 ? t1 : t, rn = t1 >= 0 ? r1 : r0;
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       if (t < T - 1) {
         // (k-step order and read-ahead as in the forward scan)
@@ -1271,7 +1297,16 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
           __builtin_amdgcn_sched_barrier(0);
           acc = mfma16(__builtin_bit_cast(bf16x8, fr[q & 1]), __builtin_bit_cast(bf16x8, bu[4 * (q & 3) + (q >> 2)]), acc);
           __builtin_amdgcn_sched_barrier(0);
+          if (q == 1) KL_REQUEST_INPUT(0, tn, rn);
+          if (q == 3) KL_REQUEST_INPUT(1, tn, rn);
+          if (q == 5) KL_REQUEST_INPUT(2, tn, rn);
+          if (q == 7) KL_REQUEST_INPUT(3, tn, rn);
+          if (q == 9) KL_REQUEST_INPUT(4, tn, rn);
+          if (q == 11) KL_REQUEST_INPUT(5, tn, rn);
+          __builtin_amdgcn_sched_barrier(0);
         }
+      } else {
+        KL_REQUEST_INPUTS(tn, rn);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) zt[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
@@ -1321,22 +1356,6 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
       if (!FLAGS && a.pf_mode == 2 && alive && t2 >= 0 && t2 < T - 1) issue_tile(t2, r2, buf);         // (every wave has finished this block's MFMAs)
       // ---- epilogue: thread = (row er, unit eu)
       // (loads and stores retire independently, so the count is an estimate: the armed registers are checked)
-      wait_vm(vq - seq_in);
-      unsigned gin0, gin1, cpin, c1in, dhin, dcin, mkin;
-      KL_BWD_INPUTS_READ(gin0, gin1, cpin, c1in, dhin, dcin, mkin);
-      if (__any(bwd_inputs_missing(gin0, gin1, cpin, c1in, dhin, dcin, mkin))) {
-#ifdef KL_STAMP
-        if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[29] += 1;
-#endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        KL_BWD_INPUTS_READ(gin0, gin1, cpin, c1in, dhin, dcin, mkin);
-        if (__any(bwd_inputs_missing(gin0, gin1, cpin, c1in, dhin, dcin, mkin))) {      // (nothing in flight any more: the data itself is bad)
-          __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok_flag = 0;
-        }
-      }
-      // ... and the next block's go out at once: a whole block of latency cover
-      if (t1 >= 0) KL_REQUEST_INPUTS(t1, r1);
       const float gi = bf2f((bf16_t)(gin0 & 0xffffu)), gf = bf2f((bf16_t)(gin0 >> 16));
       const float gg = bf2f((bf16_t)(gin1 & 0xffffu)), go = bf2f((bf16_t)(gin1 >> 16));
       const float cp = u2f(cpin << 16);
