@@ -1421,6 +1421,384 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
   if (a.db && wave >= 8 && wave < 12) atomicAdd(a.db + (long)((tid - 512) >> 6) * W + u0 + (tid & 63), dbsum);
 }
 
+// ---------------------------------------------------------------- backward, third cut: eight waves, two cells per thread
+// Same grid, hand-off and tile image as lstm_scan_bwd_wide2_kernel, re-cut around what round 3's stamps showed: the address
+// unit takes ~16 cycles per vector-memory wave instruction whatever its width, so 16 waves x (4 tile pieces + 3..6 two- and
+// four-byte input loads + stores) kept it busy for 2400-3000 cycles per 16-row block, in bursts; the LDS served the same
+// 1 KiB fragment to four waves (one MFMA per read); and the 128 registers of a 1024-thread workgroup left no room for
+// anything in flight.  Here:
+//  * 512 threads, 256 registers each: wave = (gate quarter of K, 32 units) -- every 1 KiB fragment read feeds two MFMAs with
+//    independent accumulators, the fragment reads per block halve, and the read-ahead is three k-steps deep;
+//  * an epilogue thread owns TWO neighbouring units of one row: its inputs come as 16 + 4 + 4 bytes (gates, c_{t-1}, dH) --
+//    24 wave instructions per block instead of 64-96 -- into accumulator registers a0..a5, requested a whole block ahead
+//    between the MFMAs of the block before (KL_B3_*; see KL_BWD_INPUTS_* above for how they stay out of the compiler's way);
+//  * the per-slot state (running dc, c_t, dropout mask: 6 x NP registers) is back in registers, where there is room now;
+//  * waves 0..3 publish (two 16-byte write-through stores per lane) and post the flags, waves 4..7 fetch the tiles (sixteen
+//    1 KiB pieces each): a publishing wave then has NOTHING but stores in flight once its epilogue inputs have been seen to
+//    have landed, and stores retire in order -- so "the block before last has reached memory" is an exact counted wait
+//    (s_waitcnt vmcnt(3)) instead of a drain, which at this block length (~2 us against a write-through acknowledgement
+//    of ~3 us) would stall every block.  A flag is therefore posted two blocks after its data: five or more blocks per
+//    step (the launcher's rule for flags) leave that time;
+//  * all eight waves sum the bias gradient from the staged tile.
+// LDS map (bytes): tile [2][64][1024] | zt [8 waves][584 words] (rows of 36 words: conflict-free partial-tile writes and
+// 8-byte epilogue reads) | pub [4 gates][16 rows][64 units] bf16 | flags | hand-off words [64]
+constexpr int B3_ZT_ROW = 36, B3_ZT_WAVE = 16 * 36 + 8;
+constexpr int bwd3_lds_bytes() { return 2 * 64 * 1024 + 8 * B3_ZT_WAVE * 4 + 4 * 16 * 64 * 2 + 16 + 256; }
+
+#define KL_B3_DECL register unsigned lb0_ asm("a0"), lb1_ asm("a1"), lb2_ asm("a2"), lb3_ asm("a3"), lb4_ asm("a4"), lb5_ asm("a5")
+#define KL_B3_REQ_G(g_base, g_off)                                                                                                 \
+  asm volatile("v_accvgpr_write_b32 a0, -1\n\tv_accvgpr_write_b32 a1, -1\n\tv_accvgpr_write_b32 a2, -1\n\t"                         \
+               "v_accvgpr_write_b32 a3, -1\n\tv_accvgpr_write_b32 a4, -1\n\tv_accvgpr_write_b32 a5, -1\n\ts_nop 4\n\t"              \
+               "global_load_dwordx4 a[0:3], %6, %7"                                                                                \
+               : "=a"(lb0_), "=a"(lb1_), "=a"(lb2_), "=a"(lb3_), "=a"(lb4_), "=a"(lb5_) : "v"(g_off), "s"(g_base) : "memory")
+#define KL_B3_REQ_CP(c_base, h_off) asm volatile("s_nop 4\n\tglobal_load_dword a4, %1, %2" : "+a"(lb4_) : "v"(h_off), "s"(c_base) : "memory")
+#define KL_B3_REQ_DH(dh_base, h_off) asm volatile("s_nop 4\n\tglobal_load_dword a5, %1, %2" : "+a"(lb5_) : "v"(h_off), "s"(dh_base) : "memory")
+#define KL_B3_READ(g0, g1, g2, g3, cp, dh)                                                                                         \
+  asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\t"                            \
+               "v_accvgpr_read_b32 %3, a3\n\tv_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5"                               \
+               : "=v"(g0), "=v"(g1), "=v"(g2), "=v"(g3), "=v"(cp), "=v"(dh)                                                        \
+               : "a"(lb0_), "a"(lb1_), "a"(lb2_), "a"(lb3_), "a"(lb4_), "a"(lb5_) : "memory")
+
+template <int NP, bool FLAGS>
+__global__ __launch_bounds__(512, 1) void lstm_scan_bwd_wide3_kernel(const KlScanBwd a) {
+  constexpr int KSTEPS = 16, W = 512, NWG_RB = W / 64, NPIECE = 64, JW = 16;      // (JW: tile pieces per DMA wave = 4 quarters x 4 rows)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq4 = wave & 3, uh = wave >> 2;
+  const int n_rg = a.n_rg, B = a.B, T = a.T;
+  const int xcd = blockIdx.x & 7, yy = blockIdx.x >> 3;
+  const int cg = yy % NWG_RB, rq = yy / NWG_RB, rg = xcd * ((n_rg + 7) >> 3) + rq;
+  if (rg >= n_rg) return;
+  const int u0 = cg * 64;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const zt = reinterpret_cast<float*>(smem + 2 * NPIECE * 1024);
+  bf16_t* const pub = reinterpret_cast<bf16_t*>(smem + 2 * NPIECE * 1024 + 8 * B3_ZT_WAVE * 4);
+  int& ok_flag = *reinterpret_cast<int*>(smem + 2 * NPIECE * 1024 + 8 * B3_ZT_WAVE * 4 + 4 * 16 * 64 * 2);
+  constexpr int FL_OFF = 2 * NPIECE * 1024 + 8 * B3_ZT_WAVE * 4 + 4 * 16 * 64 * 2 + 16;
+  unsigned* const fl_l = reinterpret_cast<unsigned*>(smem + FL_OFF);
+  const unsigned lds_tile = (unsigned)(size_t)(lds_void_t*)smem;
+
+  // resident weights: B fragments of this wave's two 16-unit tiles, its gate quarter of K
+  u32x4 bu[2][KSTEPS];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const long wrow = (long)(u0 + uh * 32 + x * 16 + (lane & 15)) * 4 * W + (long)kq4 * W + (lane >> 4) * 8;
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j) bu[x][j] = *reinterpret_cast<const u32x4*>(a.Un[0] + wrow + j * 32);
+  }
+  // epilogue thread = (row er of the block, units eu and eu + 1 of the workgroup's 64)
+  const int er = 2 * wave + (lane >> 5), eu = 2 * (lane & 31);
+  const long BW = (long)B * W;
+  const bf16_t* Gl = a.G[0];
+  const float* Cl = a.C[0];
+  bf16_t* dZl = a.dZ[0];
+  const bf16_t* dHb = a.dHb;
+  const bf16_t* Cb = a.Cb;
+  const float* maskl = a.mask[0];
+  unsigned* status = a.status;
+  // per block slot of this workgroup (slot 0 = the current one: rotated) and cell: running dc, the cell state c_t of the
+  // step being processed (the c_{t-1} loaded for step t is the c_t of step t - 1), the dropout keep-mask on dH
+  float dcr[NP][2], ccur[NP][2], mkr[NP][2];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const long row = (long)(rg + p * n_rg) * 16 + er;
+    const float2 c2 = *reinterpret_cast<const float2*>(Cl + (long)T * BW + row * W + u0 + eu);
+    float2 m2 = float2{1.f, 1.f};
+    if (maskl) m2 = *reinterpret_cast<const float2*>(maskl + row * W + u0 + eu);
+    dcr[p][0] = dcr[p][1] = 0.f;
+    ccur[p][0] = c2.x; ccur[p][1] = c2.y;
+    mkr[p][0] = m2.x; mkr[p][1] = m2.y;
+  }
+  float dbsum = 0.f;      // bias gradient of column (gate, unit) = tid & 255, rows 8 (tid >> 8) .. + 8 of every block
+  const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(dZl, (long)T * BW * 4 * 2);
+  const __amdgpu_buffer_rsrc_t rs_null = make_rsrc(dZl, 0);
+  // (hand-off by flags or rolling sentinels: see lstm_scan_bwd_wide2_kernel; here all eight waves publish and post)
+  unsigned* const flags = FLAGS ? a.flags : nullptr;
+  const unsigned epoch = FLAGS ? *a.epoch : 0u;
+  const __amdgpu_buffer_rsrc_t rs_fl = make_rsrc(flags, FLAGS ? (long)a.n_rb * 64 * 4 : 0);
+  bool alive = true;
+  if (tid == 0) ok_flag = 1;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j) asm volatile("" : "+v"(bu[x][j]));
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    asm volatile("" : "+v"(ccur[p][0]), "+v"(ccur[p][1]), "+v"(mkr[p][0]), "+v"(mkr[p][1]));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  SSTAMP_INIT(0);
+
+  int vq = 0, seq_tile[2] = {0, 0}, seq_in = 0;
+  // tile image as in the 16-wave kernel: piece (gate quarter j, row r) = 1 KiB, chunk c of row r at position c ^ r; wave 4 + d
+  // fetches the four quarters of rows 4d .. 4d + 3
+  const bool dma_wave = wave >= 4;
+  const int wd = wave & 3;
+  const unsigned frag_lane = (unsigned)((lane & 15) * 1024 + (((lane >> 4) ^ (lane & 3)) * 16) + 64 * ((lane >> 2) & 3));
+  auto issue_tile = [&](int t, int r0, int buf) __attribute__((always_inline)) {      // tile = dZ[t + 1], rows r0 .. r0 + 16 (DMA waves)
+#pragma unroll
+    for (int k = 0; k < JW; ++k) arm16(smem + (buf * NPIECE + (k >> 2) * 16 + 4 * wd + (k & 3)) * 1024 + lane * 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < JW; ++k) {
+      const int j = k >> 2, row = 4 * wd + (k & 3), p = j * 16 + row;
+      const unsigned soff = (unsigned)((((long)(t + 1) * B + r0 + row) * 4 * W + (long)j * W) * 2);
+      glds16_sc1_s(rs_own, (unsigned)(((lane ^ row) & 63) * 16), soff, lds_tile + (unsigned)((buf * NPIECE + p) * 1024));
+      ++vq;
+    }
+    seq_tile[buf] = vq;
+  };
+  auto tile_there = [&](int buf) __attribute__((always_inline)) -> bool {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < JW; ++k) ok = ok && piece_there(smem + (buf * NPIECE + (k >> 2) * 16 + 4 * wd + (k & 3)) * 1024 + lane * 16);
+    return __all(ok);
+  };
+  // (lane part of the input addresses: first unit of this thread's pair, in row 2 wave or 2 wave + 1; the rest is wave-uniform)
+  const unsigned in_g = (unsigned)((u0 + eu) * 8 + (lane >> 5) * W * 8), in_h = (unsigned)((u0 + eu) * 2 + (lane >> 5) * W * 2);
+  KL_B3_DECL;
+#define KL_B3_REQUEST(k_, t_, r0_)                                                                                                  \
+  do {                                                                                                                             \
+    const long trow_ = (long)(t_) * B + (r0_) + 2 * wave;                                                                          \
+    if (k_ == 0) KL_B3_REQ_G(Gl + trow_ * W * 4, in_g);                                                                            \
+    if (k_ == 1) KL_B3_REQ_CP(Cb + trow_ * W, in_h);                                                                               \
+    if (k_ == 2) KL_B3_REQ_DH(dHb + trow_ * W, in_h);                                                                              \
+    ++vq;                                                                                                                          \
+    if (k_ == 2) seq_in = vq;                                                                                                      \
+  } while (0)
+  KL_B3_REQUEST(0, T - 1, rg * 16); KL_B3_REQUEST(1, T - 1, rg * 16); KL_B3_REQUEST(2, T - 1, rg * 16);
+
+  int n = 0;
+  for (int t = T - 1; t >= 0; --t) {
+#pragma unroll 1
+    for (int ip = 0; ip < NP; ++ip, ++n) {
+      const int buf = n & 1;
+      const int r0 = (rg + ip * n_rg) * 16;
+      int t1 = t, ip1 = ip + 1;
+      if (ip1 >= NP) { ip1 = 0; t1 = t - 1; }
+      int t2 = t1, ip2 = ip1 + 1;
+      if (ip2 >= NP) { ip2 = 0; t2 = t1 - 1; }
+      const int r1 = (rg + ip1 * n_rg) * 16, r2 = (rg + ip2 * n_rg) * 16;
+      SSTAMP(16);
+      // (flags: the 64 words of the block whose tile is requested next come into LDS -- armed with 0 = "not yet" -- and are looked
+      //  at behind the MFMAs; the last wave fetches them.  a.pf_mode 2: the tile of the block AFTER next, behind the epilogue)
+      const bool pf2 = a.pf_mode == 2;
+      const int tF = pf2 ? t2 : t1, rF = pf2 ? r2 : r1;
+      if (FLAGS && wave == 7 && tF >= 0 && tF < T - 1) {      // (a DMA wave)
+        fl_l[lane] = 0u;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        glds4_sc1_s(rs_fl, (unsigned)(lane * 4), (unsigned)((rF >> 4) * 256), lds_tile + (unsigned)FL_OFF);
+        ++vq;
+      }
+      if (dma_wave && alive && t < T - 1) {
+        wait_vm(vq - seq_tile[buf]);
+        SSTAMP(25);
+        bool ok = tile_there(buf);
+        if (!ok) {
+#ifdef KL_STAMP
+          if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[28] += 1;
+#endif
+          for (unsigned spin = 0; spin < SPIN_LIMIT && !ok; ++spin) {
+            if (spin > 0) {                 // (first round: only wait until everything issued has landed)
+#pragma unroll
+              for (int k = 0; k < JW; ++k) {
+                const int j = k >> 2, row = 4 * wd + (k & 3), p = j * 16 + row;
+                const unsigned soff = (unsigned)((((long)(t + 1) * B + r0 + row) * 4 * W + (long)j * W) * 2);
+                glds16_sc1_s(rs_own, (unsigned)(((lane ^ row) & 63) * 16), soff, lds_tile + (unsigned)((buf * NPIECE + p) * 1024));
+                ++vq;
+              }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ok = tile_there(buf);
+            if (!ok) {
+              if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+              __builtin_amdgcn_s_sleep(2);
+            }
+          }
+          if (!ok) {
+            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok_flag = 0;
+          }
+        }
+      }
+      SSTAMP(17);
+      __syncthreads();
+      SSTAMP(18);
+      alive = __builtin_amdgcn_readfirstlane(ok_flag) != 0;
+      // ---- this block's epilogue inputs out of their landing registers (requested during the MFMAs of the block before); the
+      // next block's requests go out between this block's MFMAs (the very last block asks for its own rows again: every
+      // statement runs on every path, the landing registers never see a conditional definition)
+      wait_vm(vq - seq_in);
+      unsigned gin[4], cpin, dhin;
+      KL_B3_READ(gin[0], gin[1], gin[2], gin[3], cpin, dhin);
+      if (__any(max(max(max(gin[0], gin[1]), max(gin[2], gin[3])), max(cpin, dhin)) == 0xFFFFFFFFu)) {
+#ifdef KL_STAMP
+        if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[29] += 1;
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KL_B3_READ(gin[0], gin[1], gin[2], gin[3], cpin, dhin);
+        if (__any(max(max(max(gin[0], gin[1]), max(gin[2], gin[3])), max(cpin, dhin)) == 0xFFFFFFFFu)) {      // (nothing in flight any more)
+          __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok_flag = 0;
+        }
+      }
+      if (FLAGS && !dma_wave && n > 1) {
+        // Post the block before last.  This wave's loads are its epilogue inputs only, and those of this block have just been
+        // seen to have landed (loads return in order): whatever is in flight now are stores, which retire in order -- the two
+        // publishes of the last block and the post before this one may be among them, the block before last's publishes not
+        int tp = t, ipp = ip - 2;
+        if (ipp < 0) { ipp += NP; tp = t + 1; }
+        const int rbp = rg + ipp * n_rg;
+        wait_vm(n == 2 ? 2 : 3);      // (the third store in flight is the post of the block before: there is none yet in block 2)
+        if (lane < 2)
+          __builtin_amdgcn_raw_buffer_store_b32(epoch - (unsigned)tp, alive ? rs_fl : rs_null, (rbp * 64 + cg * 8 + wave * 2 + lane) * 4, 0, 16);
+        ++vq;
+      }
+      const int tn = t1 >= 0 ? t1 : t, rn = t1 >= 0 ? r1 : r0;
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < T - 1) {
+        // k-steps in the order j = 4 (q & 3) + (q >> 2) (one lane address per group of four), fragments three steps ahead
+        const unsigned char* tb = smem + (buf * NPIECE + kq4 * 16) * 1024;
+        auto frag = [&](int q) __attribute__((always_inline)) -> u32x4 {
+          return *reinterpret_cast<const u32x4*>(tb + (frag_lane ^ (unsigned)(64 * (q >> 2))) + 256 * (q & 3));
+        };
+        u32x4 fr[4];
+        fr[0] = frag(0); fr[1] = frag(1); fr[2] = frag(2);
+#pragma unroll
+        for (int q = 0; q < KSTEPS; ++q) {
+          if (q + 3 < KSTEPS) fr[(q + 3) & 3] = frag(q + 3);
+          __builtin_amdgcn_sched_barrier(0);
+          const int j = 4 * (q & 3) + (q >> 2);
+          acc0 = mfma16(__builtin_bit_cast(bf16x8, fr[q & 3]), __builtin_bit_cast(bf16x8, bu[0][j]), acc0);
+          acc1 = mfma16(__builtin_bit_cast(bf16x8, fr[q & 3]), __builtin_bit_cast(bf16x8, bu[1][j]), acc1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (q == 2) KL_B3_REQUEST(0, tn, rn);
+          if (q == 6) KL_B3_REQUEST(1, tn, rn);
+          if (q == 10) KL_B3_REQUEST(2, tn, rn);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        KL_B3_REQUEST(0, tn, rn); KL_B3_REQUEST(1, tn, rn); KL_B3_REQUEST(2, tn, rn);
+      }
+      {
+        float* zw = zt + wave * B3_ZT_WAVE + ((lane >> 4) * 4) * B3_ZT_ROW + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { zw[r * B3_ZT_ROW] = acc0[r]; zw[r * B3_ZT_ROW + 16] = acc1[r]; }
+      }
+      SSTAMP(19);
+      __syncthreads();
+      SSTAMP(20);
+      auto request_next = [&]() __attribute__((always_inline)) {
+        if (dma_wave && alive && tF >= 0 && tF < T - 1) {
+          bool ready = true;
+          if (FLAGS) {
+            // (unsigned distance: a word of this launch is at most T - 1 behind the epoch, one of an earlier launch at least T + 2)
+            const unsigned far = (unsigned)(tF + 1);
+            ready = __all(epoch - *reinterpret_cast<const volatile unsigned*>(fl_l + lane) <= far);
+            if (!ready) {      // not posted when the words were fetched, or the fetch itself still on its way: ask memory
+#ifdef KL_STAMP
+              if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[28] += 1;
+#endif
+              for (unsigned spin = 0; spin < SPIN_LIMIT && !ready; ++spin) {
+                const unsigned now = __hip_atomic_load(flags + (long)(rF >> 4) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ready = __all(epoch - now <= far);
+                if (!ready) {
+                  if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                  __builtin_amdgcn_s_sleep(2);
+                }
+              }
+              if (!ready) {
+                __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok_flag = 0;
+              }
+            }
+          }
+          if (ready) issue_tile(tF, rF, pf2 ? buf : buf ^ 1);
+        }
+      };
+      if (!pf2) request_next();
+      // ---- epilogue: thread = (row er, units eu and eu + 1)
+      float dzv[2][4];
+      {
+        const float* zr = zt + (eu >> 5) * 4 * B3_ZT_WAVE + er * B3_ZT_ROW + (eu & 31);
+        const float2 p0 = *reinterpret_cast<const float2*>(zr), p1 = *reinterpret_cast<const float2*>(zr + B3_ZT_WAVE);
+        const float2 p2 = *reinterpret_cast<const float2*>(zr + 2 * B3_ZT_WAVE), p3 = *reinterpret_cast<const float2*>(zr + 3 * B3_ZT_WAVE);
+        const float rec[2] = {(p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y)};
+        SSTAMP(21);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const unsigned g01 = gin[2 * c], g23 = gin[2 * c + 1];
+          const float gi = u2f(g01 << 16), gf = u2f(g01 & 0xffff0000u), gg = u2f(g23 << 16), go = u2f(g23 & 0xffff0000u);
+          const float cp = c ? u2f(cpin & 0xffff0000u) : u2f(cpin << 16);
+          const float dhi = c ? u2f(dhin & 0xffff0000u) : u2f(dhin << 16);
+          const float dh = dhi * mkr[0][c] + rec[c];
+          const float tc = fast_tanh(ccur[0][c]);
+          const float dc = dh * go * (1.f - tc * tc) + dcr[0][c];
+          dcr[0][c] = dc * gf;
+          ccur[0][c] = cp;
+          const float d_o = dh * tc, d_i = dc * gg, d_g = dc * gi, d_f = dc * cp;
+          dzv[c][0] = d_i * gi * (1.f - gi);
+          dzv[c][1] = d_f * gf * (1.f - gf);
+          dzv[c][2] = d_g * (1.f - gg * gg);
+          dzv[c][3] = d_o * go * (1.f - go);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<unsigned*>(pub + (g * 16 + er) * 64 + eu) = (unsigned)f2bf(dzv[0][g]) | ((unsigned)f2bf(dzv[1][g]) << 16);
+      }
+      if (pf2) request_next();
+      SSTAMP(22);
+      __syncthreads();
+      SSTAMP(23);
+      // ---- publish dZ[t] (waves 0..3, two 16-byte write-through stores per lane); sentinel mode: re-arm step t - 2
+      {
+        int stid = tid;
+        asm volatile("" : "+v"(stid));
+        if (!dma_wave) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int pi = k * 256 + stid;
+            const int g = pi >> 7, prow = (pi >> 3) & 15, seg = pi & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>(pub + (g * 16 + prow) * 64 + seg * 8);
+            const unsigned off = (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2);
+            store16_sc1(alive ? rs_own : rs_null, off, v);
+            ++vq;
+            if (!FLAGS) {
+              const unsigned soff = off - (unsigned)((long)2 * B * 4 * W * 2);
+              const uint4 ones = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+              store16_sc1((alive && t >= 2) ? rs_own : rs_null, soff, ones);      // (a null buffer drops the store, the count stays)
+              ++vq;
+            }
+          }
+        }
+        // bias gradient: column (gate, unit) = tid & 255 of the staged tile, rows 8 (tid >> 8) .. + 8 (what was stored: the bf16 values)
+        if (alive) {
+          const bf16_t* col = pub + ((stid & 255) >> 6) * 1024 + (stid >> 8) * 512 + (stid & 63);
+          float sum = 0.f;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) sum += bf2f(col[r * 64]);
+          dbsum += sum;
+        }
+      }
+      SSTAMP(24);
+      if (NP > 1) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const float d0 = dcr[0][c], c0 = ccur[0][c], m0 = mkr[0][c];
+#pragma unroll
+          for (int p = 0; p + 1 < NP; ++p) { dcr[p][c] = dcr[p + 1][c]; ccur[p][c] = ccur[p + 1][c]; mkr[p][c] = mkr[p + 1][c]; }
+          dcr[NP - 1][c] = d0; ccur[NP - 1][c] = c0; mkr[NP - 1][c] = m0;
+        }
+      }
+    }
+  }
+  SSTAMP_FLUSH();
+  // db[g*W + u] += sum over this workgroup's rows and all steps (two row halves per column)
+  if (a.db) atomicAdd(a.db + (long)((tid & 255) >> 6) * W + u0 + (tid & 63), dbsum);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- helpers of the gate-interleaved layouts
@@ -1648,6 +2026,43 @@ int kl_launch_scan_bwd_wide2(KlScanBwd a, hipStream_t stream) {
 #undef KL_B2_NP
 #undef KL_B2_CASE
 #undef KL_B2_CASE1
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+// third cut of the backward scan (eight waves, two cells per thread); same arguments and hand-off memory as kl_launch_scan_bwd_wide2.
+// Flags need five or more blocks per workgroup and step here (a flag is posted two blocks after its data), else rolling sentinels.
+int kl_scan_bwd_wide3_min_np_flags() { return 5; }
+int kl_launch_scan_bwd_wide3(KlScanBwd a, hipStream_t stream) {
+  const int W = a.W;
+  const int np = kl_scan_wide2_phases(a.B, a.T, W, 16, 6);
+  if (!np || W != 512 || a.L != 1 || a.dZT || a.T < 3) return KL_ERR_SHAPE;
+  if (!a.Cb || !a.dHb) return KL_ERR_ARG;
+  if (a.flags ? (np < kl_scan_bwd_wide3_min_np_flags() || !a.epoch) : a.sentinel != 2) return KL_ERR_SHAPE;
+  if (a.pf_mode == 2 && np < 3) a.pf_mode = 1;      // (two blocks ahead needs the rows to have been published at least a block before the request)
+  a.n_rb = a.B / 16;
+  a.n_rg = a.n_rb / np;
+  dim3 grid(8 * (W / 64) * ((a.n_rg + 7) / 8)), block(512);
+  const size_t lds = (size_t)bwd3_lds_bytes();
+#define KL_B3_CASE1(NP_, FL_)                                                                                               \
+  do {                                                                                                                      \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_bwd_wide3_kernel<NP_, FL_>),                          \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;     \
+    hipLaunchKernelGGL((lstm_scan_bwd_wide3_kernel<NP_, FL_>), grid, block, lds, stream, a);                                \
+  } while (0)
+#define KL_B3_CASE(NP_)                    \
+  do {                                     \
+    if (a.flags) KL_B3_CASE1(NP_, true);   \
+    else KL_B3_CASE1(NP_, false);          \
+  } while (0)
+  switch (np) {
+    case 2: KL_B3_CASE(2); break;
+    case 3: KL_B3_CASE(3); break;
+    case 4: KL_B3_CASE(4); break;
+    case 5: KL_B3_CASE(5); break;
+    default: KL_B3_CASE(6); break;
+  }
+#undef KL_B3_CASE
+#undef KL_B3_CASE1
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 

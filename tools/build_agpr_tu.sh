@@ -7,7 +7,7 @@
 #     budget of a 1024-thread workgroup between VGPRs and AGPRs as soon as an AGPR is named (64 + 64: the weights alone take 64);
 #   * -amdgpu-mfma-vgpr-form, so that the MFMA accumulator stays in VGPRs and the compiler has no reason to touch an AGPR.
 # So the translation unit is built in the steps hipcc runs internally, with the attribute set on the device IR in between:
-#   device IR (optimised, -emit-llvm)  ->  attribute on the lstm_scan_bwd_wide2_kernel definitions  ->  code object
+#   device IR (optimised, -emit-llvm)  ->  attribute on the lstm_scan_bwd_wide2 / wide3 kernel definitions  ->  code object
 #   (-disable-llvm-optzns: the IR is already optimised; the forward kernels come out instruction for instruction as from
 #   plain hipcc)  ->  offload bundle  ->  host object with the bundle embedded (-fcuda-include-gpubinary).
 # Usage: build_agpr_tu.sh <src.hip> <out.o> <out.s> -- <hipcc flags...>
@@ -20,8 +20,8 @@ TMP=$(mktemp -d /tmp/kl_agpr_XXXXXX)
 trap 'rm -rf "$TMP"' EXIT
 "$HIPCC" "$@" --cuda-device-only -emit-llvm -S "$SRC" -o "$TMP/dev.ll" 2> "$TMP/err" || { cat "$TMP/err" >&2; exit 1; }
 grep -v "argument unused during compilation" "$TMP/err" >&2 || true
-N=$(grep -c '^define .*lstm_scan_bwd_wide2_kernel' "$TMP/dev.ll" || true)
-sed -E -i '/^define .*lstm_scan_bwd_wide2_kernel/ s/\) local_unnamed_addr (#[0-9]+)/) local_unnamed_addr \1 "amdgpu-agpr-alloc"="8,8"/' "$TMP/dev.ll"
+N=$(grep -c '^define .*lstm_scan_bwd_wide[23]_kernel' "$TMP/dev.ll" || true)
+sed -E -i '/^define .*lstm_scan_bwd_wide[23]_kernel/ s/\) local_unnamed_addr (#[0-9]+)/) local_unnamed_addr \1 "amdgpu-agpr-alloc"="8,8"/' "$TMP/dev.ll"
 M=$(grep -c '"amdgpu-agpr-alloc"="8,8"' "$TMP/dev.ll" || true)
 if [ "$N" -lt 1 ] || [ "$N" != "$M" ]; then echo "build_agpr_tu: attribute set on $M of $N backward-scan kernels" >&2; exit 1; fi
 CG="-target amdgcn-amd-amdhsa -mcpu=$ARCH -O3 -Xclang -disable-llvm-optzns -mllvm -amdgpu-mfma-vgpr-form=1"
