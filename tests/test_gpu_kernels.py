@@ -377,8 +377,8 @@ def test_train_window_wide_forward(monkeypatch, depth, width, voc, B, T, n_ctx, 
     (2, 512, 64, 3072, 4, 1, True, {"KL_SCAN2_PF": "2"}),      # ... with three 32-row phases forward, six blocks backward
     (2, 512, 64, 1024, 4, 1, True, {"KL_SCAN2_PF": "2"}),      # ... with two phases: every request too early (the re-fetch path)
     # the 8-wave backward scan (default since round 3) by flags (five and six blocks per step) and by rolling sentinels
-    (2, 512, 64, 2560, 4, 1, True, {}), (2, 512, 64, 3072, 5, 1, True, {}), (2, 512, 64, 3072, 4, 1, True, {"KL_SCAN2_FLAGS": "0"}),
-    (2, 512, 64, 2560, 3, 0, False, {"KL_SCAN2_PFB": "1"}),
+    (2, 512, 64, 3072, 5, 1, True, {}), (2, 512, 64, 3072, 4, 1, True, {"KL_SCAN2_FLAGS": "0"}),
+    (2, 512, 64, 3072, 3, 0, False, {"KL_SCAN2_PFB": "1"}),
     # the 16-wave backward scan of the second generation (KL_SCAN3=0): flags from three blocks per step, sentinels below
     (2, 512, 64, 1024, 4, 1, True, {"KL_SCAN3": "0"}), (2, 512, 64, 3072, 4, 1, True, {"KL_SCAN3": "0"}),
     (2, 512, 64, 1536, 5, 1, True, {"KL_SCAN3": "0"})])

@@ -17,7 +17,7 @@ for v in ""; do
     KL_SCAN2_FLAGS=$fl KL_LIB=ocrd_keraslm_amd/libkeraslm_hip$v.so KL_PROBE_TRACE=1 KL_PROBE_TRAIN_ONLY=1 timeout -k 10 120 python tools/probe_perf.py 3072 2>&1 | grep -v amdgpu.ids >> $OUT/r3c.log || exit 1
   done
 done
-for B in 3072 2560 2048 1536 1024; do
+for B in 3072 2048 1536 1024; do
   for s3 in 1 0; do
     echo "=== shipped B=$B KL_SCAN3=$s3" >> $OUT/r3c.log
     KL_SCAN3=$s3 KL_PROBE_TRACE=1 KL_PROBE_TRAIN_ONLY=1 timeout -k 10 120 python tools/probe_perf.py $B 2>&1 | grep -v amdgpu.ids >> $OUT/r3c.log || exit 1
