@@ -131,6 +131,7 @@ struct kl_handle {
   bool scan2_bf16 = true;       // KL_SCAN2_BF16=0: f32 instead of bf16 for what the scans exchange with later kernels (P, dH, c for backward)
   bool logits_ws = true;        // KL_LOGITS_WS = 0: GEMM + softmax kernel for the training window's output layer instead of the fused kernel
   bool proj_ws = true;          // KL_PROJ_WS = 0: the ring GEMM for the gate inputs P of the second-generation scans too
+  bool regtile = true;          // KL_REGTILE = 0: the backward scan's tiles by LDS-DMA at every size (else through registers from five blocks per step)
   bool scan3 = true;            // KL_SCAN3 = 0: the 16-wave backward scan of the second generation instead of the 8-wave one
   bool scan2_flags = true;      // KL_SCAN2_FLAGS = 0: the backward scan hands over by data sentinels at every size (else by flags from three blocks per step)
   bool flags_zeroed = false;
@@ -819,6 +820,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   if (env8i) h->logits_ws = atoi(env8i) != 0;
   const char* env8h = getenv("KL_PROJ_WS");
   if (env8h) h->proj_ws = atoi(env8h) != 0;
+  const char* env8k = getenv("KL_REGTILE");
+  if (env8k) h->regtile = atoi(env8k) != 0;
   const char* env8j = getenv("KL_SCAN3");
   if (env8j) h->scan3 = atoi(env8j) != 0;
   const char* env8g = getenv("KL_SCAN2_FLAGS");
@@ -1128,7 +1131,9 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       a.dZT = (!w.km_plan && BTp == BT && (B & 7) == 0) ? w.dZT : nullptr;
       a.ldt = BTp;
       a.db = grads + h->off_b[l];
-      int e = w.scan2_bwd ? (v3 ? kl_launch_scan_bwd_wide3(a, s) : kl_launch_scan_bwd_wide2(a, s)) : (h->wide_bwd ? kl_launch_scan_bwd_wide(a, s) : KL_ERR_SHAPE);
+      const bool rt = v3 && h->regtile && by_flags && kl_scan_wide2_phases(B, T, W, 16, 6) >= kl_scan_bwd_regtile_min_np();
+      int e = w.scan2_bwd ? (rt ? kl_launch_scan_bwd_regtile(a, s) : (v3 ? kl_launch_scan_bwd_wide3(a, s) : kl_launch_scan_bwd_wide2(a, s)))
+                          : (h->wide_bwd ? kl_launch_scan_bwd_wide(a, s) : KL_ERR_SHAPE);
       const bool wide = e == 0;
       if (e == KL_ERR_SHAPE && w.scan2_bwd) return KL_ERR_SHAPE;      // (the forward scans wrote gate-interleaved G: planned together, plan_scan2)
       if (e == KL_ERR_SHAPE) {
@@ -1140,7 +1145,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       if (e != 0) return e;
       if (l == L - 1) {
         h->trace_persistent[1] = true;
-        h->trace_name[1] = w.scan2_bwd ? (v3 ? "lstm_scan_bwd_wide3_kernel" : "lstm_scan_bwd_wide2_kernel") : (wide ? "lstm_scan_bwd_wide_kernel" : "lstm_scan_bwd_kernel");
+        h->trace_name[1] = w.scan2_bwd ? (rt ? "lstm_scan_bwd_regtile_kernel" : (v3 ? "lstm_scan_bwd_wide3_kernel" : "lstm_scan_bwd_wide2_kernel")) : (wide ? "lstm_scan_bwd_wide_kernel" : "lstm_scan_bwd_kernel");
         h->trace_flops[1] = (double)B * T * (2.0 * W * 4.0 * W);   // one layer's recurrent contraction
         h->trace_end(1, s);
       }

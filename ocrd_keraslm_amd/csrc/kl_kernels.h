@@ -194,6 +194,8 @@ int kl_scan_wide_blocks_per_wg(int B, int W);
 int kl_launch_scan_bwd_wide(KlScanBwd args, hipStream_t stream);   // one layer per launch, 64-unit workgroups
 int kl_launch_scan_bwd_wide2(KlScanBwd args, hipStream_t stream);
 int kl_launch_scan_bwd_wide3(KlScanBwd args, hipStream_t stream);   // third cut: eight waves, two cells per thread (same arguments)
+int kl_launch_scan_bwd_regtile(KlScanBwd args, hipStream_t stream);  // ... with the tile through registers, two blocks ahead (flags only)
+int kl_scan_bwd_regtile_min_np();
 int kl_scan_bwd_wide3_min_np_flags();                               // blocks per workgroup and step from which it can hand over by flags
 // output projection + softmax + CE + dlogits of a training window in one pass (V = 256, width 512); KL_ERR_SHAPE = not applicable
 int kl_launch_logits_ce_ws(const bf16_t* X, const bf16_t* E, const int* tgt, bf16_t* dlogits, float* rowstat, int B, int T, int W,

@@ -1443,7 +1443,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
 // LDS map (bytes): tile [2][64][1024] | zt [8 waves][584 words] (rows of 36 words: conflict-free partial-tile writes and
 // 8-byte epilogue reads) | pub [4 gates][16 rows][64 units] bf16 | flags | hand-off words [64]
 constexpr int B3_ZT_ROW = 36, B3_ZT_WAVE = 16 * 36 + 8;
-constexpr int bwd3_lds_bytes() { return 2 * 64 * 1024 + 8 * B3_ZT_WAVE * 4 + 4 * 16 * 64 * 2 + 16 + 256; }
+constexpr int bwd3_lds_bytes() { return 2 * 64 * 1024 + 8 * B3_ZT_WAVE * 4 + 4 * 16 * 64 * 2 + 16 + 512; }      // (two slots of hand-off words: the register-tile kernel)
 
 #define KL_B3_DECL register unsigned lb0_ asm("a0"), lb1_ asm("a1"), lb2_ asm("a2"), lb3_ asm("a3"), lb4_ asm("a4"), lb5_ asm("a5")
 #define KL_B3_REQ_G(g_base, g_off)                                                                                                 \
@@ -1799,6 +1799,331 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_bwd_wide3_kernel(const KlSca
   if (a.db) atomicAdd(a.db + (long)((tid & 255) >> 6) * W + u0 + (tid & 63), dbsum);
 }
 
+// ---------------------------------------------------------------- backward, register-landing tiles (five or more blocks per step)
+// lstm_scan_bwd_wide3_kernel with the dZ tile fetched through REGISTERS instead of LDS-DMA.  What the stamps of the LDS-DMA
+// form showed: 64 DMA pieces per block cost the CU's address unit ~2000 cycles (~32 per 1 KiB piece; a 1 KiB register load
+// passes in 16), they can only be requested once the target buffer is free -- behind the MFMA phase of the block that last
+// read it --, so they go out as one burst and land ~2000 cycles late.  Here every wave loads eight 1 KiB pieces of the tile
+// of the block AFTER NEXT into 32 accumulator registers (a8..a39) between the MFMAs of the current block -- two blocks
+// ahead, no LDS involved, so nothing has to be free --, and a block later, again between MFMAs, writes them into the LDS
+// buffer that has just been released (ds_write_b128 straight from the accumulator registers) and re-uses the registers for
+// the next tile.  The register file is the third tile buffer the LDS has no room for.
+//  * order inside a wave's queue: the eight tile loads of a block are issued BEFORE its three epilogue-input loads; loads
+//    return in order, so when the (armed, checked) inputs of block n have landed, the tile pieces requested in front of
+//    them have too -- and then nothing but stores is in flight, which makes the flag post an exact counted wait for every
+//    wave (all eight publish one 16-byte store per lane and post one word);
+//  * flags only (the launcher takes this kernel from five blocks per step on): a tile is requested two blocks before it is
+//    used and its flag was posted two blocks after its data.  The flag words of the tile to request come into LDS a block
+//    earlier (wave 7, right behind its post: older than that block's inputs in the queue, so the argument above covers them;
+//    two slots, so that the fetch never overwrites words another wave is still looking at).
+#define KL_B4_TILE_CLOBBER "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", \
+                           "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39"
+// piece k of this wave (registers a[8 + 4k : 11 + 4k]): out to LDS / in from memory (register names must be literal)
+#define KL_B4_PUT1(k_, K_, REGS_, addr_) if ((k_) == K_) asm volatile("ds_write_b128 %0, " REGS_ :: "v"(addr_) : "memory")
+#define KL_B4_GET1(k_, K_, REGS_, voff_, rsrc_, soff_) if ((k_) == K_) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 " REGS_ ", %0, %1, %2 offen sc1" :: "v"(voff_), "s"(rsrc_), "s"(soff_) : "memory", KL_B4_TILE_CLOBBER)
+#define KL_B4_PUT(k_, addr_)                                                                                                       \
+  do {                                                                                                                             \
+    KL_B4_PUT1(k_, 0, "a[8:11]", addr_); KL_B4_PUT1(k_, 1, "a[12:15]", addr_); KL_B4_PUT1(k_, 2, "a[16:19]", addr_); KL_B4_PUT1(k_, 3, "a[20:23]", addr_);   \
+    KL_B4_PUT1(k_, 4, "a[24:27]", addr_); KL_B4_PUT1(k_, 5, "a[28:31]", addr_); KL_B4_PUT1(k_, 6, "a[32:35]", addr_); KL_B4_PUT1(k_, 7, "a[36:39]", addr_); \
+  } while (0)
+#define KL_B4_GET(k_, voff_, rsrc_, soff_)                                                                                         \
+  do {                                                                                                                             \
+    KL_B4_GET1(k_, 0, "a[8:11]", voff_, rsrc_, soff_); KL_B4_GET1(k_, 1, "a[12:15]", voff_, rsrc_, soff_);                                 \
+    KL_B4_GET1(k_, 2, "a[16:19]", voff_, rsrc_, soff_); KL_B4_GET1(k_, 3, "a[20:23]", voff_, rsrc_, soff_);                                \
+    KL_B4_GET1(k_, 4, "a[24:27]", voff_, rsrc_, soff_); KL_B4_GET1(k_, 5, "a[28:31]", voff_, rsrc_, soff_);                                \
+    KL_B4_GET1(k_, 6, "a[32:35]", voff_, rsrc_, soff_); KL_B4_GET1(k_, 7, "a[36:39]", voff_, rsrc_, soff_);                                \
+  } while (0)
+
+template <int NP>
+__global__ __launch_bounds__(512, 1) void lstm_scan_bwd_regtile_kernel(const KlScanBwd a) {
+  static_assert(NP >= 5, "a tile is requested two blocks ahead of its use and posted two blocks behind its publish");
+  constexpr int KSTEPS = 16, W = 512, NWG_RB = W / 64, NPIECE = 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq4 = wave & 3, uh = wave >> 2;
+  const int n_rg = a.n_rg, B = a.B, T = a.T;
+  const int xcd = blockIdx.x & 7, yy = blockIdx.x >> 3;
+  const int cg = yy % NWG_RB, rq = yy / NWG_RB, rg = xcd * ((n_rg + 7) >> 3) + rq;
+  if (rg >= n_rg) return;
+  const int u0 = cg * 64;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const zt = reinterpret_cast<float*>(smem + 2 * NPIECE * 1024);
+  bf16_t* const pub = reinterpret_cast<bf16_t*>(smem + 2 * NPIECE * 1024 + 8 * B3_ZT_WAVE * 4);
+  int& ok_flag = *reinterpret_cast<int*>(smem + 2 * NPIECE * 1024 + 8 * B3_ZT_WAVE * 4 + 4 * 16 * 64 * 2);
+  constexpr int FL_OFF = 2 * NPIECE * 1024 + 8 * B3_ZT_WAVE * 4 + 4 * 16 * 64 * 2 + 16;
+  unsigned* const fl_l = reinterpret_cast<unsigned*>(smem + FL_OFF);
+  const unsigned lds_tile = (unsigned)(size_t)(lds_void_t*)smem;
+
+  u32x4 bu[2][KSTEPS];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const long wrow = (long)(u0 + uh * 32 + x * 16 + (lane & 15)) * 4 * W + (long)kq4 * W + (lane >> 4) * 8;
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j) bu[x][j] = *reinterpret_cast<const u32x4*>(a.Un[0] + wrow + j * 32);
+  }
+  const int er = 2 * wave + (lane >> 5), eu = 2 * (lane & 31);
+  const long BW = (long)B * W;
+  const bf16_t* Gl = a.G[0];
+  const float* Cl = a.C[0];
+  bf16_t* dZl = a.dZ[0];
+  const bf16_t* dHb = a.dHb;
+  const bf16_t* Cb = a.Cb;
+  const float* maskl = a.mask[0];
+  unsigned* status = a.status;
+  // (the dropout keep-masks of this thread's 2 NP cells as one bit each + their common scale: inverted dropout knows two
+  //  values, 0 and 1 / keep-probability (rating.py:146-152); a mask with other values is refused through the status word)
+  float dcr[NP][2], ccur[NP][2];
+  unsigned mbits = 0u;
+  float mscale = 1.f;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const long row = (long)(rg + p * n_rg) * 16 + er;
+    const float2 c2 = *reinterpret_cast<const float2*>(Cl + (long)T * BW + row * W + u0 + eu);
+    float2 m2 = float2{1.f, 1.f};
+    if (maskl) m2 = *reinterpret_cast<const float2*>(maskl + row * W + u0 + eu);
+    dcr[p][0] = dcr[p][1] = 0.f;
+    ccur[p][0] = c2.x; ccur[p][1] = c2.y;
+    mbits |= (m2.x != 0.f ? 1u : 0u) << (2 * p) | (m2.y != 0.f ? 2u : 0u) << (2 * p);
+    if (m2.x != 0.f) { if (mscale != 1.f && m2.x != mscale) a.status[0] = 1u; mscale = m2.x; }
+    if (m2.y != 0.f) { if (mscale != 1.f && m2.y != mscale) a.status[0] = 1u; mscale = m2.y; }
+  }
+  float dbsum = 0.f;
+  const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(dZl, (long)T * BW * 4 * 2);
+  const __amdgpu_buffer_rsrc_t rs_null = make_rsrc(dZl, 0);
+  unsigned* const flags = a.flags;
+  const unsigned epoch = *a.epoch;
+  const __amdgpu_buffer_rsrc_t rs_fl = make_rsrc(flags, (long)a.n_rb * 64 * 4);
+  bool alive = true;
+  if (tid == 0) ok_flag = 1;
+  if (tid < 128) fl_l[tid] = 0u;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j) asm volatile("" : "+v"(bu[x][j]));
+#pragma unroll
+  for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(ccur[p][0]), "+v"(ccur[p][1]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  SSTAMP_INIT(0);
+
+  // tile image in LDS as before (piece (gate quarter j, row r) = 1 KiB, chunk c of row r at position c ^ r); this wave moves
+  // the four quarters of rows 2w and 2w + 1: piece k = (quarter k >> 1, row 2w + (k & 1))
+  const unsigned src_lane0 = (unsigned)(((lane ^ (2 * wave)) & 63) * 16), src_lane1 = (unsigned)(((lane ^ (2 * wave + 1)) & 63) * 16);
+  const unsigned frag_lane = (unsigned)((lane & 15) * 1024 + (((lane >> 4) ^ (lane & 3)) * 16) + 64 * ((lane >> 2) & 3));
+  const unsigned in_g = (unsigned)((u0 + eu) * 8 + (lane >> 5) * W * 8), in_h = (unsigned)((u0 + eu) * 2 + (lane >> 5) * W * 2);
+  KL_B3_DECL;
+#define KL_B4_REQUEST(k_, t_, r0_)                                                                                                  \
+  do {                                                                                                                             \
+    const long trow_ = (long)(t_) * B + (r0_) + 2 * wave;                                                                          \
+    if (k_ == 0) KL_B3_REQ_G(Gl + trow_ * W * 4, in_g);                                                                            \
+    if (k_ == 1) KL_B3_REQ_CP(Cb + trow_ * W, in_h);                                                                               \
+    if (k_ == 2) KL_B3_REQ_DH(dHb + trow_ * W, in_h);                                                                              \
+  } while (0)
+  // piece k of the tile dZ[tt + 1], rows rr .. rr + 16: out of the landing registers into LDS buffer bb / in from memory
+#define KL_B4_PUT_PIECE(k_, bb_)                                                                                                    \
+  do {                                                                                                                             \
+    const unsigned la_ = lds_tile + (unsigned)(((bb_) * NPIECE + ((k_) >> 1) * 16 + 2 * wave + ((k_) & 1)) * 1024) + (unsigned)(lane * 16);   \
+    KL_B4_PUT(k_, la_);                                                                                                            \
+  } while (0)
+#define KL_B4_GET_PIECE(k_, tt_, rr_)                                                                                               \
+  do {                                                                                                                             \
+    const unsigned so_ = (unsigned)((((long)((tt_) + 1) * B + (rr_) + 2 * wave + ((k_) & 1)) * 4 * W + (long)((k_) >> 1) * W) * 2);  \
+    KL_B4_GET(k_, ((k_) & 1) ? src_lane1 : src_lane0, alive ? rs_own : rs_null, so_);                                              \
+  } while (0)
+  KL_B4_REQUEST(0, T - 1, rg * 16); KL_B4_REQUEST(1, T - 1, rg * 16); KL_B4_REQUEST(2, T - 1, rg * 16);
+
+  int n = 0;
+  bool loaded = false;      // the landing registers hold the tile of the NEXT block (requested during the block before this one)
+  for (int t = T - 1; t >= 0; --t) {
+#pragma unroll 1
+    for (int ip = 0; ip < NP; ++ip, ++n) {
+      const int buf = n & 1;
+      const int r0 = (rg + ip * n_rg) * 16;
+      int t1 = t, ip1 = ip + 1;
+      if (ip1 >= NP) { ip1 = 0; t1 = t - 1; }
+      int t2 = t1, ip2 = ip1 + 1;
+      if (ip2 >= NP) { ip2 = 0; t2 = t1 - 1; }
+      int t3 = t2, ip3 = ip2 + 1;
+      if (ip3 >= NP) { ip3 = 0; t3 = t2 - 1; }
+      const int r1 = (rg + ip1 * n_rg) * 16, r2 = (rg + ip2 * n_rg) * 16, r3 = (rg + ip3 * n_rg) * 16;
+      SSTAMP(16);
+      SSTAMP(25);
+      SSTAMP(17);
+      __syncthreads();
+      SSTAMP(18);
+      alive = __builtin_amdgcn_readfirstlane(ok_flag) != 0;
+      // ---- this block's epilogue inputs out of their landing registers; with them every load this wave has issued so far
+      // has landed (they were the last ones requested during the block before, and loads return in order): the tile pieces of
+      // the next block in a8..a39 too
+      // (polled, not waited for by count: a count of the operations issued since would also wait for OLDER stores -- the post of
+      //  the block before, a write-through store that takes longer than a block to be acknowledged)
+      unsigned gin[4], cpin, dhin;
+      {
+        bool got = false;
+        for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
+          KL_B3_READ(gin[0], gin[1], gin[2], gin[3], cpin, dhin);
+          if (!__any(max(max(max(gin[0], gin[1]), max(gin[2], gin[3])), max(cpin, dhin)) == 0xFFFFFFFFu)) { got = true; break; }
+#ifdef KL_STAMP
+          if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[29] += 1;
+#endif
+          if ((spin & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (!got) {
+          __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok_flag = 0;
+        }
+      }
+      if (n > 1) {
+        // Post the block before last: only stores are in flight now, they retire in order, and the two youngest -- the last
+        // block's publish and the post before this one (none yet in block 2) -- are all that may still be on their way
+        int tp = t, ipp = ip - 2;
+        if (ipp < 0) { ipp += NP; tp = t + 1; }
+        const int rbp = rg + ipp * n_rg;
+        wait_vm(n == 2 ? 1 : 2);
+        if (lane == 0)
+          __builtin_amdgcn_raw_buffer_store_b32(epoch - (unsigned)tp, alive ? rs_fl : rs_null, (rbp * 64 + cg * 8 + wave) * 4, 0, 16);
+      }
+      // the tile to request now (block n + 2: dZ[t2 + 1], rows r2) is there if its 64 flag words, fetched a block ago, say so
+      const bool want = t2 >= 0 && t2 < T - 1;
+      bool ready = want && alive;
+      if (ready) {
+        const unsigned far = (unsigned)(t2 + 1);      // (a word of this launch is at most T - 1 behind the epoch, one of an earlier launch at least T + 2)
+        ready = __all(epoch - *reinterpret_cast<const volatile unsigned*>(fl_l + (n & 1) * 64 + lane) <= far);
+        if (!ready) {      // not posted when the words were fetched: ask memory (rare; this wait drains the wave's queue)
+#ifdef KL_STAMP
+          if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[28] += 1;
+#endif
+          for (unsigned spin = 0; spin < SPIN_LIMIT && !ready; ++spin) {
+            const unsigned now = __hip_atomic_load(flags + (long)(r2 >> 4) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ready = __all(epoch - now <= far);
+            if (!ready) {
+              if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+              __builtin_amdgcn_s_sleep(2);
+            }
+          }
+          if (!ready) {
+            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok_flag = 0;
+          }
+        }
+      }
+      // the flag words of the tile the NEXT block will request (block n + 3), a block ahead of their use, into the other slot
+      // (last read during the block before this one)
+      if (wave == 7 && t3 >= 0 && t3 < T - 1) {
+        fl_l[((n + 1) & 1) * 64 + lane] = 0u;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        glds4_sc1_s(rs_fl, (unsigned)(lane * 4), (unsigned)((r3 >> 4) * 256), lds_tile + (unsigned)(FL_OFF + ((n + 1) & 1) * 256));
+      }
+      const bool put = loaded;                 // write the next block's tile into the buffer the block before this one released
+      const int tn = t1 >= 0 ? t1 : t, rn = t1 >= 0 ? r1 : r0;
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      // one slot per pair of MFMAs: piece k out to LDS and its registers re-used for the tile after next, then the inputs
+#define KL_B4_SLOT(q_)                                                                                                              \
+  do {                                                                                                                             \
+    if ((q_) < 8) {                                                                                                                \
+      if (put) KL_B4_PUT_PIECE((q_), buf ^ 1);                                                                                     \
+      if (ready) KL_B4_GET_PIECE((q_), t2, r2);                                                                                    \
+    }                                                                                                                              \
+    if ((q_) == 9) KL_B4_REQUEST(0, tn, rn);                                                                                       \
+    if ((q_) == 11) KL_B4_REQUEST(1, tn, rn);                                                                                      \
+    if ((q_) == 13) KL_B4_REQUEST(2, tn, rn);                                                                                      \
+  } while (0)
+      if (t < T - 1) {
+        const unsigned char* tb = smem + (buf * NPIECE + kq4 * 16) * 1024;
+        auto frag = [&](int q) __attribute__((always_inline)) -> u32x4 {
+          return *reinterpret_cast<const u32x4*>(tb + (frag_lane ^ (unsigned)(64 * (q >> 2))) + 256 * (q & 3));
+        };
+        u32x4 fr[4];
+        fr[0] = frag(0); fr[1] = frag(1); fr[2] = frag(2);
+#pragma unroll
+        for (int q = 0; q < KSTEPS; ++q) {
+          if (q + 3 < KSTEPS) fr[(q + 3) & 3] = frag(q + 3);
+          __builtin_amdgcn_sched_barrier(0);
+          const int j = 4 * (q & 3) + (q >> 2);
+          acc0 = mfma16(__builtin_bit_cast(bf16x8, fr[q & 3]), __builtin_bit_cast(bf16x8, bu[0][j]), acc0);
+          acc1 = mfma16(__builtin_bit_cast(bf16x8, fr[q & 3]), __builtin_bit_cast(bf16x8, bu[1][j]), acc1);
+          __builtin_amdgcn_sched_barrier(0);
+          KL_B4_SLOT(q);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < KSTEPS; ++q) KL_B4_SLOT(q);
+      }
+      loaded = ready;
+      {
+        float* zw = zt + wave * B3_ZT_WAVE + ((lane >> 4) * 4) * B3_ZT_ROW + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { zw[r * B3_ZT_ROW] = acc0[r]; zw[r * B3_ZT_ROW + 16] = acc1[r]; }
+      }
+      SSTAMP(19);
+      __syncthreads();
+      SSTAMP(20);
+      // ---- epilogue: thread = (row er, units eu and eu + 1)
+      float dzv[2][4];
+      {
+        const float* zr = zt + (eu >> 5) * 4 * B3_ZT_WAVE + er * B3_ZT_ROW + (eu & 31);
+        const float2 p0 = *reinterpret_cast<const float2*>(zr), p1 = *reinterpret_cast<const float2*>(zr + B3_ZT_WAVE);
+        const float2 p2 = *reinterpret_cast<const float2*>(zr + 2 * B3_ZT_WAVE), p3 = *reinterpret_cast<const float2*>(zr + 3 * B3_ZT_WAVE);
+        const float rec[2] = {(p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y)};
+        SSTAMP(21);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const unsigned g01 = gin[2 * c], g23 = gin[2 * c + 1];
+          const float gi = u2f(g01 << 16), gf = u2f(g01 & 0xffff0000u), gg = u2f(g23 << 16), go = u2f(g23 & 0xffff0000u);
+          const float cp = c ? u2f(cpin & 0xffff0000u) : u2f(cpin << 16);
+          const float dhi = c ? u2f(dhin & 0xffff0000u) : u2f(dhin << 16);
+          const float dh = dhi * (((mbits >> c) & 1u) ? mscale : 0.f) + rec[c];
+          const float tc = fast_tanh(ccur[0][c]);
+          const float dc = dh * go * (1.f - tc * tc) + dcr[0][c];
+          dcr[0][c] = dc * gf;
+          ccur[0][c] = cp;
+          const float d_o = dh * tc, d_i = dc * gg, d_g = dc * gi, d_f = dc * cp;
+          dzv[c][0] = d_i * gi * (1.f - gi);
+          dzv[c][1] = d_f * gf * (1.f - gf);
+          dzv[c][2] = d_g * (1.f - gg * gg);
+          dzv[c][3] = d_o * go * (1.f - go);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<unsigned*>(pub + (g * 16 + er) * 64 + eu) = (unsigned)f2bf(dzv[0][g]) | ((unsigned)f2bf(dzv[1][g]) << 16);
+      }
+      SSTAMP(22);
+      __syncthreads();
+      SSTAMP(23);
+      // ---- publish dZ[t] (all eight waves, one 16-byte write-through store per lane) and the bias gradient
+      {
+        int stid = tid;
+        asm volatile("" : "+v"(stid));
+        const int g = stid >> 7, prow = (stid >> 3) & 15, seg = stid & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(pub + (g * 16 + prow) * 64 + seg * 8);
+        const unsigned off = (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2);
+        store16_sc1(alive ? rs_own : rs_null, off, v);
+        if (alive) {
+          const bf16_t* col = pub + ((stid & 255) >> 6) * 1024 + (stid >> 8) * 512 + (stid & 63);
+          float sum = 0.f;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) sum += bf2f(col[r * 64]);
+          dbsum += sum;
+        }
+      }
+      SSTAMP(24);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float d0 = dcr[0][c], c0 = ccur[0][c];
+#pragma unroll
+        for (int p = 0; p + 1 < NP; ++p) { dcr[p][c] = dcr[p + 1][c]; ccur[p][c] = ccur[p + 1][c]; }
+        dcr[NP - 1][c] = d0; ccur[NP - 1][c] = c0;
+      }
+      mbits = (mbits >> 2) | ((mbits & 3u) << (2 * (NP - 1)));
+    }
+  }
+  SSTAMP_FLUSH();
+  if (a.db) atomicAdd(a.db + (long)((tid & 255) >> 6) * W + u0 + (tid & 63), dbsum);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- helpers of the gate-interleaved layouts
@@ -2063,6 +2388,29 @@ int kl_launch_scan_bwd_wide3(KlScanBwd a, hipStream_t stream) {
   }
 #undef KL_B3_CASE
 #undef KL_B3_CASE1
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+// register-landing tiles (lstm_scan_bwd_regtile_kernel): flags only, from this many blocks per workgroup and step
+int kl_scan_bwd_regtile_min_np() { return 5; }
+int kl_launch_scan_bwd_regtile(KlScanBwd a, hipStream_t stream) {
+  const int W = a.W;
+  const int np = kl_scan_wide2_phases(a.B, a.T, W, 16, 6);
+  if (np < kl_scan_bwd_regtile_min_np() || W != 512 || a.L != 1 || a.dZT || a.T < 3 || !a.flags || !a.epoch) return KL_ERR_SHAPE;
+  if (!a.Cb || !a.dHb) return KL_ERR_ARG;
+  a.n_rb = a.B / 16;
+  a.n_rg = a.n_rb / np;
+  dim3 grid(8 * (W / 64) * ((a.n_rg + 7) / 8)), block(512);
+  const size_t lds = (size_t)bwd3_lds_bytes();
+#define KL_B4_CASE(NP_)                                                                                                     \
+  do {                                                                                                                      \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_bwd_regtile_kernel<NP_>),                             \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;     \
+    hipLaunchKernelGGL((lstm_scan_bwd_regtile_kernel<NP_>), grid, block, lds, stream, a);                                   \
+  } while (0)
+  if (np == 5) KL_B4_CASE(5);
+  else KL_B4_CASE(6);
+#undef KL_B4_CASE
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 

@@ -20,9 +20,11 @@ TMP=$(mktemp -d /tmp/kl_agpr_XXXXXX)
 trap 'rm -rf "$TMP"' EXIT
 "$HIPCC" "$@" --cuda-device-only -emit-llvm -S "$SRC" -o "$TMP/dev.ll" 2> "$TMP/err" || { cat "$TMP/err" >&2; exit 1; }
 grep -v "argument unused during compilation" "$TMP/err" >&2 || true
-N=$(grep -c '^define .*lstm_scan_bwd_wide[23]_kernel' "$TMP/dev.ll" || true)
+N=$(grep -cE '^define .*lstm_scan_bwd_(wide[23]|regtile)_kernel' "$TMP/dev.ll" || true)
+# (8 accumulator registers: the epilogue inputs; 40: + the register-landing tile of lstm_scan_bwd_regtile_kernel)
 sed -E -i '/^define .*lstm_scan_bwd_wide[23]_kernel/ s/\) local_unnamed_addr (#[0-9]+)/) local_unnamed_addr \1 "amdgpu-agpr-alloc"="8,8"/' "$TMP/dev.ll"
-M=$(grep -c '"amdgpu-agpr-alloc"="8,8"' "$TMP/dev.ll" || true)
+sed -E -i '/^define .*lstm_scan_bwd_regtile_kernel/ s/\) local_unnamed_addr (#[0-9]+)/) local_unnamed_addr \1 "amdgpu-agpr-alloc"="40,40"/' "$TMP/dev.ll"
+M=$(grep -cE '"amdgpu-agpr-alloc"="(8,8|40,40)"' "$TMP/dev.ll" || true)
 if [ "$N" -lt 1 ] || [ "$N" != "$M" ]; then echo "build_agpr_tu: attribute set on $M of $N backward-scan kernels" >&2; exit 1; fi
 CG="-target amdgcn-amd-amdhsa -mcpu=$ARCH -O3 -Xclang -disable-llvm-optzns -mllvm -amdgpu-mfma-vgpr-form=1"
 "$LLVM/clang" $CG -S "$TMP/dev.ll" -o "$ASM"

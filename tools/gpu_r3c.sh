@@ -11,16 +11,8 @@ grep -v amdgpu.ids $OUT/r3c_tests.log | tail -5
 if [ $rc -ne 0 ]; then echo "tests rc=$rc: stopping"; exit $rc; fi
 echo "=== stamps B=3072" >> $OUT/r3c.log
 KL_LIB=ocrd_keraslm_amd/libkeraslm_hip_stamps.so timeout -k 10 200 python tools/probe_scan2_stamps.py 3072 2>&1 | grep -v amdgpu.ids >> $OUT/r3c.log || exit 1
-for v in ""; do
-  for fl in 1 0; do
-    echo "=== lib libkeraslm_hip$v.so B=3072 KL_SCAN2_FLAGS=$fl" >> $OUT/r3c.log
-    KL_SCAN2_FLAGS=$fl KL_LIB=ocrd_keraslm_amd/libkeraslm_hip$v.so KL_PROBE_TRACE=1 KL_PROBE_TRAIN_ONLY=1 timeout -k 10 120 python tools/probe_perf.py 3072 2>&1 | grep -v amdgpu.ids >> $OUT/r3c.log || exit 1
-  done
-done
-for B in 3072 2048 1536 1024; do
-  for s3 in 1 0; do
-    echo "=== shipped B=$B KL_SCAN3=$s3" >> $OUT/r3c.log
-    KL_SCAN3=$s3 KL_PROBE_TRACE=1 KL_PROBE_TRAIN_ONLY=1 timeout -k 10 120 python tools/probe_perf.py $B 2>&1 | grep -v amdgpu.ids >> $OUT/r3c.log || exit 1
-  done
+for e in "KL_REGTILE=1" "KL_REGTILE=0" "KL_SCAN2_FLAGS=0" "KL_SCAN3=0"; do
+  echo "=== B=3072 $e" >> $OUT/r3c.log
+  env $e KL_PROBE_TRACE=1 KL_PROBE_TRAIN_ONLY=1 timeout -k 10 120 python tools/probe_perf.py 3072 2>&1 | grep -v amdgpu.ids >> $OUT/r3c.log || exit 1
 done
 cat $OUT/r3c.log
