@@ -131,6 +131,7 @@ struct kl_handle {
   bool scan2_bf16 = true;       // KL_SCAN2_BF16=0: f32 instead of bf16 for what the scans exchange with later kernels (P, dH, c for backward)
   bool logits_ws = true;        // KL_LOGITS_WS = 0: GEMM + softmax kernel for the training window's output layer instead of the fused kernel
   bool proj_ws = true;          // KL_PROJ_WS = 0: the ring GEMM for the gate inputs P of the second-generation scans too
+  bool rt_local = true;         // KL_RT_LOCAL = 0: write-through publishes in the register-tile backward scan even where its partners share an XCD
   bool regtile = true;          // KL_REGTILE = 0: the backward scan's tiles by LDS-DMA at every size (else through registers from five blocks per step)
   bool scan3 = true;            // KL_SCAN3 = 0: the 16-wave backward scan of the second generation instead of the 8-wave one
   bool scan2_flags = true;      // KL_SCAN2_FLAGS = 0: the backward scan hands over by data sentinels at every size (else by flags from three blocks per step)
@@ -820,6 +821,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   if (env8i) h->logits_ws = atoi(env8i) != 0;
   const char* env8h = getenv("KL_PROJ_WS");
   if (env8h) h->proj_ws = atoi(env8h) != 0;
+  const char* env8l = getenv("KL_RT_LOCAL");
+  if (env8l) h->rt_local = atoi(env8l) != 0;
   const char* env8k = getenv("KL_REGTILE");
   if (env8k) h->regtile = atoi(env8k) != 0;
   const char* env8j = getenv("KL_SCAN3");
@@ -1132,6 +1135,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       a.ldt = BTp;
       a.db = grads + h->off_b[l];
       const bool rt = v3 && h->regtile && by_flags && kl_scan_wide2_phases(B, T, W, 16, 6) >= kl_scan_bwd_regtile_min_np();
+      if (rt) a.xcc_slots = h->rt_local ? w.scan_status + 4 : nullptr;
       int e = w.scan2_bwd ? (rt ? kl_launch_scan_bwd_regtile(a, s) : (v3 ? kl_launch_scan_bwd_wide3(a, s) : kl_launch_scan_bwd_wide2(a, s)))
                           : (h->wide_bwd ? kl_launch_scan_bwd_wide(a, s) : KL_ERR_SHAPE);
       const bool wide = e == 0;

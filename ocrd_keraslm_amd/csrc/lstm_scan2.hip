@@ -1905,6 +1905,14 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_bwd_regtile_kernel(const KlS
   for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(ccur[p][0]), "+v"(ccur[p][1]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // XCD-local hand-off: the eight workgroups that exchange a row group's tiles are dealt to ONE XCD by the grid mapping; where
+  // that is verified (posted XCC ids, kl_scan_common.h) the publishes are PLAIN stores that stay in that XCD's L2, where the
+  // partners' L1-bypassing loads find them at a fraction of the write-through round trip -- at ~2 us per tile load the CU's
+  // ~64 loads in flight were what bounded the scan.  Not verified: write-through stores as before.
+  bool local = false;
+  if (a.xcc_slots)
+    local = __builtin_amdgcn_readfirstlane(
+                xcd_local_group(a.xcc_slots, a.gen, NWG_RB, [&](int j) { return xcd + 8 * (rq * NWG_RB + j); }, &ok_flag + 1, status) ? 1 : 0) != 0;
   SSTAMP_INIT(0);
 
   // tile image in LDS as before (piece (gate quarter j, row r) = 1 KiB, chunk c of row r at position c ^ r); this wave moves
@@ -2022,28 +2030,29 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_bwd_regtile_kernel(const KlS
       // one slot per pair of MFMAs: piece k out to LDS and its registers re-used for the tile after next, then the inputs
 #define KL_B4_SLOT(q_)                                                                                                              \
   do {                                                                                                                             \
-    if ((q_) < 8) {                                                                                                                \
-      if (put) KL_B4_PUT_PIECE((q_), buf ^ 1);                                                                                     \
-      if (ready) KL_B4_GET_PIECE((q_), t2, r2);                                                                                    \
+    const int kk_ = (q_) < 11 ? ((q_) & 1 ? -1 : (q_) >> 1) : ((q_) == 11 ? 6 : ((q_) == 12 ? 7 : -1));                       \
+    if (kk_ >= 0) {                                                                                                                \
+      if (put) KL_B4_PUT_PIECE(kk_, buf ^ 1);                                                                                      \
+      if (ready) KL_B4_GET_PIECE(kk_, t2, r2);                                                                                     \
     }                                                                                                                              \
-    if ((q_) == 9) KL_B4_REQUEST(0, tn, rn);                                                                                       \
-    if ((q_) == 11) KL_B4_REQUEST(1, tn, rn);                                                                                      \
-    if ((q_) == 13) KL_B4_REQUEST(2, tn, rn);                                                                                      \
+    if ((q_) == 13) KL_B4_REQUEST(0, tn, rn);                                                                                      \
+    if ((q_) == 14) KL_B4_REQUEST(1, tn, rn);                                                                                      \
+    if ((q_) == 15) KL_B4_REQUEST(2, tn, rn);                                                                                      \
   } while (0)
       if (t < T - 1) {
         const unsigned char* tb = smem + (buf * NPIECE + kq4 * 16) * 1024;
         auto frag = [&](int q) __attribute__((always_inline)) -> u32x4 {
           return *reinterpret_cast<const u32x4*>(tb + (frag_lane ^ (unsigned)(64 * (q >> 2))) + 256 * (q & 3));
         };
-        u32x4 fr[4];
-        fr[0] = frag(0); fr[1] = frag(1); fr[2] = frag(2);
+        u32x4 fr[3];      // (fragments two k-steps ahead: a third one in flight did not fit the 216 VGPRs next to 40 accumulator registers)
+        fr[0] = frag(0); fr[1] = frag(1);
 #pragma unroll
         for (int q = 0; q < KSTEPS; ++q) {
-          if (q + 3 < KSTEPS) fr[(q + 3) & 3] = frag(q + 3);
+          if (q + 2 < KSTEPS) fr[(q + 2) % 3] = frag(q + 2);
           __builtin_amdgcn_sched_barrier(0);
           const int j = 4 * (q & 3) + (q >> 2);
-          acc0 = mfma16(__builtin_bit_cast(bf16x8, fr[q & 3]), __builtin_bit_cast(bf16x8, bu[0][j]), acc0);
-          acc1 = mfma16(__builtin_bit_cast(bf16x8, fr[q & 3]), __builtin_bit_cast(bf16x8, bu[1][j]), acc1);
+          acc0 = mfma16(__builtin_bit_cast(bf16x8, fr[q % 3]), __builtin_bit_cast(bf16x8, bu[0][j]), acc0);
+          acc1 = mfma16(__builtin_bit_cast(bf16x8, fr[q % 3]), __builtin_bit_cast(bf16x8, bu[1][j]), acc1);
           __builtin_amdgcn_sched_barrier(0);
           KL_B4_SLOT(q);
           __builtin_amdgcn_sched_barrier(0);
@@ -2100,7 +2109,8 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_bwd_regtile_kernel(const KlS
         const int g = stid >> 7, prow = (stid >> 3) & 15, seg = stid & 7;
         const uint4 v = *reinterpret_cast<const uint4*>(pub + (g * 16 + prow) * 64 + seg * 8);
         const unsigned off = (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2);
-        store16_sc1(alive ? rs_own : rs_null, off, v);
+        if (local) store16(alive ? rs_own : rs_null, off, 0u, v);
+        else store16_sc1(alive ? rs_own : rs_null, off, v);
         if (alive) {
           const bf16_t* col = pub + ((stid & 255) >> 6) * 1024 + (stid >> 8) * 512 + (stid & 63);
           float sum = 0.f;
