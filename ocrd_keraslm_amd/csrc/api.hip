@@ -133,7 +133,6 @@ struct kl_handle {
   bool proj_ws = true;          // KL_PROJ_WS = 0: the ring GEMM for the gate inputs P of the second-generation scans too
   bool rt_local = true;         // KL_RT_LOCAL = 0: write-through publishes in the register-tile backward scan even where its partners share an XCD
   bool regtile = true;          // KL_REGTILE = 0: the backward scan's tiles by LDS-DMA at every size (else through registers from five blocks per step)
-  bool scan3 = true;            // KL_SCAN3 = 0: the 16-wave backward scan of the second generation instead of the 8-wave one
   bool scan2_flags = true;      // KL_SCAN2_FLAGS = 0: the backward scan hands over by data sentinels at every size (else by flags from three blocks per step)
   bool flags_zeroed = false;
   bool fuse_wg = true;          // KL_FUSE_WG = 0: one launch per weight-gradient product (else products over the same dZ share a pass)
@@ -490,7 +489,7 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
         a.bias = P + h->off_b[0];
       }
       a.H = (bf16_t*)w.H[l]; a.C = w.C[l]; a.G = w.G[l];
-      a.Cb = (v2 && w.scan2_bwd) ? w.Cb[l] : nullptr;      // (the backward scan reads every cell state as bf16, blocks 0..T)
+      a.Cb = (v2 && w.scan2_bwd && h->scan2_bf16) ? w.Cb[l] : nullptr;      // (the backward scans read the cell states as bf16, blocks 0..T)
       a.Hd = masked ? w.Hd[l] : nullptr;
       a.mask = masked ? masks + (size_t)l * BW : nullptr;
       a.HT = w.km_plan ? nullptr : w.HTf[l]; a.ldt = (long)(T + 1) * B;       // (K-major GEMMs: no transposed outputs)
@@ -825,8 +824,6 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   if (env8l) h->rt_local = atoi(env8l) != 0;
   const char* env8k = getenv("KL_REGTILE");
   if (env8k) h->regtile = atoi(env8k) != 0;
-  const char* env8j = getenv("KL_SCAN3");
-  if (env8j) h->scan3 = atoi(env8j) != 0;
   const char* env8g = getenv("KL_SCAN2_FLAGS");
   if (env8g) h->scan2_flags = atoi(env8g) != 0;
   h->flags_zeroed = false;
@@ -1093,11 +1090,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       a.mask[0] = (masks != nullptr && l > 0) ? masks + (size_t)l * BW : nullptr;
       a.dH = w.dH;
       a.dHb = reinterpret_cast<const bf16_t*>(w.dH);
-      a.Cb = w.scan2_bwd ? w.Cb[l] : nullptr;
-      if (w.scan2_bwd) {      // the running dc of every cell between two steps lives in memory (lstm_scan_bwd_wide2_kernel): starts at zero
-        a.dc_state = w.dc0[l];
-        KL_TRY(kl_zero_async(w.dc0[l], (size_t)B * W * sizeof(float), s));
-      }
+      a.Cb = (w.scan2_bwd && h->scan2_bf16) ? w.Cb[l] : nullptr;
       a.counters = w.scan_cnt;
       a.status = w.scan_status + 1;
       // (sentinels pay with several row blocks per workgroup, where the next tile is prefetched; with one
@@ -1108,9 +1101,10 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       a.pf_mode = h->scan2_pfb >= 0 ? h->scan2_pfb : 1;
       a.xcc_slots = (a.sentinel && h->xcd_local_bwd) ? w.scan_status + 4 : nullptr;
       a.gen = (unsigned)(1 + L + l);
-      const bool v3 = w.scan2_bwd && h->scan3;
-      const bool by_flags = w.scan2_bwd && h->scan2_flags && h->flags_zeroed &&
-                            kl_scan_wide2_phases(B, T, W, 16, 6) >= (v3 ? kl_scan_bwd_wide3_min_np_flags() : 3);
+      const int np_b = w.scan2_bwd ? kl_scan_wide2_phases(B, T, W, 16, 6) : 0;
+      const bool by_flags = w.scan2_bwd && h->scan2_flags && h->flags_zeroed && np_b >= 3;
+      // (from five blocks per step: eight waves, the tile through registers two blocks ahead -- lstm_scan_bwd_regtile_kernel)
+      const bool rt = by_flags && h->regtile && h->scan2_bf16 && np_b >= kl_scan_bwd_regtile_min_np();
       if (by_flags) {
         // hand-off by flags (lstm_scan_bwd_wide2_kernel): nothing to arm, the epoch moves on
         a.flags = d.scan_flags;
@@ -1134,10 +1128,8 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       a.dZT = (!w.km_plan && BTp == BT && (B & 7) == 0) ? w.dZT : nullptr;
       a.ldt = BTp;
       a.db = grads + h->off_b[l];
-      const bool rt = v3 && h->regtile && by_flags && kl_scan_wide2_phases(B, T, W, 16, 6) >= kl_scan_bwd_regtile_min_np();
       if (rt) a.xcc_slots = h->rt_local ? w.scan_status + 4 : nullptr;
-      int e = w.scan2_bwd ? (rt ? kl_launch_scan_bwd_regtile(a, s) : (v3 ? kl_launch_scan_bwd_wide3(a, s) : kl_launch_scan_bwd_wide2(a, s)))
-                          : (h->wide_bwd ? kl_launch_scan_bwd_wide(a, s) : KL_ERR_SHAPE);
+      int e = w.scan2_bwd ? (rt ? kl_launch_scan_bwd_regtile(a, s) : kl_launch_scan_bwd_wide2(a, s)) : (h->wide_bwd ? kl_launch_scan_bwd_wide(a, s) : KL_ERR_SHAPE);
       const bool wide = e == 0;
       if (e == KL_ERR_SHAPE && w.scan2_bwd) return KL_ERR_SHAPE;      // (the forward scans wrote gate-interleaved G: planned together, plan_scan2)
       if (e == KL_ERR_SHAPE) {
@@ -1149,7 +1141,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       if (e != 0) return e;
       if (l == L - 1) {
         h->trace_persistent[1] = true;
-        h->trace_name[1] = w.scan2_bwd ? (rt ? "lstm_scan_bwd_regtile_kernel" : (v3 ? "lstm_scan_bwd_wide3_kernel" : "lstm_scan_bwd_wide2_kernel")) : (wide ? "lstm_scan_bwd_wide_kernel" : "lstm_scan_bwd_kernel");
+        h->trace_name[1] = w.scan2_bwd ? (rt ? "lstm_scan_bwd_regtile_kernel" : "lstm_scan_bwd_wide2_kernel") : (wide ? "lstm_scan_bwd_wide_kernel" : "lstm_scan_bwd_kernel");
         h->trace_flops[1] = (double)B * T * (2.0 * W * 4.0 * W);   // one layer's recurrent contraction
         h->trace_end(1, s);
       }

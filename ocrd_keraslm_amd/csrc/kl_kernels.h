@@ -185,7 +185,6 @@ struct KlScanBwd {
   const bf16_t* dHb;                   // second generation: the gradient from above as bf16 [T*B][W] (dH unused)
   const bf16_t* Cb;                    // second generation: cell states as bf16 [(T+1)B][W], blocks 1..T (null: C, f32)
   unsigned* flags; const unsigned* epoch;   // second generation: hand-off by flags [n_rb][64] instead of sentinels (null: sentinels); *epoch: this launch's
-  float* dc_state;                     // second generation: the running dc of every cell between two steps, [B][W] f32, ZEROED in front of the launch
 };
 int kl_launch_scan_epoch(unsigned* flags, int n_flags, unsigned* epoch, unsigned step, hipStream_t stream);   // epoch += step in front of a flag-mode scan
 int kl_launch_scan_bwd(KlScanBwd args, hipStream_t stream);
@@ -193,10 +192,10 @@ bool kl_scan_bwd_wide_applicable(int B, int T, int W);
 int kl_scan_wide_blocks_per_wg(int B, int W);
 int kl_launch_scan_bwd_wide(KlScanBwd args, hipStream_t stream);   // one layer per launch, 64-unit workgroups
 int kl_launch_scan_bwd_wide2(KlScanBwd args, hipStream_t stream);
-int kl_launch_scan_bwd_wide3(KlScanBwd args, hipStream_t stream);   // third cut: eight waves, two cells per thread (same arguments)
-int kl_launch_scan_bwd_regtile(KlScanBwd args, hipStream_t stream);  // ... with the tile through registers, two blocks ahead (flags only)
+// eight waves, two cells per thread, the tile through registers two blocks ahead (flags only; same arguments); from
+// kl_scan_bwd_regtile_min_np() blocks per workgroup and step
+int kl_launch_scan_bwd_regtile(KlScanBwd args, hipStream_t stream);
 int kl_scan_bwd_regtile_min_np();
-int kl_scan_bwd_wide3_min_np_flags();                               // blocks per workgroup and step from which it can hand over by flags
 // output projection + softmax + CE + dlogits of a training window in one pass (V = 256, width 512); KL_ERR_SHAPE = not applicable
 int kl_launch_logits_ce_ws(const bf16_t* X, const bf16_t* E, const int* tgt, bf16_t* dlogits, float* rowstat, int B, int T, int W,
                            int V, long ld_dl, float inv_count, int last_only, hipStream_t stream);

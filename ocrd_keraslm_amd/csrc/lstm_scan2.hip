@@ -1021,54 +1021,6 @@ __global__ __launch_bounds__(1024, 1) void logits_ce_ws_kernel(const KlLogitsCe 
 }
 
 // ---------------------------------------------------------------- backward
-// Epilogue inputs of the backward scan, a whole block ahead: they land in the ACCUMULATOR registers a0..a6.  These kernels
-// are built with 8 accumulator registers (function attribute "amdgpu-agpr-alloc"="8,8", set on the device IR by
-// tools/build_scan2.sh: HIP has no spelling for it, and without it the compiler halves the register budget as soon as an
-// AGPR is named).  The six are register variables of the kernel (`register unsigned x asm("a0")`) and every statement
-// that touches them takes them as operands, so the compiler sees them live from the request to the read-out a block later,
-// keeps its own temporaries out of them and never copies them (with -amdgpu-mfma-vgpr-form the MFMA accumulator stays in VGPRs): a load can stay in flight
-// around the loop's back-edge, which a compiler-chosen VGPR destination cannot (it was copied at the loop head before its
-// data had landed).  tools/audit_async_regs.py checks on the generated ISA that no compiler
-// instruction names an accumulator register.
-//   a[0:1] the four gates of this thread's cell (bf16)     a2 c_{t-1}, a3 c_t, a6 dH: zero-extended 16-bit loads, one register each
-//   (NOT two halves of one register by d16 loads: with SRAM ECC on -- gfx950's default -- a d16 load rewrites the whole register)
-//   a4 the running dc of this cell, kept in a [B][W] f32 array between the steps     a5 dropout mask
-// With the per-block state (dc, c_t) in memory instead of 2 x NP registers, and the bias gradient in one accumulator
-// instead of four, the kernel fits its 120 VGPRs at every NP without scratch.
-// Armed with all-ones before the request (no zero-extended halfword, no f32 datum here is that pattern), checked after the wait.
-#ifndef KL_BWD_VAR
-#define KL_BWD_VAR 0      /* timing experiments only (tools/gpu_variants.sh): 1 no bias-gradient atomics, 2 dc read without sc1, 4 no dc store */
-#endif
-#if KL_BWD_VAR & 2
-#define KL_BWD_DC_SC ""
-#else
-#define KL_BWD_DC_SC " sc1"
-#endif
-#define KL_BWD_INPUTS_DECL                                                                                                         \
-  register unsigned la0_ asm("a0"), la1_ asm("a1"), la2_ asm("a2"), la3_ asm("a3"), la4_ asm("a4"), la5_ asm("a5"), la6_ asm("a6")
-// (s_nop: the scalar ALU may have written a base a cycle ago, and nothing pads inside or in front of an asm statement)
-// (six statements, so that the kernel can spread them over its MFMA phase: the address unit takes ~16 cycles per wave
-//  instruction whatever its width, and sixteen waves issuing six loads each in one burst stood still for ~2000 cycles)
-#define KL_BWD_REQ_G(g_base, g_off)                                                                                                \
-  asm volatile("v_accvgpr_write_b32 a0, -1\n\tv_accvgpr_write_b32 a1, -1\n\tv_accvgpr_write_b32 a2, -1\n\t"                         \
-               "v_accvgpr_write_b32 a3, -1\n\tv_accvgpr_write_b32 a4, -1\n\tv_accvgpr_write_b32 a5, -1\n\t"                         \
-               "v_accvgpr_write_b32 a6, -1\n\ts_nop 4\n\tglobal_load_dwordx2 a[0:1], %7, %8"                                         \
-               : "=a"(la0_), "=a"(la1_), "=a"(la2_), "=a"(la3_), "=a"(la4_), "=a"(la5_), "=a"(la6_)                                \
-               : "v"(g_off), "s"(g_base) : "memory")
-#define KL_BWD_REQ_CP(c_base, h_off) asm volatile("s_nop 4\n\tglobal_load_ushort a2, %1, %2" : "+a"(la2_) : "v"(h_off), "s"(c_base) : "memory")
-#define KL_BWD_REQ_DH(dh_base, h_off) asm volatile("s_nop 4\n\tglobal_load_ushort a6, %1, %2" : "+a"(la6_) : "v"(h_off), "s"(dh_base) : "memory")
-#define KL_BWD_REQ_CT(c1_base, h_off) asm volatile("s_nop 4\n\tglobal_load_ushort a3, %1, %2" : "+a"(la3_) : "v"(h_off), "s"(c1_base) : "memory")
-#define KL_BWD_REQ_DC(dc_base, m_off) asm volatile("s_nop 4\n\tglobal_load_dword a4, %1, %2" KL_BWD_DC_SC : "+a"(la4_) : "v"(m_off), "s"(dc_base) : "memory")
-#define KL_BWD_REQ_MK(m_base, m_off) asm volatile("s_nop 4\n\tglobal_load_dword a5, %1, %2" : "+a"(la5_) : "v"(m_off), "s"(m_base) : "memory")
-#define KL_BWD_INPUTS_READ(g0, g1, cp, c1, dh, dc, mk)                                                                             \
-  asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\t"                            \
-               "v_accvgpr_read_b32 %3, a3\n\tv_accvgpr_read_b32 %4, a6\n\tv_accvgpr_read_b32 %5, a4\n\tv_accvgpr_read_b32 %6, a5"   \
-               : "=v"(g0), "=v"(g1), "=v"(cp), "=v"(c1), "=v"(dh), "=v"(dc), "=v"(mk)                                              \
-               : "a"(la0_), "a"(la1_), "a"(la2_), "a"(la3_), "a"(la4_), "a"(la5_), "a"(la6_) : "memory")
-__device__ __forceinline__ bool bwd_inputs_missing(unsigned g0, unsigned g1, unsigned cp, unsigned c1, unsigned dh, unsigned dc, unsigned mk) {
-  return max(max(max(g0, g1), max(dc, mk)), max(max(cp, c1), dh)) == 0xFFFFFFFFu;
-}
-
 // LDS map (bytes): tile [2][4*KSTEPS][1024] | zt [16 waves][16][17] f32 | pub [4 gates][16 rows][64 units] bf16 | flags | hand-off words [64]
 constexpr int bwd2_lds_bytes(int ksteps) { return 2 * 4 * ksteps * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16 + 256; }
 
@@ -1115,16 +1067,18 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
   const bf16_t* Cb = a.Cb;
   const float* maskl = a.mask[0];
   unsigned* status = a.status;
-  // Per-cell state between the steps lives in memory, not in 2 x NP registers: the running dc in a.dc_state [B][W] f32
-  // (zeroed in front of the launch; read back NP blocks after it was written, by the thread that wrote it), c_t from the
-  // bf16 cell states the forward scan left (block t + 1).  The bias gradient is summed by four otherwise idle waves from the
-  // staged tile (below).
-  float dbsum = 0.f;      // (waves 8..11: the bias gradient of column (gate, unit) = tid - 512)
-  float* const dcs = a.dc_state;
-  (void)Cl;
+  // per block of this workgroup (slot 0 = the current one: rotated): running dc, the cell state c_t of the step
+  // being processed (the c_{t-1} loaded for step t is the c_t of step t-1), the dropout mask on dH
+  float dcr[NP], ccur[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const long row = (long)(rg + p * n_rg) * 16 + er;
+    dcr[p] = 0.f;
+    ccur[p] = Cl[(long)T * BW + row * W + u0 + eu];
+  }
+  float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
   const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(dZl, (long)T * BW * 4 * 2);
   const __amdgpu_buffer_rsrc_t rs_null = make_rsrc(dZl, 0);
-  const __amdgpu_buffer_rsrc_t rs_dc = make_rsrc(dcs, (long)B * W * 4);
   // Hand-off by flags (a.flags; NP >= 3): each publishing wave posts "my rows of step t are in memory" as the number
   // epoch - t in its own word, flags[row block][column group * 8 + wave], once its stores have completed -- which it
   // learns for free half a block later, where it waits for its epilogue inputs anyway.  A consumer looks at the 64
@@ -1138,6 +1092,8 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
   if (tid == 0) ok_flag = 1;
 #pragma unroll
   for (int j = 0; j < KSTEPS; ++j) asm volatile("" : "+v"(bu[j]));
+#pragma unroll
+  for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(ccur[p]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   bool local = false;      // XCD-local hand-off (opt-in), as in the forward scan
@@ -1171,29 +1127,6 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
   // the top of the block they belong to and consumed behind its MFMA phase.  They are NOT carried around the loop:
   // a loop-carried asm destination was copied by the compiler at the loop head before its data had landed.
   const unsigned in_lane4 = (unsigned)((u0 + eu) * 4);
-  KL_BWD_INPUTS_DECL;
-  // (of the block (t_, r0_): this thread's row er, unit u0 + eu; a macro because a register variable cannot be captured.
-  //  Without a dropout mask the sixth load reads the thread's own dc word again and the value is ignored: every statement
-  //  runs on every path, so the landing registers have ONE definition per block and the compiler has nothing to merge.)
-#define KL_REQUEST_INPUT(k_, t_, r0_)                                                                                                \
-  do {                                                                                                                             \
-    const long trow_ = (long)(t_) * B + (r0_) + er;                                                                                \
-    const float* dcrow_ = dcs + (long)((r0_) + er) * W;                                                                            \
-    if (k_ == 0) KL_BWD_REQ_G(Gl + trow_ * W * 4, in_lane4 * 2);                                                                   \
-    if (k_ == 1) KL_BWD_REQ_CP(Cb + trow_ * W, in_lane4 >> 1);                                                                     \
-    if (k_ == 2) KL_BWD_REQ_DH(dHb + trow_ * W, in_lane4 >> 1);                                                                    \
-    if (k_ == 3) KL_BWD_REQ_CT(Cb + (trow_ + B) * W, in_lane4 >> 1);                                                               \
-    if (k_ == 4) KL_BWD_REQ_DC(dcrow_, in_lane4);                                                                                  \
-    if (k_ == 5) KL_BWD_REQ_MK(maskl ? maskl + (long)((r0_) + er) * W : dcrow_, in_lane4);                                         \
-    ++vq;                                                                                                                          \
-    if (k_ == 5) seq_in = vq;                                                                                                      \
-  } while (0)
-#define KL_REQUEST_INPUTS(t_, r0_)                                                                                                  \
-  do {                                                                                                                             \
-    KL_REQUEST_INPUT(0, t_, r0_); KL_REQUEST_INPUT(1, t_, r0_); KL_REQUEST_INPUT(2, t_, r0_);                                      \
-    KL_REQUEST_INPUT(3, t_, r0_); KL_REQUEST_INPUT(4, t_, r0_); KL_REQUEST_INPUT(5, t_, r0_);                                      \
-  } while (0)
-  KL_REQUEST_INPUTS(T - 1, rg * 16);
   int n = 0;
   for (int t = T - 1; t >= 0; --t) {
 #pragma unroll 1
@@ -1206,7 +1139,26 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
       if (ip2 >= NP) { ip2 = 0; t2 = t1 - 1; }
       const int r1 = (rg + ip1 * n_rg) * 16, r2 = (rg + ip2 * n_rg) * 16;
       SSTAMP(16);
-      // (the epilogue inputs of this block were requested a block ago, into a4..a7: bwd_inputs_request)
+      // Epilogue inputs of this block (gates 8 bytes, c_{t-1} and dh as bf16 or f32, the dropout mask on dH): asm loads of THIS
+      // iteration into compiler registers armed with all-ones (which no valid datum is: a 16-bit load zero-extends),
+      // consumed behind the MFMA phase.  They are not carried around the loop -- a loop-carried asm destination was copied
+      // by the compiler at the loop head before its data had landed -- and not kept in registers "reserved" from the
+      // compiler either: hipcc honoured neither amdgpu_num_vgpr nor asm clobbers once a variant needed the registers.
+      u32x2 gin = u32x2{0xFFFFFFFFu, 0xFFFFFFFFu};
+      unsigned cpin = 0xFFFFFFFFu, dhin = 0xFFFFFFFFu, mkin = maskl ? 0xFFFFFFFFu : 0x3f800000u;      // (no mask: 1.0f)
+      {
+        const long trow = (long)t * B + r0 + er;
+        aload8_glb(gin, Gl + trow * W * 4, in_lane4 * 2);
+        if (Cb && t > 0) aload2_glb(cpin, Cb + trow * W, in_lane4 >> 1);
+        else aload4_glb(cpin, Cl + trow * W, in_lane4);
+        aload2_glb(dhin, dHb + trow * W, in_lane4 >> 1);
+        vq += 3;
+        if (maskl) {
+          aload4_glb(mkin, maskl + (long)(r0 + er) * W, in_lane4);
+          ++vq;
+        }
+        seq_in = vq;
+      }
       // (flags: the 64 words of the next block's rows come into LDS -- armed with 0 = "not yet" -- and are looked at behind
       //  the MFMAs; the last wave fetches them, it publishes nothing)
       // (a.pf_mode 2: the tile of the block after next is asked for -- into the buffer this block's MFMAs leave --, a block and
@@ -1264,24 +1216,6 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
       __syncthreads();
       SSTAMP(18);
       alive = __builtin_amdgcn_readfirstlane(ok_flag) != 0;
-      // ---- this block's epilogue inputs out of their landing registers (requested during the MFMA phase of the block before),
-      // and the next block's requests spread over this block's MFMAs (the very last block asks for its own rows again: every
-      // statement runs on every path, the landing registers never see a conditional definition)
-      wait_vm(vq - seq_in);
-      unsigned gin0, gin1, cpin, c1in, dhin, dcin, mkin;
-      KL_BWD_INPUTS_READ(gin0, gin1, cpin, c1in, dhin, dcin, mkin);
-      if (__any(bwd_inputs_missing(gin0, gin1, cpin, c1in, dhin, dcin, mkin))) {
-#ifdef KL_STAMP
-        if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[29] += 1;
-#endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        KL_BWD_INPUTS_READ(gin0, gin1, cpin, c1in, dhin, dcin, mkin);
-        if (__any(bwd_inputs_missing(gin0, gin1, cpin, c1in, dhin, dcin, mkin))) {      // (nothing in flight any more: the data itself is bad)
-          __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok_flag = 0;
-        }
-      }
-      const int tn = t1 >= 0 ? t1 : t, rn = t1 >= 0 ? r1 : r0;
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       if (t < T - 1) {
         // (k-step order and read-ahead as in the forward scan)
@@ -1297,16 +1231,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
           __builtin_amdgcn_sched_barrier(0);
           acc = mfma16(__builtin_bit_cast(bf16x8, fr[q & 1]), __builtin_bit_cast(bf16x8, bu[4 * (q & 3) + (q >> 2)]), acc);
           __builtin_amdgcn_sched_barrier(0);
-          if (q == 1) KL_REQUEST_INPUT(0, tn, rn);
-          if (q == 3) KL_REQUEST_INPUT(1, tn, rn);
-          if (q == 5) KL_REQUEST_INPUT(2, tn, rn);
-          if (q == 7) KL_REQUEST_INPUT(3, tn, rn);
-          if (q == 9) KL_REQUEST_INPUT(4, tn, rn);
-          if (q == 11) KL_REQUEST_INPUT(5, tn, rn);
-          __builtin_amdgcn_sched_barrier(0);
         }
-      } else {
-        KL_REQUEST_INPUTS(tn, rn);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) zt[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
@@ -1356,24 +1281,44 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
       if (!FLAGS && a.pf_mode == 2 && alive && t2 >= 0 && t2 < T - 1) issue_tile(t2, r2, buf);         // (every wave has finished this block's MFMAs)
       // ---- epilogue: thread = (row er, unit eu)
       // (loads and stores retire independently, so the count is an estimate: the armed registers are checked)
-      const float gi = bf2f((bf16_t)(gin0 & 0xffffu)), gf = bf2f((bf16_t)(gin0 >> 16));
-      const float gg = bf2f((bf16_t)(gin1 & 0xffffu)), go = bf2f((bf16_t)(gin1 >> 16));
-      const float cp = u2f(cpin << 16);
+      wait_vm(vq - seq_in);
+      use_regs(gin);
+      use_regs(cpin);
+      use_regs(dhin);
+      use_regs(mkin);
+      if (__any(max(max(gin.x, gin.y), max(cpin, max(dhin, mkin))) == 0xFFFFFFFFu)) {
+#ifdef KL_STAMP
+        if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[29] += 1;
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        use_regs(gin);
+        use_regs(cpin);
+        use_regs(dhin);
+        use_regs(mkin);
+        // (nothing is in flight any more: registers that are STILL all-ones never received their data -- e.g. a destination the
+        //  compiler moved; tools/audit_async_regs.py looks for that in the ISA, this is the run-time net)
+        if (__any(max(max(gin.x, gin.y), max(cpin, max(dhin, mkin))) == 0xFFFFFFFFu)) {
+          __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok_flag = 0;
+        }
+      }
+      const float gi = bf2f((bf16_t)(gin.x & 0xffffu)), gf = bf2f((bf16_t)(gin.x >> 16));
+      const float gg = bf2f((bf16_t)(gin.y & 0xffffu)), go = bf2f((bf16_t)(gin.y >> 16));
+      const float cp = (Cb && t > 0) ? u2f(cpin << 16) : u2f(cpin);
       float dh = u2f(dhin << 16);
-      const float ct = u2f(c1in << 16), dc_run = u2f(dcin);
-      const float mk = maskl ? u2f(mkin) : 1.f;
       SSTAMP(21);
       const int wz = (eu >> 4) * 4;      // the four K-quarter waves of this unit group
-      dh = dh * mk + (zt[wz][er][eu & 15] + zt[wz + 1][er][eu & 15] + zt[wz + 2][er][eu & 15] + zt[wz + 3][er][eu & 15]);
-      const float tc = fast_tanh(ct);
-      const float dc = dh * go * (1.f - tc * tc) + dc_run;
-      // the running dc of this cell for the step before: read back a whole step (NP blocks) from now
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dc * gf), (alive && !(KL_BWD_VAR & 4)) ? rs_dc : rs_null, (int)(in_lane4 + (unsigned)(er * W * 4)),
-                                            (int)(unsigned)(r0 * W * 4), 0);
-      ++vq;
+      dh = dh * u2f(mkin) + (zt[wz][er][eu & 15] + zt[wz + 1][er][eu & 15] + zt[wz + 2][er][eu & 15] + zt[wz + 3][er][eu & 15]);
+      const float tc = fast_tanh(ccur[0]);
+      const float dc = dh * go * (1.f - tc * tc) + dcr[0];
+      dcr[0] = dc * gf;
+      ccur[0] = cp;
       const float d_o = dh * tc, d_i = dc * gg, d_g = dc * gi, d_f = dc * cp;
       const unsigned z0 = f2bf(d_i * gi * (1.f - gi)), z1 = f2bf(d_f * gf * (1.f - gf));
       const unsigned z2 = f2bf(d_g * (1.f - gg * gg)), z3 = f2bf(d_o * go * (1.f - go));
+      if (alive) {
+        dbacc[0] += bf2f((bf16_t)z0); dbacc[1] += bf2f((bf16_t)z1); dbacc[2] += bf2f((bf16_t)z2); dbacc[3] += bf2f((bf16_t)z3);
+      }
       pub[(0 * 16 + er) * 64 + eu] = (bf16_t)z0;
       pub[(1 * 16 + er) * 64 + eu] = (bf16_t)z1;
       pub[(2 * 16 + er) * 64 + eu] = (bf16_t)z2;
@@ -1403,45 +1348,62 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
         }
         vq += 2;
       }
-      // ---- bias gradient: waves 8..11 (idle while waves 0..7 publish) sum the staged tile's columns over its sixteen rows;
-      // thread = (gate, unit), ONE accumulator register (four per thread when every thread kept its own cell's; LDS float
-      // atomics from all sixteen waves onto the same 256 words cost 7000 cycles per block)
-      if (wave >= 8 && wave < 12 && alive && !(KL_BWD_VAR & 1)) {
-        const bf16_t* col = pub + (tid - 512 + ((tid - 512) >> 6) * 15 * 64);      // pub[(g * 16 + r) * 64 + u], g = (tid - 512) >> 6, u = tid & 63
-        float sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sum += bf2f(col[r * 64]);
-        dbsum += sum;
-      }
       SSTAMP(24);
+      if (NP > 1) {
+        const float d0 = dcr[0], c0 = ccur[0];
+#pragma unroll
+        for (int p = 0; p + 1 < NP; ++p) { dcr[p] = dcr[p + 1]; ccur[p] = ccur[p + 1]; }
+        dcr[NP - 1] = d0;
+        ccur[NP - 1] = c0;
+      }
     }
   }
   SSTAMP_FLUSH();
-  // db[g*W + u] += sum over this workgroup's rows and all steps
-  if (a.db && wave >= 8 && wave < 12) atomicAdd(a.db + (long)((tid - 512) >> 6) * W + u0 + (tid & 63), dbsum);
+  // db[g*W + u] += sum over this workgroup's rows and all steps (16 partials per column meet in LDS)
+  if (a.db) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);     // [4 gates][16 rows][64 units]
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[(g * 16 + er) * 64 + eu] = dbacc[g];
+    __syncthreads();
+    if (tid < 256) {
+      const int g = tid >> 6, u = tid & 63;
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += red[(g * 16 + r) * 64 + u];
+      atomicAdd(a.db + (long)g * W + u0 + u, sum);
+    }
+  }
 }
 
-// ---------------------------------------------------------------- backward, third cut: eight waves, two cells per thread
-// Same grid, hand-off and tile image as lstm_scan_bwd_wide2_kernel, re-cut around what round 3's stamps showed: the address
-// unit takes ~16 cycles per vector-memory wave instruction whatever its width, so 16 waves x (4 tile pieces + 3..6 two- and
-// four-byte input loads + stores) kept it busy for 2400-3000 cycles per 16-row block, in bursts; the LDS served the same
-// 1 KiB fragment to four waves (one MFMA per read); and the 128 registers of a 1024-thread workgroup left no room for
-// anything in flight.  Here:
+
+// ---------------------------------------------------------------- backward, eight waves with the tile through registers
+// (five or more 16-row blocks per workgroup and step; below that the 16-wave kernel above)
+// What round 3's stamps of the 16-wave kernel showed: the address unit takes ~16 cycles per vector-memory wave instruction
+// whatever its width (~32 for a 1 KiB LDS-DMA piece), so 16 waves x (4 tile pieces + 3..4 two- and four-byte input loads +
+// stores) kept it busy for 2400-3000 cycles per block, in bursts; the LDS served the same 1 KiB fragment to four waves (one
+// MFMA per read); the epilogue inputs, requested at the top of the block they belong to, arrived 1500-2200 cycles late; and
+// the 128 registers of a 1024-thread workgroup left no room for anything in flight.  Here:
 //  * 512 threads, 256 registers each: wave = (gate quarter of K, 32 units) -- every 1 KiB fragment read feeds two MFMAs with
-//    independent accumulators, the fragment reads per block halve, and the read-ahead is three k-steps deep;
+//    independent accumulators, the fragment reads per block halve;
 //  * an epilogue thread owns TWO neighbouring units of one row: its inputs come as 16 + 4 + 4 bytes (gates, c_{t-1}, dH) --
-//    24 wave instructions per block instead of 64-96 -- into accumulator registers a0..a5, requested a whole block ahead
-//    between the MFMAs of the block before (KL_B3_*; see KL_BWD_INPUTS_* above for how they stay out of the compiler's way);
-//  * the per-slot state (running dc, c_t, dropout mask: 6 x NP registers) is back in registers, where there is room now;
-//  * waves 0..3 publish (two 16-byte write-through stores per lane) and post the flags, waves 4..7 fetch the tiles (sixteen
-//    1 KiB pieces each): a publishing wave then has NOTHING but stores in flight once its epilogue inputs have been seen to
-//    have landed, and stores retire in order -- so "the block before last has reached memory" is an exact counted wait
-//    (s_waitcnt vmcnt(3)) instead of a drain, which at this block length (~2 us against a write-through acknowledgement
-//    of ~3 us) would stall every block.  A flag is therefore posted two blocks after its data: five or more blocks per
-//    step (the launcher's rule for flags) leave that time;
-//  * all eight waves sum the bias gradient from the staged tile.
+//    24 wave instructions per block instead of 64 -- into ACCUMULATOR registers a0..a5, requested a whole block ahead between
+//    the MFMAs of the block before.  Accumulator registers, because a load in flight around the loop's back-edge must land
+//    where the compiler never looks: a compiler-chosen VGPR destination was copied at the loop head before its data had
+//    landed.  These kernels are built with a fixed number of accumulator registers (function attribute
+//    "amdgpu-agpr-alloc", set on the device IR by tools/build_agpr_tu.sh: HIP has no spelling for it, and without it the
+//    compiler halves the register budget as soon as an AGPR is named) and with -amdgpu-mfma-vgpr-form (the MFMA accumulator
+//    stays in VGPRs); the six are register variables of the kernel (`register unsigned x asm("a0")`) that every statement
+//    touching them takes as operands, so the compiler sees them live from the request to the read-out a block later and
+//    neither re-uses nor copies them.  tools/audit_async_regs.py checks on the generated ISA that no compiler instruction
+//    names an accumulator register.  They are armed with all-ones before a request and polled at the read-out.
+//    (NOT two halves of one register by d16 loads: with SRAM ECC on -- gfx950's default -- a d16 load rewrites the whole register.)
+//  * the per-slot state (running dc, c_t: 4 x NP registers, the dropout mask as a bit per cell) stays in registers.
 // LDS map (bytes): tile [2][64][1024] | zt [8 waves][584 words] (rows of 36 words: conflict-free partial-tile writes and
-// 8-byte epilogue reads) | pub [4 gates][16 rows][64 units] bf16 | flags | hand-off words [64]
+// 8-byte epilogue reads) | pub [4 gates][16 rows][64 units] bf16 | flags | hand-off words [2][64]
+#ifndef KL_BWD_VAR
+#define KL_BWD_VAR 0      /* timing experiments only (tools/gpu_variants.sh): 8 no tile writes to LDS, 16 no tile loads, 32 no MFMAs, 64 no fragment reads */
+#endif
 constexpr int B3_ZT_ROW = 36, B3_ZT_WAVE = 16 * 36 + 8;
 constexpr int bwd3_lds_bytes() { return 2 * 64 * 1024 + 8 * B3_ZT_WAVE * 4 + 4 * 16 * 64 * 2 + 16 + 512; }      // (two slots of hand-off words: the register-tile kernel)
 
@@ -1459,379 +1421,52 @@ constexpr int bwd3_lds_bytes() { return 2 * 64 * 1024 + 8 * B3_ZT_WAVE * 4 + 4 *
                : "=v"(g0), "=v"(g1), "=v"(g2), "=v"(g3), "=v"(cp), "=v"(dh)                                                        \
                : "a"(lb0_), "a"(lb1_), "a"(lb2_), "a"(lb3_), "a"(lb4_), "a"(lb5_) : "memory")
 
-template <int NP, bool FLAGS>
-__global__ __launch_bounds__(512, 1) void lstm_scan_bwd_wide3_kernel(const KlScanBwd a) {
-  constexpr int KSTEPS = 16, W = 512, NWG_RB = W / 64, NPIECE = 64, JW = 16;      // (JW: tile pieces per DMA wave = 4 quarters x 4 rows)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kq4 = wave & 3, uh = wave >> 2;
-  const int n_rg = a.n_rg, B = a.B, T = a.T;
-  const int xcd = blockIdx.x & 7, yy = blockIdx.x >> 3;
-  const int cg = yy % NWG_RB, rq = yy / NWG_RB, rg = xcd * ((n_rg + 7) >> 3) + rq;
-  if (rg >= n_rg) return;
-  const int u0 = cg * 64;
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* const zt = reinterpret_cast<float*>(smem + 2 * NPIECE * 1024);
-  bf16_t* const pub = reinterpret_cast<bf16_t*>(smem + 2 * NPIECE * 1024 + 8 * B3_ZT_WAVE * 4);
-  int& ok_flag = *reinterpret_cast<int*>(smem + 2 * NPIECE * 1024 + 8 * B3_ZT_WAVE * 4 + 4 * 16 * 64 * 2);
-  constexpr int FL_OFF = 2 * NPIECE * 1024 + 8 * B3_ZT_WAVE * 4 + 4 * 16 * 64 * 2 + 16;
-  unsigned* const fl_l = reinterpret_cast<unsigned*>(smem + FL_OFF);
-  const unsigned lds_tile = (unsigned)(size_t)(lds_void_t*)smem;
-
-  // resident weights: B fragments of this wave's two 16-unit tiles, its gate quarter of K
-  u32x4 bu[2][KSTEPS];
-#pragma unroll
-  for (int x = 0; x < 2; ++x) {
-    const long wrow = (long)(u0 + uh * 32 + x * 16 + (lane & 15)) * 4 * W + (long)kq4 * W + (lane >> 4) * 8;
-#pragma unroll
-    for (int j = 0; j < KSTEPS; ++j) bu[x][j] = *reinterpret_cast<const u32x4*>(a.Un[0] + wrow + j * 32);
-  }
-  // epilogue thread = (row er of the block, units eu and eu + 1 of the workgroup's 64)
-  const int er = 2 * wave + (lane >> 5), eu = 2 * (lane & 31);
-  const long BW = (long)B * W;
-  const bf16_t* Gl = a.G[0];
-  const float* Cl = a.C[0];
-  bf16_t* dZl = a.dZ[0];
-  const bf16_t* dHb = a.dHb;
-  const bf16_t* Cb = a.Cb;
-  const float* maskl = a.mask[0];
-  unsigned* status = a.status;
-  // per block slot of this workgroup (slot 0 = the current one: rotated) and cell: running dc, the cell state c_t of the
-  // step being processed (the c_{t-1} loaded for step t is the c_t of step t - 1), the dropout keep-mask on dH
-  float dcr[NP][2], ccur[NP][2], mkr[NP][2];
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    const long row = (long)(rg + p * n_rg) * 16 + er;
-    const float2 c2 = *reinterpret_cast<const float2*>(Cl + (long)T * BW + row * W + u0 + eu);
-    float2 m2 = float2{1.f, 1.f};
-    if (maskl) m2 = *reinterpret_cast<const float2*>(maskl + row * W + u0 + eu);
-    dcr[p][0] = dcr[p][1] = 0.f;
-    ccur[p][0] = c2.x; ccur[p][1] = c2.y;
-    mkr[p][0] = m2.x; mkr[p][1] = m2.y;
-  }
-  float dbsum = 0.f;      // bias gradient of column (gate, unit) = tid & 255, rows 8 (tid >> 8) .. + 8 of every block
-  const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(dZl, (long)T * BW * 4 * 2);
-  const __amdgpu_buffer_rsrc_t rs_null = make_rsrc(dZl, 0);
-  // (hand-off by flags or rolling sentinels: see lstm_scan_bwd_wide2_kernel; here all eight waves publish and post)
-  unsigned* const flags = FLAGS ? a.flags : nullptr;
-  const unsigned epoch = FLAGS ? *a.epoch : 0u;
-  const __amdgpu_buffer_rsrc_t rs_fl = make_rsrc(flags, FLAGS ? (long)a.n_rb * 64 * 4 : 0);
-  bool alive = true;
-  if (tid == 0) ok_flag = 1;
-#pragma unroll
-  for (int x = 0; x < 2; ++x)
-#pragma unroll
-    for (int j = 0; j < KSTEPS; ++j) asm volatile("" : "+v"(bu[x][j]));
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    asm volatile("" : "+v"(ccur[p][0]), "+v"(ccur[p][1]), "+v"(mkr[p][0]), "+v"(mkr[p][1]));
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  SSTAMP_INIT(0);
-
-  int vq = 0, seq_tile[2] = {0, 0}, seq_in = 0;
-  // tile image as in the 16-wave kernel: piece (gate quarter j, row r) = 1 KiB, chunk c of row r at position c ^ r; wave 4 + d
-  // fetches the four quarters of rows 4d .. 4d + 3
-  const bool dma_wave = wave >= 4;
-  const int wd = wave & 3;
-  const unsigned frag_lane = (unsigned)((lane & 15) * 1024 + (((lane >> 4) ^ (lane & 3)) * 16) + 64 * ((lane >> 2) & 3));
-  auto issue_tile = [&](int t, int r0, int buf) __attribute__((always_inline)) {      // tile = dZ[t + 1], rows r0 .. r0 + 16 (DMA waves)
-#pragma unroll
-    for (int k = 0; k < JW; ++k) arm16(smem + (buf * NPIECE + (k >> 2) * 16 + 4 * wd + (k & 3)) * 1024 + lane * 16);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < JW; ++k) {
-      const int j = k >> 2, row = 4 * wd + (k & 3), p = j * 16 + row;
-      const unsigned soff = (unsigned)((((long)(t + 1) * B + r0 + row) * 4 * W + (long)j * W) * 2);
-      glds16_sc1_s(rs_own, (unsigned)(((lane ^ row) & 63) * 16), soff, lds_tile + (unsigned)((buf * NPIECE + p) * 1024));
-      ++vq;
-    }
-    seq_tile[buf] = vq;
-  };
-  auto tile_there = [&](int buf) __attribute__((always_inline)) -> bool {
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < JW; ++k) ok = ok && piece_there(smem + (buf * NPIECE + (k >> 2) * 16 + 4 * wd + (k & 3)) * 1024 + lane * 16);
-    return __all(ok);
-  };
-  // (lane part of the input addresses: first unit of this thread's pair, in row 2 wave or 2 wave + 1; the rest is wave-uniform)
-  const unsigned in_g = (unsigned)((u0 + eu) * 8 + (lane >> 5) * W * 8), in_h = (unsigned)((u0 + eu) * 2 + (lane >> 5) * W * 2);
-  KL_B3_DECL;
-#define KL_B3_REQUEST(k_, t_, r0_)                                                                                                  \
-  do {                                                                                                                             \
-    const long trow_ = (long)(t_) * B + (r0_) + 2 * wave;                                                                          \
-    if (k_ == 0) KL_B3_REQ_G(Gl + trow_ * W * 4, in_g);                                                                            \
-    if (k_ == 1) KL_B3_REQ_CP(Cb + trow_ * W, in_h);                                                                               \
-    if (k_ == 2) KL_B3_REQ_DH(dHb + trow_ * W, in_h);                                                                              \
-    ++vq;                                                                                                                          \
-    if (k_ == 2) seq_in = vq;                                                                                                      \
-  } while (0)
-  KL_B3_REQUEST(0, T - 1, rg * 16); KL_B3_REQUEST(1, T - 1, rg * 16); KL_B3_REQUEST(2, T - 1, rg * 16);
-
-  int n = 0;
-  for (int t = T - 1; t >= 0; --t) {
-#pragma unroll 1
-    for (int ip = 0; ip < NP; ++ip, ++n) {
-      const int buf = n & 1;
-      const int r0 = (rg + ip * n_rg) * 16;
-      int t1 = t, ip1 = ip + 1;
-      if (ip1 >= NP) { ip1 = 0; t1 = t - 1; }
-      int t2 = t1, ip2 = ip1 + 1;
-      if (ip2 >= NP) { ip2 = 0; t2 = t1 - 1; }
-      const int r1 = (rg + ip1 * n_rg) * 16, r2 = (rg + ip2 * n_rg) * 16;
-      SSTAMP(16);
-      // (flags: the 64 words of the block whose tile is requested next come into LDS -- armed with 0 = "not yet" -- and are looked
-      //  at behind the MFMAs; the last wave fetches them.  a.pf_mode 2: the tile of the block AFTER next, behind the epilogue)
-      const bool pf2 = a.pf_mode == 2;
-      const int tF = pf2 ? t2 : t1, rF = pf2 ? r2 : r1;
-      if (FLAGS && wave == 7 && tF >= 0 && tF < T - 1) {      // (a DMA wave)
-        fl_l[lane] = 0u;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        glds4_sc1_s(rs_fl, (unsigned)(lane * 4), (unsigned)((rF >> 4) * 256), lds_tile + (unsigned)FL_OFF);
-        ++vq;
-      }
-      if (dma_wave && alive && t < T - 1) {
-        wait_vm(vq - seq_tile[buf]);
-        SSTAMP(25);
-        bool ok = tile_there(buf);
-        if (!ok) {
-#ifdef KL_STAMP
-          if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[28] += 1;
-#endif
-          for (unsigned spin = 0; spin < SPIN_LIMIT && !ok; ++spin) {
-            if (spin > 0) {                 // (first round: only wait until everything issued has landed)
-#pragma unroll
-              for (int k = 0; k < JW; ++k) {
-                const int j = k >> 2, row = 4 * wd + (k & 3), p = j * 16 + row;
-                const unsigned soff = (unsigned)((((long)(t + 1) * B + r0 + row) * 4 * W + (long)j * W) * 2);
-                glds16_sc1_s(rs_own, (unsigned)(((lane ^ row) & 63) * 16), soff, lds_tile + (unsigned)((buf * NPIECE + p) * 1024));
-                ++vq;
-              }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            ok = tile_there(buf);
-            if (!ok) {
-              if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-              __builtin_amdgcn_s_sleep(2);
-            }
-          }
-          if (!ok) {
-            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok_flag = 0;
-          }
-        }
-      }
-      SSTAMP(17);
-      __syncthreads();
-      SSTAMP(18);
-      alive = __builtin_amdgcn_readfirstlane(ok_flag) != 0;
-      // ---- this block's epilogue inputs out of their landing registers (requested during the MFMAs of the block before); the
-      // next block's requests go out between this block's MFMAs (the very last block asks for its own rows again: every
-      // statement runs on every path, the landing registers never see a conditional definition)
-      wait_vm(vq - seq_in);
-      unsigned gin[4], cpin, dhin;
-      KL_B3_READ(gin[0], gin[1], gin[2], gin[3], cpin, dhin);
-      if (__any(max(max(max(gin[0], gin[1]), max(gin[2], gin[3])), max(cpin, dhin)) == 0xFFFFFFFFu)) {
-#ifdef KL_STAMP
-        if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[29] += 1;
-#endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        KL_B3_READ(gin[0], gin[1], gin[2], gin[3], cpin, dhin);
-        if (__any(max(max(max(gin[0], gin[1]), max(gin[2], gin[3])), max(cpin, dhin)) == 0xFFFFFFFFu)) {      // (nothing in flight any more)
-          __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok_flag = 0;
-        }
-      }
-      if (FLAGS && !dma_wave && n > 1) {
-        // Post the block before last.  This wave's loads are its epilogue inputs only, and those of this block have just been
-        // seen to have landed (loads return in order): whatever is in flight now are stores, which retire in order -- the two
-        // publishes of the last block and the post before this one may be among them, the block before last's publishes not
-        int tp = t, ipp = ip - 2;
-        if (ipp < 0) { ipp += NP; tp = t + 1; }
-        const int rbp = rg + ipp * n_rg;
-        wait_vm(n == 2 ? 2 : 3);      // (the third store in flight is the post of the block before: there is none yet in block 2)
-        if (lane < 2)
-          __builtin_amdgcn_raw_buffer_store_b32(epoch - (unsigned)tp, alive ? rs_fl : rs_null, (rbp * 64 + cg * 8 + wave * 2 + lane) * 4, 0, 16);
-        ++vq;
-      }
-      const int tn = t1 >= 0 ? t1 : t, rn = t1 >= 0 ? r1 : r0;
-      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t < T - 1) {
-        // k-steps in the order j = 4 (q & 3) + (q >> 2) (one lane address per group of four), fragments three steps ahead
-        const unsigned char* tb = smem + (buf * NPIECE + kq4 * 16) * 1024;
-        auto frag = [&](int q) __attribute__((always_inline)) -> u32x4 {
-          return *reinterpret_cast<const u32x4*>(tb + (frag_lane ^ (unsigned)(64 * (q >> 2))) + 256 * (q & 3));
-        };
-        u32x4 fr[4];
-        fr[0] = frag(0); fr[1] = frag(1); fr[2] = frag(2);
-#pragma unroll
-        for (int q = 0; q < KSTEPS; ++q) {
-          if (q + 3 < KSTEPS) fr[(q + 3) & 3] = frag(q + 3);
-          __builtin_amdgcn_sched_barrier(0);
-          const int j = 4 * (q & 3) + (q >> 2);
-          acc0 = mfma16(__builtin_bit_cast(bf16x8, fr[q & 3]), __builtin_bit_cast(bf16x8, bu[0][j]), acc0);
-          acc1 = mfma16(__builtin_bit_cast(bf16x8, fr[q & 3]), __builtin_bit_cast(bf16x8, bu[1][j]), acc1);
-          __builtin_amdgcn_sched_barrier(0);
-          if (q == 2) KL_B3_REQUEST(0, tn, rn);
-          if (q == 6) KL_B3_REQUEST(1, tn, rn);
-          if (q == 10) KL_B3_REQUEST(2, tn, rn);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
-        KL_B3_REQUEST(0, tn, rn); KL_B3_REQUEST(1, tn, rn); KL_B3_REQUEST(2, tn, rn);
-      }
-      {
-        float* zw = zt + wave * B3_ZT_WAVE + ((lane >> 4) * 4) * B3_ZT_ROW + (lane & 15);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { zw[r * B3_ZT_ROW] = acc0[r]; zw[r * B3_ZT_ROW + 16] = acc1[r]; }
-      }
-      SSTAMP(19);
-      __syncthreads();
-      SSTAMP(20);
-      auto request_next = [&]() __attribute__((always_inline)) {
-        if (dma_wave && alive && tF >= 0 && tF < T - 1) {
-          bool ready = true;
-          if (FLAGS) {
-            // (unsigned distance: a word of this launch is at most T - 1 behind the epoch, one of an earlier launch at least T + 2)
-            const unsigned far = (unsigned)(tF + 1);
-            ready = __all(epoch - *reinterpret_cast<const volatile unsigned*>(fl_l + lane) <= far);
-            if (!ready) {      // not posted when the words were fetched, or the fetch itself still on its way: ask memory
-#ifdef KL_STAMP
-              if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[28] += 1;
-#endif
-              for (unsigned spin = 0; spin < SPIN_LIMIT && !ready; ++spin) {
-                const unsigned now = __hip_atomic_load(flags + (long)(rF >> 4) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ready = __all(epoch - now <= far);
-                if (!ready) {
-                  if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                  __builtin_amdgcn_s_sleep(2);
-                }
-              }
-              if (!ready) {
-                __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok_flag = 0;
-              }
-            }
-          }
-          if (ready) issue_tile(tF, rF, pf2 ? buf : buf ^ 1);
-        }
-      };
-      if (!pf2) request_next();
-      // ---- epilogue: thread = (row er, units eu and eu + 1)
-      float dzv[2][4];
-      {
-        const float* zr = zt + (eu >> 5) * 4 * B3_ZT_WAVE + er * B3_ZT_ROW + (eu & 31);
-        const float2 p0 = *reinterpret_cast<const float2*>(zr), p1 = *reinterpret_cast<const float2*>(zr + B3_ZT_WAVE);
-        const float2 p2 = *reinterpret_cast<const float2*>(zr + 2 * B3_ZT_WAVE), p3 = *reinterpret_cast<const float2*>(zr + 3 * B3_ZT_WAVE);
-        const float rec[2] = {(p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y)};
-        SSTAMP(21);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const unsigned g01 = gin[2 * c], g23 = gin[2 * c + 1];
-          const float gi = u2f(g01 << 16), gf = u2f(g01 & 0xffff0000u), gg = u2f(g23 << 16), go = u2f(g23 & 0xffff0000u);
-          const float cp = c ? u2f(cpin & 0xffff0000u) : u2f(cpin << 16);
-          const float dhi = c ? u2f(dhin & 0xffff0000u) : u2f(dhin << 16);
-          const float dh = dhi * mkr[0][c] + rec[c];
-          const float tc = fast_tanh(ccur[0][c]);
-          const float dc = dh * go * (1.f - tc * tc) + dcr[0][c];
-          dcr[0][c] = dc * gf;
-          ccur[0][c] = cp;
-          const float d_o = dh * tc, d_i = dc * gg, d_g = dc * gi, d_f = dc * cp;
-          dzv[c][0] = d_i * gi * (1.f - gi);
-          dzv[c][1] = d_f * gf * (1.f - gf);
-          dzv[c][2] = d_g * (1.f - gg * gg);
-          dzv[c][3] = d_o * go * (1.f - go);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<unsigned*>(pub + (g * 16 + er) * 64 + eu) = (unsigned)f2bf(dzv[0][g]) | ((unsigned)f2bf(dzv[1][g]) << 16);
-      }
-      if (pf2) request_next();
-      SSTAMP(22);
-      __syncthreads();
-      SSTAMP(23);
-      // ---- publish dZ[t] (waves 0..3, two 16-byte write-through stores per lane); sentinel mode: re-arm step t - 2
-      {
-        int stid = tid;
-        asm volatile("" : "+v"(stid));
-        if (!dma_wave) {
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const int pi = k * 256 + stid;
-            const int g = pi >> 7, prow = (pi >> 3) & 15, seg = pi & 7;
-            const uint4 v = *reinterpret_cast<const uint4*>(pub + (g * 16 + prow) * 64 + seg * 8);
-            const unsigned off = (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2);
-            store16_sc1(alive ? rs_own : rs_null, off, v);
-            ++vq;
-            if (!FLAGS) {
-              const unsigned soff = off - (unsigned)((long)2 * B * 4 * W * 2);
-              const uint4 ones = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-              store16_sc1((alive && t >= 2) ? rs_own : rs_null, soff, ones);      // (a null buffer drops the store, the count stays)
-              ++vq;
-            }
-          }
-        }
-        // bias gradient: column (gate, unit) = tid & 255 of the staged tile, rows 8 (tid >> 8) .. + 8 (what was stored: the bf16 values)
-        if (alive) {
-          const bf16_t* col = pub + ((stid & 255) >> 6) * 1024 + (stid >> 8) * 512 + (stid & 63);
-          float sum = 0.f;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) sum += bf2f(col[r * 64]);
-          dbsum += sum;
-        }
-      }
-      SSTAMP(24);
-      if (NP > 1) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const float d0 = dcr[0][c], c0 = ccur[0][c], m0 = mkr[0][c];
-#pragma unroll
-          for (int p = 0; p + 1 < NP; ++p) { dcr[p][c] = dcr[p + 1][c]; ccur[p][c] = ccur[p + 1][c]; mkr[p][c] = mkr[p + 1][c]; }
-          dcr[NP - 1][c] = d0; ccur[NP - 1][c] = c0; mkr[NP - 1][c] = m0;
-        }
-      }
-    }
-  }
-  SSTAMP_FLUSH();
-  // db[g*W + u] += sum over this workgroup's rows and all steps (two row halves per column)
-  if (a.db) atomicAdd(a.db + (long)((tid & 255) >> 6) * W + u0 + (tid & 63), dbsum);
-}
-
-// ---------------------------------------------------------------- backward, register-landing tiles (five or more blocks per step)
-// lstm_scan_bwd_wide3_kernel with the dZ tile fetched through REGISTERS instead of LDS-DMA.  What the stamps of the LDS-DMA
-// form showed: 64 DMA pieces per block cost the CU's address unit ~2000 cycles (~32 per 1 KiB piece; a 1 KiB register load
-// passes in 16), they can only be requested once the target buffer is free -- behind the MFMA phase of the block that last
-// read it --, so they go out as one burst and land ~2000 cycles late.  Here every wave loads eight 1 KiB pieces of the tile
-// of the block AFTER NEXT into 32 accumulator registers (a8..a39) between the MFMAs of the current block -- two blocks
-// ahead, no LDS involved, so nothing has to be free --, and a block later, again between MFMAs, writes them into the LDS
-// buffer that has just been released (ds_write_b128 straight from the accumulator registers) and re-uses the registers for
-// the next tile.  The register file is the third tile buffer the LDS has no room for.
+// ---- the dZ tile through REGISTERS instead of LDS-DMA
+// 64 LDS-DMA pieces per block cost the CU's address unit ~2000 cycles (~32 per 1 KiB piece; a 1 KiB register load passes in
+// 16), and they can only be requested once the target buffer is free -- behind the MFMA phase of the block that last read it
+// --, so they went out as one burst and landed ~2000 cycles late (stamps of an 8-wave LDS-DMA form, round 3).  Here every
+// wave loads eight 1 KiB pieces of the tile of the block AFTER NEXT into 32 accumulator registers (a8..a39) between the MFMAs
+// of the current block -- two blocks ahead, no LDS involved, so nothing has to be free --, and a block later, again between
+// MFMAs, writes them into the LDS buffer that has just been released (ds_write_b128 straight from the accumulator registers)
+// and re-uses the registers for the next tile.  The register file is the third tile buffer the LDS has no room for.
 //  * order inside a wave's queue: the eight tile loads of a block are issued BEFORE its three epilogue-input loads; loads
-//    return in order, so when the (armed, checked) inputs of block n have landed, the tile pieces requested in front of
-//    them have too -- and then nothing but stores is in flight, which makes the flag post an exact counted wait for every
-//    wave (all eight publish one 16-byte store per lane and post one word);
-//  * flags only (the launcher takes this kernel from five blocks per step on): a tile is requested two blocks before it is
-//    used and its flag was posted two blocks after its data.  The flag words of the tile to request come into LDS a block
-//    earlier (wave 7, right behind its post: older than that block's inputs in the queue, so the argument above covers them;
-//    two slots, so that the fetch never overwrites words another wave is still looking at).
+//    return in order, so when the (armed, polled) inputs of block n have landed, the tile pieces requested in front of them
+//    have too -- and then nothing but stores is in flight, they retire in order, and "the block before last has reached
+//    memory" is an exact counted wait (s_waitcnt vmcnt(2)) instead of a drain, which at this block length (~1.8 us against
+//    a write-through acknowledgement of ~3 us) would stall every block.  All eight waves publish one 16-byte store per lane
+//    and post one flag word;
+//  * flags only: a tile is requested two blocks before it is used and its flag is posted two blocks after its data, hence
+//    five or more blocks per step.  The flag words of the tile to request come into LDS a block earlier (wave 7, right behind
+//    its post: older than that block's inputs in the queue, so the argument above covers them; two slots, so that the fetch
+//    never overwrites words another wave is still looking at);
+//  * XCD-local publishes where the row group's eight workgroups are verified to share an XCD (plain stores that stay in its L2).
 #define KL_B4_TILE_CLOBBER "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", \
                            "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39"
-// piece k of this wave (registers a[8 + 4k : 11 + 4k]): out to LDS / in from memory (register names must be literal)
-#define KL_B4_PUT1(k_, K_, REGS_, addr_) if ((k_) == K_) asm volatile("ds_write_b128 %0, " REGS_ :: "v"(addr_) : "memory")
-#define KL_B4_GET1(k_, K_, REGS_, voff_, rsrc_, soff_) if ((k_) == K_) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 " REGS_ ", %0, %1, %2 offen sc1" :: "v"(voff_), "s"(rsrc_), "s"(soff_) : "memory", KL_B4_TILE_CLOBBER)
+// piece k of this wave (registers a[8 + 4k : 11 + 4k]; register names and offsets must be literal): piece k = (gate quarter
+// k >> 1, row 2 wave + (k & 1)).  Out to LDS: addr_ = this lane's place in piece 0 of the target buffer, the piece itself is
+// an immediate offset.  In from memory: soff_ = the byte offset of row 2 wave of the tile, voff0_ / voff1_ = this lane's
+// (swizzled) chunk in an even / odd row (+ one row), the quarter an immediate offset -- no per-piece address arithmetic.
 #define KL_B4_PUT(k_, addr_)                                                                                                       \
   do {                                                                                                                             \
-    KL_B4_PUT1(k_, 0, "a[8:11]", addr_); KL_B4_PUT1(k_, 1, "a[12:15]", addr_); KL_B4_PUT1(k_, 2, "a[16:19]", addr_); KL_B4_PUT1(k_, 3, "a[20:23]", addr_);   \
-    KL_B4_PUT1(k_, 4, "a[24:27]", addr_); KL_B4_PUT1(k_, 5, "a[28:31]", addr_); KL_B4_PUT1(k_, 6, "a[32:35]", addr_); KL_B4_PUT1(k_, 7, "a[36:39]", addr_); \
+    if ((k_) == 0) asm volatile("ds_write_b128 %0, a[8:11] offset:0" :: "v"(addr_) : "memory");                    \
+    if ((k_) == 1) asm volatile("ds_write_b128 %0, a[12:15] offset:1024" :: "v"(addr_) : "memory");                    \
+    if ((k_) == 2) asm volatile("ds_write_b128 %0, a[16:19] offset:16384" :: "v"(addr_) : "memory");                    \
+    if ((k_) == 3) asm volatile("ds_write_b128 %0, a[20:23] offset:17408" :: "v"(addr_) : "memory");                    \
+    if ((k_) == 4) asm volatile("ds_write_b128 %0, a[24:27] offset:32768" :: "v"(addr_) : "memory");                    \
+    if ((k_) == 5) asm volatile("ds_write_b128 %0, a[28:31] offset:33792" :: "v"(addr_) : "memory");                    \
+    if ((k_) == 6) asm volatile("ds_write_b128 %0, a[32:35] offset:49152" :: "v"(addr_) : "memory");                    \
+    if ((k_) == 7) asm volatile("ds_write_b128 %0, a[36:39] offset:50176" :: "v"(addr_) : "memory");                    \
   } while (0)
-#define KL_B4_GET(k_, voff_, rsrc_, soff_)                                                                                         \
+#define KL_B4_GET(k_, voff0_, voff1_, rsrc_, soff_)                                                                                \
   do {                                                                                                                             \
-    KL_B4_GET1(k_, 0, "a[8:11]", voff_, rsrc_, soff_); KL_B4_GET1(k_, 1, "a[12:15]", voff_, rsrc_, soff_);                                 \
-    KL_B4_GET1(k_, 2, "a[16:19]", voff_, rsrc_, soff_); KL_B4_GET1(k_, 3, "a[20:23]", voff_, rsrc_, soff_);                                \
-    KL_B4_GET1(k_, 4, "a[24:27]", voff_, rsrc_, soff_); KL_B4_GET1(k_, 5, "a[28:31]", voff_, rsrc_, soff_);                                \
-    KL_B4_GET1(k_, 6, "a[32:35]", voff_, rsrc_, soff_); KL_B4_GET1(k_, 7, "a[36:39]", voff_, rsrc_, soff_);                                \
+    if ((k_) == 0) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[8:11], %0, %1, %2 offen offset:0 sc1" :: "v"(voff0_), "s"(rsrc_), "s"(soff_) : "memory", KL_B4_TILE_CLOBBER); \
+    if ((k_) == 1) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[12:15], %0, %1, %2 offen offset:0 sc1" :: "v"(voff1_), "s"(rsrc_), "s"(soff_) : "memory", KL_B4_TILE_CLOBBER); \
+    if ((k_) == 2) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[16:19], %0, %1, %2 offen offset:1024 sc1" :: "v"(voff0_), "s"(rsrc_), "s"(soff_) : "memory", KL_B4_TILE_CLOBBER); \
+    if ((k_) == 3) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[20:23], %0, %1, %2 offen offset:1024 sc1" :: "v"(voff1_), "s"(rsrc_), "s"(soff_) : "memory", KL_B4_TILE_CLOBBER); \
+    if ((k_) == 4) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[24:27], %0, %1, %2 offen offset:2048 sc1" :: "v"(voff0_), "s"(rsrc_), "s"(soff_) : "memory", KL_B4_TILE_CLOBBER); \
+    if ((k_) == 5) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[28:31], %0, %1, %2 offen offset:2048 sc1" :: "v"(voff1_), "s"(rsrc_), "s"(soff_) : "memory", KL_B4_TILE_CLOBBER); \
+    if ((k_) == 6) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[32:35], %0, %1, %2 offen offset:3072 sc1" :: "v"(voff0_), "s"(rsrc_), "s"(soff_) : "memory", KL_B4_TILE_CLOBBER); \
+    if ((k_) == 7) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[36:39], %0, %1, %2 offen offset:3072 sc1" :: "v"(voff1_), "s"(rsrc_), "s"(soff_) : "memory", KL_B4_TILE_CLOBBER); \
   } while (0)
 
 template <int NP>
@@ -1928,17 +1563,10 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_bwd_regtile_kernel(const KlS
     if (k_ == 1) KL_B3_REQ_CP(Cb + trow_ * W, in_h);                                                                               \
     if (k_ == 2) KL_B3_REQ_DH(dHb + trow_ * W, in_h);                                                                              \
   } while (0)
-  // piece k of the tile dZ[tt + 1], rows rr .. rr + 16: out of the landing registers into LDS buffer bb / in from memory
-#define KL_B4_PUT_PIECE(k_, bb_)                                                                                                    \
-  do {                                                                                                                             \
-    const unsigned la_ = lds_tile + (unsigned)(((bb_) * NPIECE + ((k_) >> 1) * 16 + 2 * wave + ((k_) & 1)) * 1024) + (unsigned)(lane * 16);   \
-    KL_B4_PUT(k_, la_);                                                                                                            \
-  } while (0)
-#define KL_B4_GET_PIECE(k_, tt_, rr_)                                                                                               \
-  do {                                                                                                                             \
-    const unsigned so_ = (unsigned)((((long)((tt_) + 1) * B + (rr_) + 2 * wave + ((k_) & 1)) * 4 * W + (long)((k_) >> 1) * W) * 2);  \
-    KL_B4_GET(k_, ((k_) & 1) ? src_lane1 : src_lane0, alive ? rs_own : rs_null, so_);                                              \
-  } while (0)
+  // (per block: put_addr = this lane's place in piece 0 of the buffer the next block's tile goes to; get_soff = row 2 wave of
+  //  the tile of the block after next)
+  const unsigned put_lane = lds_tile + (unsigned)(2 * wave * 1024 + lane * 16);
+  const unsigned src_lane1r = src_lane1 + (unsigned)(4 * W * 2);
   KL_B4_REQUEST(0, T - 1, rg * 16); KL_B4_REQUEST(1, T - 1, rg * 16); KL_B4_REQUEST(2, T - 1, rg * 16);
 
   int n = 0;
@@ -2025,6 +1653,9 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_bwd_regtile_kernel(const KlS
         glds4_sc1_s(rs_fl, (unsigned)(lane * 4), (unsigned)((r3 >> 4) * 256), lds_tile + (unsigned)(FL_OFF + ((n + 1) & 1) * 256));
       }
       const bool put = loaded;                 // write the next block's tile into the buffer the block before this one released
+      const unsigned put_addr = put_lane + (unsigned)((buf ^ 1) * NPIECE * 1024);
+      const unsigned get_soff = (unsigned)((((long)(t2 + 1) * B + r2 + 2 * wave) * 4 * W) * 2);
+      const __amdgpu_buffer_rsrc_t get_rs = alive ? rs_own : rs_null;
       const int tn = t1 >= 0 ? t1 : t, rn = t1 >= 0 ? r1 : r0;
       f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
       // one slot per pair of MFMAs: piece k out to LDS and its registers re-used for the tile after next, then the inputs
@@ -2032,8 +1663,8 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_bwd_regtile_kernel(const KlS
   do {                                                                                                                             \
     const int kk_ = (q_) < 11 ? ((q_) & 1 ? -1 : (q_) >> 1) : ((q_) == 11 ? 6 : ((q_) == 12 ? 7 : -1));                       \
     if (kk_ >= 0) {                                                                                                                \
-      if (put) KL_B4_PUT_PIECE(kk_, buf ^ 1);                                                                                      \
-      if (ready) KL_B4_GET_PIECE(kk_, t2, r2);                                                                                     \
+      if (put && !(KL_BWD_VAR & 8)) KL_B4_PUT(kk_, put_addr);                     /* (KL_BWD_VAR: timing experiments only) */      \
+      if (ready && !(KL_BWD_VAR & 16)) KL_B4_GET(kk_, src_lane0, src_lane1r, get_rs, get_soff);                                    \
     }                                                                                                                              \
     if ((q_) == 13) KL_B4_REQUEST(0, tn, rn);                                                                                      \
     if ((q_) == 14) KL_B4_REQUEST(1, tn, rn);                                                                                      \
@@ -2048,11 +1679,15 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_bwd_regtile_kernel(const KlS
         fr[0] = frag(0); fr[1] = frag(1);
 #pragma unroll
         for (int q = 0; q < KSTEPS; ++q) {
-          if (q + 2 < KSTEPS) fr[(q + 2) % 3] = frag(q + 2);
+          if (q + 2 < KSTEPS && !(KL_BWD_VAR & 64)) fr[(q + 2) % 3] = frag(q + 2);
           __builtin_amdgcn_sched_barrier(0);
           const int j = 4 * (q & 3) + (q >> 2);
-          acc0 = mfma16(__builtin_bit_cast(bf16x8, fr[q % 3]), __builtin_bit_cast(bf16x8, bu[0][j]), acc0);
-          acc1 = mfma16(__builtin_bit_cast(bf16x8, fr[q % 3]), __builtin_bit_cast(bf16x8, bu[1][j]), acc1);
+          if (KL_BWD_VAR & 32) {
+            asm volatile("" :: "v"(fr[q % 3]), "v"(bu[0][j]), "v"(bu[1][j]));
+          } else {
+            acc0 = mfma16(__builtin_bit_cast(bf16x8, fr[q % 3]), __builtin_bit_cast(bf16x8, bu[0][j]), acc0);
+            acc1 = mfma16(__builtin_bit_cast(bf16x8, fr[q % 3]), __builtin_bit_cast(bf16x8, bu[1][j]), acc1);
+          }
           __builtin_amdgcn_sched_barrier(0);
           KL_B4_SLOT(q);
           __builtin_amdgcn_sched_barrier(0);
@@ -2329,7 +1964,6 @@ int kl_launch_scan_bwd_wide2(KlScanBwd a, hipStream_t stream) {
   const int W = a.W;
   const int np = kl_scan_wide2_phases(a.B, a.T, W, 16, 6);
   if (!np || a.L != 1 || a.dZT || a.T < 3) return KL_ERR_SHAPE;
-  if (!a.Cb || !a.dc_state || !a.dHb) return KL_ERR_ARG;      // (bf16 cell states incl. block 0, the dc array, bf16 gradient from above)
   if (a.flags ? (np < 3 || !a.epoch) : a.sentinel != 2) return KL_ERR_SHAPE;      // (flags: see the kernel; two blocks per step leave them no time)
   a.n_rb = a.B / 16;
   a.n_rg = a.n_rb / np;
@@ -2361,43 +1995,6 @@ int kl_launch_scan_bwd_wide2(KlScanBwd a, hipStream_t stream) {
 #undef KL_B2_NP
 #undef KL_B2_CASE
 #undef KL_B2_CASE1
-  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
-}
-
-// third cut of the backward scan (eight waves, two cells per thread); same arguments and hand-off memory as kl_launch_scan_bwd_wide2.
-// Flags need five or more blocks per workgroup and step here (a flag is posted two blocks after its data), else rolling sentinels.
-int kl_scan_bwd_wide3_min_np_flags() { return 5; }
-int kl_launch_scan_bwd_wide3(KlScanBwd a, hipStream_t stream) {
-  const int W = a.W;
-  const int np = kl_scan_wide2_phases(a.B, a.T, W, 16, 6);
-  if (!np || W != 512 || a.L != 1 || a.dZT || a.T < 3) return KL_ERR_SHAPE;
-  if (!a.Cb || !a.dHb) return KL_ERR_ARG;
-  if (a.flags ? (np < kl_scan_bwd_wide3_min_np_flags() || !a.epoch) : a.sentinel != 2) return KL_ERR_SHAPE;
-  if (a.pf_mode == 2 && np < 3) a.pf_mode = 1;      // (two blocks ahead needs the rows to have been published at least a block before the request)
-  a.n_rb = a.B / 16;
-  a.n_rg = a.n_rb / np;
-  dim3 grid(8 * (W / 64) * ((a.n_rg + 7) / 8)), block(512);
-  const size_t lds = (size_t)bwd3_lds_bytes();
-#define KL_B3_CASE1(NP_, FL_)                                                                                               \
-  do {                                                                                                                      \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_bwd_wide3_kernel<NP_, FL_>),                          \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;     \
-    hipLaunchKernelGGL((lstm_scan_bwd_wide3_kernel<NP_, FL_>), grid, block, lds, stream, a);                                \
-  } while (0)
-#define KL_B3_CASE(NP_)                    \
-  do {                                     \
-    if (a.flags) KL_B3_CASE1(NP_, true);   \
-    else KL_B3_CASE1(NP_, false);          \
-  } while (0)
-  switch (np) {
-    case 2: KL_B3_CASE(2); break;
-    case 3: KL_B3_CASE(3); break;
-    case 4: KL_B3_CASE(4); break;
-    case 5: KL_B3_CASE(5); break;
-    default: KL_B3_CASE(6); break;
-  }
-#undef KL_B3_CASE
-#undef KL_B3_CASE1
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 

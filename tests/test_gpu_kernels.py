@@ -376,14 +376,10 @@ def test_train_window_wide_forward(monkeypatch, depth, width, voc, B, T, n_ctx, 
     (2, 512, 64, 2048, 5, 1, True, {"KL_SCAN2_PF": "2"}),      # tiles requested two phases ahead (four phases per workgroup)
     (2, 512, 64, 3072, 4, 1, True, {"KL_SCAN2_PF": "2"}),      # ... with three 32-row phases forward, six blocks backward
     (2, 512, 64, 1024, 4, 1, True, {"KL_SCAN2_PF": "2"}),      # ... with two phases: every request too early (the re-fetch path)
-    # the 8-wave backward scan (default since round 3) by flags (five and six blocks per step) and by rolling sentinels
-    # (six blocks per step: the tile through registers two blocks ahead, lstm_scan_bwd_regtile_kernel; KL_REGTILE=0: by LDS-DMA)
+    # six blocks per step: the 8-wave backward scan with the tile through registers two blocks ahead (lstm_scan_bwd_regtile_kernel);
+    # KL_REGTILE=0 / KL_RT_LOCAL=0: the 16-wave kernel / write-through publishes at the same shape
     (2, 512, 64, 3072, 5, 1, True, {}), (2, 512, 64, 3072, 7, 1, False, {}), (3, 512, 40, 3072, 4, 0, True, {}),
-    (2, 512, 64, 3072, 5, 1, True, {"KL_REGTILE": "0"}), (2, 512, 64, 3072, 4, 1, True, {"KL_SCAN2_FLAGS": "0"}),
-    (2, 512, 64, 3072, 3, 0, False, {"KL_SCAN2_PFB": "1", "KL_REGTILE": "0"}),
-    # the 16-wave backward scan of the second generation (KL_SCAN3=0): flags from three blocks per step, sentinels below
-    (2, 512, 64, 1024, 4, 1, True, {"KL_SCAN3": "0"}), (2, 512, 64, 3072, 4, 1, True, {"KL_SCAN3": "0"}),
-    (2, 512, 64, 1536, 5, 1, True, {"KL_SCAN3": "0"})])
+    (2, 512, 64, 3072, 5, 1, True, {"KL_REGTILE": "0"}), (2, 512, 64, 3072, 4, 1, True, {"KL_RT_LOCAL": "0"})])
 def test_train_window_scan2(monkeypatch, depth, width, voc, B, T, n_ctx, use_masks, env):
     """Second-generation wide scans (lstm_scan2.hip: no K split in the forward scan, 32-row phases, double-buffered
     tiles, counted waits, gate-interleaved G): gradients, loss and carried state against the f64 oracle."""

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Builds lstm_scan2.o (and its ISA listing for the audit).
 #
-# The backward scan keeps six asynchronous loads in flight around its loop in ACCUMULATOR registers (lstm_scan2.hip,
-# KL_BWD_INPUTS_*).  That needs two things HIP source cannot say:
-#   * the function attribute "amdgpu-agpr-alloc"="8,8" on those kernels -- without it the compiler halves the 128-register
-#     budget of a 1024-thread workgroup between VGPRs and AGPRs as soon as an AGPR is named (64 + 64: the weights alone take 64);
+# The 8-wave backward scan keeps its asynchronous loads in flight around its loop in ACCUMULATOR registers (lstm_scan2.hip,
+# lstm_scan_bwd_regtile_kernel).  That needs two things HIP source cannot say:
+#   * the function attribute "amdgpu-agpr-alloc"="40,40" on those kernels -- without it the compiler halves the register
+#     budget between VGPRs and AGPRs as soon as an AGPR is named (128 + 128: the weights alone take 128 VGPRs);
 #   * -amdgpu-mfma-vgpr-form, so that the MFMA accumulator stays in VGPRs and the compiler has no reason to touch an AGPR.
 # So the translation unit is built in the steps hipcc runs internally, with the attribute set on the device IR in between:
-#   device IR (optimised, -emit-llvm)  ->  attribute on the lstm_scan_bwd_wide2 / wide3 kernel definitions  ->  code object
+#   device IR (optimised, -emit-llvm)  ->  attribute on the lstm_scan_bwd_regtile_kernel definitions  ->  code object
 #   (-disable-llvm-optzns: the IR is already optimised; the forward kernels come out instruction for instruction as from
 #   plain hipcc)  ->  offload bundle  ->  host object with the bundle embedded (-fcuda-include-gpubinary).
 # Usage: build_agpr_tu.sh <src.hip> <out.o> <out.s> -- <hipcc flags...>
@@ -20,12 +20,11 @@ TMP=$(mktemp -d /tmp/kl_agpr_XXXXXX)
 trap 'rm -rf "$TMP"' EXIT
 "$HIPCC" "$@" --cuda-device-only -emit-llvm -S "$SRC" -o "$TMP/dev.ll" 2> "$TMP/err" || { cat "$TMP/err" >&2; exit 1; }
 grep -v "argument unused during compilation" "$TMP/err" >&2 || true
-N=$(grep -cE '^define .*lstm_scan_bwd_(wide[23]|regtile)_kernel' "$TMP/dev.ll" || true)
-# (8 accumulator registers: the epilogue inputs; 40: + the register-landing tile of lstm_scan_bwd_regtile_kernel)
-sed -E -i '/^define .*lstm_scan_bwd_wide[23]_kernel/ s/\) local_unnamed_addr (#[0-9]+)/) local_unnamed_addr \1 "amdgpu-agpr-alloc"="8,8"/' "$TMP/dev.ll"
+N=$(grep -cE '^define .*lstm_scan_bwd_regtile_kernel' "$TMP/dev.ll" || true)
+# (40 accumulator registers: six epilogue inputs + the 32 of the register-landing tile)
 sed -E -i '/^define .*lstm_scan_bwd_regtile_kernel/ s/\) local_unnamed_addr (#[0-9]+)/) local_unnamed_addr \1 "amdgpu-agpr-alloc"="40,40"/' "$TMP/dev.ll"
-M=$(grep -cE '"amdgpu-agpr-alloc"="(8,8|40,40)"' "$TMP/dev.ll" || true)
-if [ "$N" -lt 1 ] || [ "$N" != "$M" ]; then echo "build_agpr_tu: attribute set on $M of $N backward-scan kernels" >&2; exit 1; fi
+M=$(grep -cE '"amdgpu-agpr-alloc"="40,40"' "$TMP/dev.ll" || true)
+if [ "$N" -lt 1 ] || [ "$N" != "$M" ]; then echo "build_agpr_tu: attribute set on $M of $N register-tile kernels" >&2; exit 1; fi
 CG="-target amdgcn-amd-amdhsa -mcpu=$ARCH -O3 -Xclang -disable-llvm-optzns -mllvm -amdgpu-mfma-vgpr-form=1"
 "$LLVM/clang" $CG -S "$TMP/dev.ll" -o "$ASM"
 "$LLVM/clang" $CG "$TMP/dev.ll" -o "$TMP/dev.co"
