@@ -1408,13 +1408,15 @@ constexpr int B3_ZT_ROW = 36, B3_ZT_WAVE = 16 * 36 + 8;
 constexpr int bwd3_lds_bytes() { return 2 * 64 * 1024 + 8 * B3_ZT_WAVE * 4 + 4 * 16 * 64 * 2 + 16 + 512; }      // (two slots of hand-off words: the register-tile kernel)
 
 #define KL_B3_DECL register unsigned lb0_ asm("a0"), lb1_ asm("a1"), lb2_ asm("a2"), lb3_ asm("a3"), lb4_ asm("a4"), lb5_ asm("a5")
-#define KL_B3_REQ_G(g_base, g_off)                                                                                                 \
+// (buffer loads: resource + 32-bit scalar row offset + lane offset -- the arrays are below 4 GiB, kl_scan_wide2_phases -- instead
+//  of 64-bit base pointers: a third of the scalar instructions of a block went into pointer arithmetic)
+#define KL_B3_REQ_G(rs_, soff_, g_off)                                                                                             \
   asm volatile("v_accvgpr_write_b32 a0, -1\n\tv_accvgpr_write_b32 a1, -1\n\tv_accvgpr_write_b32 a2, -1\n\t"                         \
                "v_accvgpr_write_b32 a3, -1\n\tv_accvgpr_write_b32 a4, -1\n\tv_accvgpr_write_b32 a5, -1\n\ts_nop 4\n\t"              \
-               "global_load_dwordx4 a[0:3], %6, %7"                                                                                \
-               : "=a"(lb0_), "=a"(lb1_), "=a"(lb2_), "=a"(lb3_), "=a"(lb4_), "=a"(lb5_) : "v"(g_off), "s"(g_base) : "memory")
-#define KL_B3_REQ_CP(c_base, h_off) asm volatile("s_nop 4\n\tglobal_load_dword a4, %1, %2" : "+a"(lb4_) : "v"(h_off), "s"(c_base) : "memory")
-#define KL_B3_REQ_DH(dh_base, h_off) asm volatile("s_nop 4\n\tglobal_load_dword a5, %1, %2" : "+a"(lb5_) : "v"(h_off), "s"(dh_base) : "memory")
+               "buffer_load_dwordx4 a[0:3], %6, %7, %8 offen"                                                                      \
+               : "=a"(lb0_), "=a"(lb1_), "=a"(lb2_), "=a"(lb3_), "=a"(lb4_), "=a"(lb5_) : "v"(g_off), "s"(rs_), "s"(soff_) : "memory")
+#define KL_B3_REQ_CP(rs_, soff_, h_off) asm volatile("s_nop 4\n\tbuffer_load_dword a4, %1, %2, %3 offen" : "+a"(lb4_) : "v"(h_off), "s"(rs_), "s"(soff_) : "memory")
+#define KL_B3_REQ_DH(rs_, soff_, h_off) asm volatile("s_nop 4\n\tbuffer_load_dword a5, %1, %2, %3 offen" : "+a"(lb5_) : "v"(h_off), "s"(rs_), "s"(soff_) : "memory")
 #define KL_B3_READ(g0, g1, g2, g3, cp, dh)                                                                                         \
   asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\t"                            \
                "v_accvgpr_read_b32 %3, a3\n\tv_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5"                               \
@@ -1485,7 +1487,7 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_bwd_regtile_kernel(const KlS
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* const zt = reinterpret_cast<float*>(smem + 2 * NPIECE * 1024);
   bf16_t* const pub = reinterpret_cast<bf16_t*>(smem + 2 * NPIECE * 1024 + 8 * B3_ZT_WAVE * 4);
-  int& ok_flag = *reinterpret_cast<int*>(smem + 2 * NPIECE * 1024 + 8 * B3_ZT_WAVE * 4 + 4 * 16 * 64 * 2);
+  int& lds_word = *reinterpret_cast<int*>(smem + 2 * NPIECE * 1024 + 8 * B3_ZT_WAVE * 4 + 4 * 16 * 64 * 2);
   constexpr int FL_OFF = 2 * NPIECE * 1024 + 8 * B3_ZT_WAVE * 4 + 4 * 16 * 64 * 2 + 16;
   unsigned* const fl_l = reinterpret_cast<unsigned*>(smem + FL_OFF);
   const unsigned lds_tile = (unsigned)(size_t)(lds_void_t*)smem;
@@ -1499,11 +1501,7 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_bwd_regtile_kernel(const KlS
   }
   const int er = 2 * wave + (lane >> 5), eu = 2 * (lane & 31);
   const long BW = (long)B * W;
-  const bf16_t* Gl = a.G[0];
   const float* Cl = a.C[0];
-  bf16_t* dZl = a.dZ[0];
-  const bf16_t* dHb = a.dHb;
-  const bf16_t* Cb = a.Cb;
   const float* maskl = a.mask[0];
   unsigned* status = a.status;
   // (the dropout keep-masks of this thread's 2 NP cells as one bit each + their common scale: inverted dropout knows two
@@ -1520,17 +1518,17 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_bwd_regtile_kernel(const KlS
     dcr[p][0] = dcr[p][1] = 0.f;
     ccur[p][0] = c2.x; ccur[p][1] = c2.y;
     mbits |= (m2.x != 0.f ? 1u : 0u) << (2 * p) | (m2.y != 0.f ? 2u : 0u) << (2 * p);
-    if (m2.x != 0.f) { if (mscale != 1.f && m2.x != mscale) a.status[0] = 1u; mscale = m2.x; }
-    if (m2.y != 0.f) { if (mscale != 1.f && m2.y != mscale) a.status[0] = 1u; mscale = m2.y; }
+    if (m2.x != 0.f) { if (mscale != 1.f && m2.x != mscale) status[0] = 1u; mscale = m2.x; }
+    if (m2.y != 0.f) { if (mscale != 1.f && m2.y != mscale) status[0] = 1u; mscale = m2.y; }
   }
   float dbsum = 0.f;
-  const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(dZl, (long)T * BW * 4 * 2);
-  const __amdgpu_buffer_rsrc_t rs_null = make_rsrc(dZl, 0);
+  const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(a.dZ[0], (long)T * BW * 4 * 2);
+  const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.G[0], (long)T * BW * 4 * 2);
+  const __amdgpu_buffer_rsrc_t rs_cb = make_rsrc(a.Cb, (long)(T + 1) * BW * 2);
+  const __amdgpu_buffer_rsrc_t rs_dh = make_rsrc(a.dHb, (long)T * BW * 2);
   unsigned* const flags = a.flags;
   const unsigned epoch = *a.epoch;
   const __amdgpu_buffer_rsrc_t rs_fl = make_rsrc(flags, (long)a.n_rb * 64 * 4);
-  bool alive = true;
-  if (tid == 0) ok_flag = 1;
   if (tid < 128) fl_l[tid] = 0u;
 #pragma unroll
   for (int x = 0; x < 2; ++x)
@@ -1542,228 +1540,219 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_bwd_regtile_kernel(const KlS
   __syncthreads();
   // XCD-local hand-off: the eight workgroups that exchange a row group's tiles are dealt to ONE XCD by the grid mapping; where
   // that is verified (posted XCC ids, kl_scan_common.h) the publishes are PLAIN stores that stay in that XCD's L2, where the
-  // partners' L1-bypassing loads find them at a fraction of the write-through round trip -- at ~2 us per tile load the CU's
-  // ~64 loads in flight were what bounded the scan.  Not verified: write-through stores as before.
+  // partners' L1-bypassing loads find them.  Not verified: write-through stores.
   bool local = false;
   if (a.xcc_slots)
     local = __builtin_amdgcn_readfirstlane(
-                xcd_local_group(a.xcc_slots, a.gen, NWG_RB, [&](int j) { return xcd + 8 * (rq * NWG_RB + j); }, &ok_flag + 1, status) ? 1 : 0) != 0;
+                xcd_local_group(a.xcc_slots, a.gen, NWG_RB, [&](int j) { return xcd + 8 * (rq * NWG_RB + j); }, &lds_word, status) ? 1 : 0) != 0;
   SSTAMP_INIT(0);
 
-  // tile image in LDS as before (piece (gate quarter j, row r) = 1 KiB, chunk c of row r at position c ^ r); this wave moves
-  // the four quarters of rows 2w and 2w + 1: piece k = (quarter k >> 1, row 2w + (k & 1))
-  const unsigned src_lane0 = (unsigned)(((lane ^ (2 * wave)) & 63) * 16), src_lane1 = (unsigned)(((lane ^ (2 * wave + 1)) & 63) * 16);
+  // lane parts of the addresses (everything else is wave-uniform and lives in scalar registers)
+  const unsigned src_lane0 = (unsigned)(((lane ^ (2 * wave)) & 63) * 16);                          // tile pieces of row 2 wave ...
+  const unsigned src_lane1r = (unsigned)(((lane ^ (2 * wave + 1)) & 63) * 16 + 4 * W * 2);         // ... and of row 2 wave + 1
+  const unsigned put_lane = lds_tile + (unsigned)(2 * wave * 1024 + lane * 16);
   const unsigned frag_lane = (unsigned)((lane & 15) * 1024 + (((lane >> 4) ^ (lane & 3)) * 16) + 64 * ((lane >> 2) & 3));
   const unsigned in_g = (unsigned)((u0 + eu) * 8 + (lane >> 5) * W * 8), in_h = (unsigned)((u0 + eu) * 2 + (lane >> 5) * W * 2);
+  const unsigned pub_lane = (unsigned)(((((tid >> 3) & 15) * 4 * W) + (tid >> 7) * W + u0 + (tid & 7) * 8) * 2);
+  const bf16_t* const pub_rd = pub + ((tid >> 7) * 16 + ((tid >> 3) & 15)) * 64 + (tid & 7) * 8;
+  const bf16_t* const db_col = pub + ((tid & 255) >> 6) * 1024 + (tid >> 8) * 512 + (tid & 63);
   KL_B3_DECL;
-#define KL_B4_REQUEST(k_, t_, r0_)                                                                                                  \
+  // requests of a block's epilogue inputs: trow = first row of the block + 2 wave (time-major row index)
+#define KL_B4_REQUEST(k_, trow_)                                                                                                    \
   do {                                                                                                                             \
-    const long trow_ = (long)(t_) * B + (r0_) + 2 * wave;                                                                          \
-    if (k_ == 0) KL_B3_REQ_G(Gl + trow_ * W * 4, in_g);                                                                            \
-    if (k_ == 1) KL_B3_REQ_CP(Cb + trow_ * W, in_h);                                                                               \
-    if (k_ == 2) KL_B3_REQ_DH(dHb + trow_ * W, in_h);                                                                              \
+    if (k_ == 0) KL_B3_REQ_G(rs_g, (unsigned)(trow_) * (unsigned)(W * 8), in_g);                                                   \
+    if (k_ == 1) KL_B3_REQ_CP(rs_cb, (unsigned)(trow_) * (unsigned)(W * 2), in_h);                                                 \
+    if (k_ == 2) KL_B3_REQ_DH(rs_dh, (unsigned)(trow_) * (unsigned)(W * 2), in_h);                                                 \
   } while (0)
-  // (per block: put_addr = this lane's place in piece 0 of the buffer the next block's tile goes to; get_soff = row 2 wave of
-  //  the tile of the block after next)
-  const unsigned put_lane = lds_tile + (unsigned)(2 * wave * 1024 + lane * 16);
-  const unsigned src_lane1r = src_lane1 + (unsigned)(4 * W * 2);
-  KL_B4_REQUEST(0, T - 1, rg * 16); KL_B4_REQUEST(1, T - 1, rg * 16); KL_B4_REQUEST(2, T - 1, rg * 16);
+  {
+    const int trow = (T - 1) * B + rg * 16 + 2 * wave;
+    KL_B4_REQUEST(0, trow); KL_B4_REQUEST(1, trow); KL_B4_REQUEST(2, trow);
+  }
 
-  int n = 0;
+  // positions of this block and the three after it (time step, first row); a position past the end keeps t = -1
+  int t0 = T - 1, ip0 = 0, t1, ip1, t2, ip2, t3, ip3;
+  auto next_pos = [&](int tt, int ii, int& tn, int& in) __attribute__((always_inline)) {
+    in = ii + 1; tn = tt;
+    if (in >= NP) { in = 0; tn = tt - 1; }
+    if (tt < 0) tn = -1;
+  };
+  next_pos(t0, ip0, t1, ip1); next_pos(t1, ip1, t2, ip2); next_pos(t2, ip2, t3, ip3);
   bool loaded = false;      // the landing registers hold the tile of the NEXT block (requested during the block before this one)
-  for (int t = T - 1; t >= 0; --t) {
-#pragma unroll 1
-    for (int ip = 0; ip < NP; ++ip, ++n) {
-      const int buf = n & 1;
-      const int r0 = (rg + ip * n_rg) * 16;
-      int t1 = t, ip1 = ip + 1;
-      if (ip1 >= NP) { ip1 = 0; t1 = t - 1; }
-      int t2 = t1, ip2 = ip1 + 1;
-      if (ip2 >= NP) { ip2 = 0; t2 = t1 - 1; }
-      int t3 = t2, ip3 = ip2 + 1;
-      if (ip3 >= NP) { ip3 = 0; t3 = t2 - 1; }
-      const int r1 = (rg + ip1 * n_rg) * 16, r2 = (rg + ip2 * n_rg) * 16, r3 = (rg + ip3 * n_rg) * 16;
-      SSTAMP(16);
-      SSTAMP(25);
-      SSTAMP(17);
-      __syncthreads();
-      SSTAMP(18);
-      alive = __builtin_amdgcn_readfirstlane(ok_flag) != 0;
-      // ---- this block's epilogue inputs out of their landing registers; with them every load this wave has issued so far
-      // has landed (they were the last ones requested during the block before, and loads return in order): the tile pieces of
-      // the next block in a8..a39 too
-      // (polled, not waited for by count: a count of the operations issued since would also wait for OLDER stores -- the post of
-      //  the block before, a write-through store that takes longer than a block to be acknowledged)
-      unsigned gin[4], cpin, dhin;
-      {
-        bool got = false;
-        for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
-          KL_B3_READ(gin[0], gin[1], gin[2], gin[3], cpin, dhin);
-          if (!__any(max(max(max(gin[0], gin[1]), max(gin[2], gin[3])), max(cpin, dhin)) == 0xFFFFFFFFu)) { got = true; break; }
+  for (int n = 0; n < T * NP; ++n) {
+    const int t = t0, buf = n & 1;
+    const int r0 = (rg + ip0 * n_rg) * 16, r1 = (rg + ip1 * n_rg) * 16, r2 = (rg + ip2 * n_rg) * 16;
+    SSTAMP(16);
+    SSTAMP(25);
+    SSTAMP(17);
+    __syncthreads();
+    SSTAMP(18);
+    // ---- this block's epilogue inputs out of their landing registers; with them every load this wave has issued so far has
+    // landed (they were the last ones requested during the block before, and loads return in order): the tile pieces of the
+    // next block in a8..a39 too.  Polled, not waited for by count: a count of the operations issued since would also wait
+    // for OLDER stores (the post of the block before, a write-through store that takes longer than a block to be acknowledged)
+    unsigned gin[4], cpin, dhin;
+    KL_B3_READ(gin[0], gin[1], gin[2], gin[3], cpin, dhin);
+    if (__any(max(max(max(gin[0], gin[1]), max(gin[2], gin[3])), max(cpin, dhin)) == 0xFFFFFFFFu)) {
+      bool got = false;
+      for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
 #ifdef KL_STAMP
-          if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[29] += 1;
+        if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[29] += 1;
 #endif
-          if ((spin & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-          __builtin_amdgcn_s_sleep(1);
-        }
-        if (!got) {
-          __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok_flag = 0;
-        }
+        __builtin_amdgcn_s_sleep(1);
+        KL_B3_READ(gin[0], gin[1], gin[2], gin[3], cpin, dhin);
+        if (!__any(max(max(max(gin[0], gin[1]), max(gin[2], gin[3])), max(cpin, dhin)) == 0xFFFFFFFFu)) { got = true; break; }
+        if ((spin & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
       }
-      if (n > 1) {
-        // Post the block before last: only stores are in flight now, they retire in order, and the two youngest -- the last
-        // block's publish and the post before this one (none yet in block 2) -- are all that may still be on their way
-        int tp = t, ipp = ip - 2;
-        if (ipp < 0) { ipp += NP; tp = t + 1; }
-        const int rbp = rg + ipp * n_rg;
-        wait_vm(n == 2 ? 1 : 2);
-        if (lane == 0)
-          __builtin_amdgcn_raw_buffer_store_b32(epoch - (unsigned)tp, alive ? rs_fl : rs_null, (rbp * 64 + cg * 8 + wave) * 4, 0, 16);
-      }
-      // the tile to request now (block n + 2: dZ[t2 + 1], rows r2) is there if its 64 flag words, fetched a block ago, say so
-      const bool want = t2 >= 0 && t2 < T - 1;
-      bool ready = want && alive;
-      if (ready) {
-        const unsigned far = (unsigned)(t2 + 1);      // (a word of this launch is at most T - 1 behind the epoch, one of an earlier launch at least T + 2)
-        ready = __all(epoch - *reinterpret_cast<const volatile unsigned*>(fl_l + (n & 1) * 64 + lane) <= far);
-        if (!ready) {      // not posted when the words were fetched: ask memory (rare; this wait drains the wave's queue)
+      if (!got) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (n > 1) {
+      // Post the block before last: only stores are in flight now, they retire in order, and the two youngest -- the last
+      // block's publish and the post before this one (none yet in block 2) -- are all that may still be on their way
+      if (n > 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      int tp = t, ipp = ip0 - 2;
+      if (ipp < 0) { ipp += NP; tp = t + 1; }
+      if (lane == 0)
+        __builtin_amdgcn_raw_buffer_store_b32(epoch - (unsigned)tp, rs_fl, 0, ((rg + ipp * n_rg) * 64 + cg * 8 + wave) * 4, 16);
+    }
+    // the tile to request now (block n + 2: dZ[t2 + 1], rows r2) is there if its 64 flag words, fetched a block ago, say so
+    bool ready = t2 >= 0 && t2 < T - 1;
+    if (ready) {
+      const unsigned far = (unsigned)(t2 + 1);      // (a word of this launch is at most T - 1 behind the epoch, one of an earlier launch at least T + 2)
+      ready = __all(epoch - *reinterpret_cast<const volatile unsigned*>(fl_l + (n & 1) * 64 + lane) <= far);
+      if (!ready) {      // not posted when the words were fetched: ask memory (rare; this wait drains the wave's queue)
 #ifdef KL_STAMP
-          if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[28] += 1;
+        if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[28] += 1;
 #endif
-          for (unsigned spin = 0; spin < SPIN_LIMIT && !ready; ++spin) {
-            const unsigned now = __hip_atomic_load(flags + (long)(r2 >> 4) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ready = __all(epoch - now <= far);
-            if (!ready) {
-              if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-              __builtin_amdgcn_s_sleep(2);
-            }
-          }
+        for (unsigned spin = 0; spin < SPIN_LIMIT && !ready; ++spin) {
+          const unsigned now = __hip_atomic_load(flags + (long)(r2 >> 4) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ready = __all(epoch - now <= far);
           if (!ready) {
-            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok_flag = 0;
+            if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            __builtin_amdgcn_s_sleep(2);
           }
         }
+        if (!ready) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the scan goes on without the tile: results invalid, flagged)
       }
-      // the flag words of the tile the NEXT block will request (block n + 3), a block ahead of their use, into the other slot
-      // (last read during the block before this one)
-      if (wave == 7 && t3 >= 0 && t3 < T - 1) {
-        fl_l[((n + 1) & 1) * 64 + lane] = 0u;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        glds4_sc1_s(rs_fl, (unsigned)(lane * 4), (unsigned)((r3 >> 4) * 256), lds_tile + (unsigned)(FL_OFF + ((n + 1) & 1) * 256));
-      }
-      const bool put = loaded;                 // write the next block's tile into the buffer the block before this one released
-      const unsigned put_addr = put_lane + (unsigned)((buf ^ 1) * NPIECE * 1024);
-      const unsigned get_soff = (unsigned)((((long)(t2 + 1) * B + r2 + 2 * wave) * 4 * W) * 2);
-      const __amdgpu_buffer_rsrc_t get_rs = alive ? rs_own : rs_null;
-      const int tn = t1 >= 0 ? t1 : t, rn = t1 >= 0 ? r1 : r0;
-      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-      // one slot per pair of MFMAs: piece k out to LDS and its registers re-used for the tile after next, then the inputs
-#define KL_B4_SLOT(q_)                                                                                                              \
+    }
+    // the flag words of the tile the NEXT block will request (block n + 3), a block ahead of their use, into the other slot
+    // (last read during the block before this one)
+    if (wave == 7 && t3 >= 0 && t3 < T - 1) {
+      fl_l[((n + 1) & 1) * 64 + lane] = 0u;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      glds4_sc1_s(rs_fl, (unsigned)(lane * 4), (unsigned)((rg + ip3 * n_rg) * 256), lds_tile + (unsigned)(FL_OFF + ((n + 1) & 1) * 256));
+    }
+    const bool put = loaded;                 // write the next block's tile into the buffer the block before this one released
+    const unsigned put_addr = put_lane + (unsigned)((buf ^ 1) * NPIECE * 1024);
+    const unsigned get_soff = (unsigned)(((t2 + 1) * B + r2 + 2 * wave) * (4 * W * 2));
+    const int trow_n = (t1 >= 0 ? t1 * B + r1 : t * B + r0) + 2 * wave;      // (the very last block asks for its own rows again)
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    // one slot per pair of MFMAs: tile piece k out to LDS and its registers re-used for the tile after next, then the inputs
+#define KL_B4_SLOT(q_, put_, get_)                                                                                                  \
   do {                                                                                                                             \
-    const int kk_ = (q_) < 11 ? ((q_) & 1 ? -1 : (q_) >> 1) : ((q_) == 11 ? 6 : ((q_) == 12 ? 7 : -1));                       \
+    const int kk_ = (q_) < 11 ? ((q_) & 1 ? -1 : (q_) >> 1) : ((q_) == 11 ? 6 : ((q_) == 12 ? 7 : -1));                            \
     if (kk_ >= 0) {                                                                                                                \
-      if (put && !(KL_BWD_VAR & 8)) KL_B4_PUT(kk_, put_addr);                     /* (KL_BWD_VAR: timing experiments only) */      \
-      if (ready && !(KL_BWD_VAR & 16)) KL_B4_GET(kk_, src_lane0, src_lane1r, get_rs, get_soff);                                    \
+      if ((put_) && !(KL_BWD_VAR & 8)) KL_B4_PUT(kk_, put_addr);                   /* (KL_BWD_VAR: timing experiments only) */      \
+      if ((get_) && !(KL_BWD_VAR & 16)) KL_B4_GET(kk_, src_lane0, src_lane1r, rs_own, get_soff);                                   \
     }                                                                                                                              \
-    if ((q_) == 13) KL_B4_REQUEST(0, tn, rn);                                                                                      \
-    if ((q_) == 14) KL_B4_REQUEST(1, tn, rn);                                                                                      \
-    if ((q_) == 15) KL_B4_REQUEST(2, tn, rn);                                                                                      \
+    if ((q_) == 13) KL_B4_REQUEST(0, trow_n);                                                                                      \
+    if ((q_) == 14) KL_B4_REQUEST(1, trow_n);                                                                                      \
+    if ((q_) == 15) KL_B4_REQUEST(2, trow_n);                                                                                      \
   } while (0)
-      if (t < T - 1) {
-        const unsigned char* tb = smem + (buf * NPIECE + kq4 * 16) * 1024;
-        auto frag = [&](int q) __attribute__((always_inline)) -> u32x4 {
-          return *reinterpret_cast<const u32x4*>(tb + (frag_lane ^ (unsigned)(64 * (q >> 2))) + 256 * (q & 3));
-        };
-        u32x4 fr[3];      // (fragments two k-steps ahead: a third one in flight did not fit the 216 VGPRs next to 40 accumulator registers)
-        fr[0] = frag(0); fr[1] = frag(1);
+#define KL_B4_MFMA_PHASE(put_, get_)                                                                                                \
+  do {                                                                                                                             \
+    const unsigned char* tb = smem + (buf * NPIECE + kq4 * 16) * 1024;                                                             \
+    u32x4 fr[3];      /* (fragments two k-steps ahead: a third one in flight did not fit the 216 VGPRs next to 40 accumulator registers) */ \
+    fr[0] = *reinterpret_cast<const u32x4*>(tb + frag_lane);                                                                       \
+    fr[1] = *reinterpret_cast<const u32x4*>(tb + frag_lane + 256);                                                                 \
+    _Pragma("unroll") for (int q = 0; q < KSTEPS; ++q) {                                                                           \
+      if (q + 2 < KSTEPS && !(KL_BWD_VAR & 64))                                                                                    \
+        fr[(q + 2) % 3] = *reinterpret_cast<const u32x4*>(tb + (frag_lane ^ (unsigned)(64 * ((q + 2) >> 2))) + 256 * ((q + 2) & 3)); \
+      __builtin_amdgcn_sched_barrier(0);                                                                                           \
+      const int j = 4 * (q & 3) + (q >> 2);      /* k-steps in the order j = 4 (q & 3) + (q >> 2): one lane address per group of four */ \
+      if (KL_BWD_VAR & 32) {                                                                                                       \
+        asm volatile("" :: "v"(fr[q % 3]), "v"(bu[0][j]), "v"(bu[1][j]));                                                          \
+      } else {                                                                                                                     \
+        acc0 = mfma16(__builtin_bit_cast(bf16x8, fr[q % 3]), __builtin_bit_cast(bf16x8, bu[0][j]), acc0);                          \
+        acc1 = mfma16(__builtin_bit_cast(bf16x8, fr[q % 3]), __builtin_bit_cast(bf16x8, bu[1][j]), acc1);                          \
+      }                                                                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                                           \
+      KL_B4_SLOT(q, put_, get_);                                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                                           \
+    }                                                                                                                              \
+  } while (0)
+    if (t < T - 1 && put && ready) {
+      KL_B4_MFMA_PHASE(true, true);            // (the steady state: straight-line)
+    } else if (t < T - 1) {
+      KL_B4_MFMA_PHASE(put, ready);
+    } else {
 #pragma unroll
-        for (int q = 0; q < KSTEPS; ++q) {
-          if (q + 2 < KSTEPS && !(KL_BWD_VAR & 64)) fr[(q + 2) % 3] = frag(q + 2);
-          __builtin_amdgcn_sched_barrier(0);
-          const int j = 4 * (q & 3) + (q >> 2);
-          if (KL_BWD_VAR & 32) {
-            asm volatile("" :: "v"(fr[q % 3]), "v"(bu[0][j]), "v"(bu[1][j]));
-          } else {
-            acc0 = mfma16(__builtin_bit_cast(bf16x8, fr[q % 3]), __builtin_bit_cast(bf16x8, bu[0][j]), acc0);
-            acc1 = mfma16(__builtin_bit_cast(bf16x8, fr[q % 3]), __builtin_bit_cast(bf16x8, bu[1][j]), acc1);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          KL_B4_SLOT(q);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
+      for (int q = 0; q < KSTEPS; ++q) KL_B4_SLOT(q, put, ready);
+    }
+    loaded = ready;
+    {
+      float* zw = zt + wave * B3_ZT_WAVE + ((lane >> 4) * 4) * B3_ZT_ROW + (lane & 15);
 #pragma unroll
-        for (int q = 0; q < KSTEPS; ++q) KL_B4_SLOT(q);
-      }
-      loaded = ready;
-      {
-        float* zw = zt + wave * B3_ZT_WAVE + ((lane >> 4) * 4) * B3_ZT_ROW + (lane & 15);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { zw[r * B3_ZT_ROW] = acc0[r]; zw[r * B3_ZT_ROW + 16] = acc1[r]; }
-      }
-      SSTAMP(19);
-      __syncthreads();
-      SSTAMP(20);
-      // ---- epilogue: thread = (row er, units eu and eu + 1)
+      for (int r = 0; r < 4; ++r) { zw[r * B3_ZT_ROW] = acc0[r]; zw[r * B3_ZT_ROW + 16] = acc1[r]; }
+    }
+    SSTAMP(19);
+    __syncthreads();
+    SSTAMP(20);
+    // ---- epilogue: thread = (row er, units eu and eu + 1)
+    {
+      const float* zr = zt + (eu >> 5) * 4 * B3_ZT_WAVE + er * B3_ZT_ROW + (eu & 31);
+      const float2 p0 = *reinterpret_cast<const float2*>(zr), p1 = *reinterpret_cast<const float2*>(zr + B3_ZT_WAVE);
+      const float2 p2 = *reinterpret_cast<const float2*>(zr + 2 * B3_ZT_WAVE), p3 = *reinterpret_cast<const float2*>(zr + 3 * B3_ZT_WAVE);
+      const float rec[2] = {(p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y)};
+      SSTAMP(21);
       float dzv[2][4];
-      {
-        const float* zr = zt + (eu >> 5) * 4 * B3_ZT_WAVE + er * B3_ZT_ROW + (eu & 31);
-        const float2 p0 = *reinterpret_cast<const float2*>(zr), p1 = *reinterpret_cast<const float2*>(zr + B3_ZT_WAVE);
-        const float2 p2 = *reinterpret_cast<const float2*>(zr + 2 * B3_ZT_WAVE), p3 = *reinterpret_cast<const float2*>(zr + 3 * B3_ZT_WAVE);
-        const float rec[2] = {(p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y)};
-        SSTAMP(21);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const unsigned g01 = gin[2 * c], g23 = gin[2 * c + 1];
-          const float gi = u2f(g01 << 16), gf = u2f(g01 & 0xffff0000u), gg = u2f(g23 << 16), go = u2f(g23 & 0xffff0000u);
-          const float cp = c ? u2f(cpin & 0xffff0000u) : u2f(cpin << 16);
-          const float dhi = c ? u2f(dhin & 0xffff0000u) : u2f(dhin << 16);
-          const float dh = dhi * (((mbits >> c) & 1u) ? mscale : 0.f) + rec[c];
-          const float tc = fast_tanh(ccur[0][c]);
-          const float dc = dh * go * (1.f - tc * tc) + dcr[0][c];
-          dcr[0][c] = dc * gf;
-          ccur[0][c] = cp;
-          const float d_o = dh * tc, d_i = dc * gg, d_g = dc * gi, d_f = dc * cp;
-          dzv[c][0] = d_i * gi * (1.f - gi);
-          dzv[c][1] = d_f * gf * (1.f - gf);
-          dzv[c][2] = d_g * (1.f - gg * gg);
-          dzv[c][3] = d_o * go * (1.f - go);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<unsigned*>(pub + (g * 16 + er) * 64 + eu) = (unsigned)f2bf(dzv[0][g]) | ((unsigned)f2bf(dzv[1][g]) << 16);
-      }
-      SSTAMP(22);
-      __syncthreads();
-      SSTAMP(23);
-      // ---- publish dZ[t] (all eight waves, one 16-byte write-through store per lane) and the bias gradient
-      {
-        int stid = tid;
-        asm volatile("" : "+v"(stid));
-        const int g = stid >> 7, prow = (stid >> 3) & 15, seg = stid & 7;
-        const uint4 v = *reinterpret_cast<const uint4*>(pub + (g * 16 + prow) * 64 + seg * 8);
-        const unsigned off = (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2);
-        if (local) store16(alive ? rs_own : rs_null, off, 0u, v);
-        else store16_sc1(alive ? rs_own : rs_null, off, v);
-        if (alive) {
-          const bf16_t* col = pub + ((stid & 255) >> 6) * 1024 + (stid >> 8) * 512 + (stid & 63);
-          float sum = 0.f;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) sum += bf2f(col[r * 64]);
-          dbsum += sum;
-        }
-      }
-      SSTAMP(24);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const float d0 = dcr[0][c], c0 = ccur[0][c];
-#pragma unroll
-        for (int p = 0; p + 1 < NP; ++p) { dcr[p][c] = dcr[p + 1][c]; ccur[p][c] = ccur[p + 1][c]; }
-        dcr[NP - 1][c] = d0; ccur[NP - 1][c] = c0;
+        const unsigned g01 = gin[2 * c], g23 = gin[2 * c + 1];
+        const float gi = u2f(g01 << 16), gf = u2f(g01 & 0xffff0000u), gg = u2f(g23 << 16), go = u2f(g23 & 0xffff0000u);
+        const float cp = c ? u2f(cpin & 0xffff0000u) : u2f(cpin << 16);
+        const float dhi = c ? u2f(dhin & 0xffff0000u) : u2f(dhin << 16);
+        const float dh = dhi * (((mbits >> c) & 1u) ? mscale : 0.f) + rec[c];
+        const float tc = fast_tanh(ccur[0][c]);
+        const float dc = dh * go * (1.f - tc * tc) + dcr[0][c];
+        dcr[0][c] = dc * gf;
+        ccur[0][c] = cp;
+        const float d_o = dh * tc, d_i = dc * gg, d_g = dc * gi, d_f = dc * cp;
+        dzv[c][0] = d_i * gi * (1.f - gi);
+        dzv[c][1] = d_f * gf * (1.f - gf);
+        dzv[c][2] = d_g * (1.f - gg * gg);
+        dzv[c][3] = d_o * go * (1.f - go);
       }
-      mbits = (mbits >> 2) | ((mbits & 3u) << (2 * (NP - 1)));
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<unsigned*>(pub + (g * 16 + er) * 64 + eu) = (unsigned)f2bf(dzv[0][g]) | ((unsigned)f2bf(dzv[1][g]) << 16);
     }
+    SSTAMP(22);
+    __syncthreads();
+    SSTAMP(23);
+    // ---- publish dZ[t] (all eight waves, one 16-byte store per lane) and the bias gradient: column (gate, unit) = tid & 255 of
+    // the staged tile, rows 8 (tid >> 8) .. + 8 (what was stored: the bf16 values)
+    {
+      const uint4 v = *reinterpret_cast<const uint4*>(pub_rd);
+      const unsigned soff = (unsigned)((t * B + r0) * (4 * W * 2));
+      if (local) __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_own, (int)pub_lane, (int)soff, 0);
+      else __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rs_own, (int)pub_lane, (int)soff, 16);
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sum += bf2f(db_col[r * 64]);
+      dbsum += sum;
+    }
+    SSTAMP(24);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float d0 = dcr[0][c], c0 = ccur[0][c];
+#pragma unroll
+      for (int p = 0; p + 1 < NP; ++p) { dcr[p][c] = dcr[p + 1][c]; ccur[p][c] = ccur[p + 1][c]; }
+      dcr[NP - 1][c] = d0; ccur[NP - 1][c] = c0;
+    }
+    mbits = (mbits >> 2) | ((mbits & 3u) << (2 * (NP - 1)));
+    t0 = t1; ip0 = ip1; t1 = t2; ip1 = ip2; t2 = t3; ip2 = ip3;
+    next_pos(t2, ip2, t3, ip3);
   }
   SSTAMP_FLUSH();
   if (a.db) atomicAdd(a.db + (long)((tid & 255) >> 6) * W + u0 + (tid & 63), dbsum);
