@@ -363,7 +363,7 @@ int prepare_impl(kl_handle* h, int precision, hipStream_t s) {
     const float* Kc = P + h->off_K[0] + (size_t)(W + n * c.ctx_dim) * 4 * W;
     KL_TRY(kl_launch_small_table(P + h->off_Ctx[n], c.ctx_vocab, c.ctx_dim, Kc, 4 * W, 4 * W, d.CtxK[n], 4 * W, s));
   }
-  if (precision == KL_PREC_BF16 && h->scan2 && (W == 512 || W == 256)) {
+  if (precision == KL_PREC_BF16 && h->scan2 && W == 512) {
     // gate-interleaved copies for the second-generation wide scans
     for (int l = 1; l < c.depth; ++l) {
       KL_TRY(kl_launch_permute_gate_rows_bf16(d.KT_hi[l], d.KTp[l], W, W, s));

@@ -187,8 +187,12 @@ __device__ __forceinline__ void glds4_sc1_s(__amdgpu_buffer_rsrc_t rsrc, unsigne
 // Nothing asynchronous ever lands in a register: tiles, gate-input pieces and table-row ids are all brought in by
 // LDS-DMA and read from LDS behind a counted wait (the compiler is free to move or copy registers it believes to
 // hold data, which it did with asm loads whose data had not landed yet).
-template <int KSTEPS, int NB, int NP, bool TAB>
+template <int NB, int NP, bool TAB>
 __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide2_kernel(const KlScanFwdWide a) {
+  // (width 512 only: one tile row = one 1 KiB DMA piece, and the lane constants of the tile image -- dma_lane, frag_lane -- are
+  //  written for 1 KiB rows.  A width-256 instantiation of round 2 gave a wrong recurrent gradient and was never found; the
+  //  width is no template parameter any more, so no other instantiation can be built.)
+  constexpr int KSTEPS = 16;
   constexpr int W = KSTEPS * 32;
   constexpr int NWG_RB = W / 64;
   constexpr int ROWS = 16 * NB;
@@ -1030,8 +1034,9 @@ constexpr int bwd2_lds_bytes(int ksteps) { return 2 * 4 * ksteps * 1024 + 16 * 1
 // Rolling sentinels (a.sentinel == 2) as in the first generation: the publishing lanes re-arm step t - 2 while they store
 // step t.  The re-arming store has completed before the same lanes publish step t - 1: a whole step of NP >= 2 blocks
 // lies between them, and the counted tile wait at the top of the block after next covers every store of this one.
-template <int KSTEPS, int NP, bool FLAGS>
+template <int NP, bool FLAGS>
 __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlScanBwd a) {
+  constexpr int KSTEPS = 16;              // (width 512 only, see the forward scan)
   constexpr int W = KSTEPS * 32;
   constexpr int NWG_RB = W / 64;
   constexpr int JW = KSTEPS / 4;          // tile pieces per wave
@@ -1861,9 +1866,9 @@ int kl_launch_scan_fwd_wide2(KlScanFwdWide a, int rows, hipStream_t stream) {
   const size_t lds = (size_t)fwd2_lds_bytes(W / 32, nb, tab);
 #define KL_F2_CASE(KS, NB_, NP_, TAB_)                                                                                      \
   do {                                                                                                                      \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_fwd_wide2_kernel<KS, NB_, NP_, TAB_>),                \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_fwd_wide2_kernel<NB_, NP_, TAB_>),                \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;     \
-    hipLaunchKernelGGL((lstm_scan_fwd_wide2_kernel<KS, NB_, NP_, TAB_>), grid, block, lds, stream, a);                      \
+    hipLaunchKernelGGL((lstm_scan_fwd_wide2_kernel<NB_, NP_, TAB_>), grid, block, lds, stream, a);                      \
   } while (0)
 #define KL_F2_NP(KS, NB_, TAB_)                                                    \
   do {                                                                             \
@@ -1961,9 +1966,9 @@ int kl_launch_scan_bwd_wide2(KlScanBwd a, hipStream_t stream) {
   const size_t lds = (size_t)bwd2_lds_bytes(W / 32);
 #define KL_B2_CASE1(KS, NP_, FL_)                                                                                          \
   do {                                                                                                                      \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_bwd_wide2_kernel<KS, NP_, FL_>),                      \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_scan_bwd_wide2_kernel<NP_, FL_>),                      \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;     \
-    hipLaunchKernelGGL((lstm_scan_bwd_wide2_kernel<KS, NP_, FL_>), grid, block, lds, stream, a);                            \
+    hipLaunchKernelGGL((lstm_scan_bwd_wide2_kernel<NP_, FL_>), grid, block, lds, stream, a);                            \
   } while (0)
 #define KL_B2_CASE(KS, NP_)                   \
   do {                                        \

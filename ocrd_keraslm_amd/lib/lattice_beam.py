@@ -127,7 +127,10 @@ class EdgeTracks(object):
                     self.logger.error('unmapped character "%s" at input alternative %d of element %s', self.text[a][p],
                                       self.alternatives[a].index or k, self.element.id if self.element else "space")
         p_next = np.maximum(np.asarray(probs, dtype=np.float64)[np.arange(len(rows)), target], 1e-99)
-        self.cum[rows] += -np.log2(p_next) * self.lm_weight + self.conf_term[alt]
+        # (math.log(p, 2) element by element, as the reference computes it (rating.py:843): np.log2 -- and numpy's own log --
+        #  can differ from libm in the last bit, and ties and the +2.5 / +15 margins are decided on exact values)
+        lg = np.fromiter((log(x, 2) for x in p_next.tolist()), dtype=np.float64, count=len(rows))
+        self.cum[rows] += -lg * self.lm_weight + self.conf_term[alt]
         self.pos[rows] = pos + 1
         for i, s in zip(rows, new_states):
             self.state[i] = s

@@ -270,16 +270,28 @@ class Rater(object):
                     (x, z, y), rows, masks = pending
                     if rows:
                         lm.reset_states(B, rows=rows)
-                    lm.train_window(x, z, y, masks)
-                    lm.adam_step(grad_scale=sync.reduce(lm))
+                    # (whatever fails on this rank -- a launch, a timed-out hand-off -- is kept until all ranks have agreed on
+                    #  it below: the gradient all-reduce in between is entered by every rank, failed or not)
+                    failure = None
+                    try:
+                        lm.train_window(x, z, y, masks)
+                    except Exception as err:
+                        failure = err
+                    scale = sync.reduce(lm)
+                    if failure is None:
+                        try:
+                            lm.adam_step(grad_scale=scale)
+                        except Exception as err:
+                            failure = err
                     if step + 1 < steps_per_epoch:
                         pending = (next_batch(train_gens), sorted(reset_rows), lm.draw_dropout_masks(B))
                         reset_rows.clear()
-                    failure = None
-                    try:
-                        ce, acc, reg = lm.read_loss(reset=True)
-                    except Exception as err:      # (a failed hand-off on this rank: every rank must leave together)
-                        failure, ce, acc, reg = err, float('nan'), 0.0, 0.0
+                    ce, acc, reg = float('nan'), 0.0, 0.0
+                    if failure is None:
+                        try:
+                            ce, acc, reg = lm.read_loss(reset=True)
+                        except Exception as err:      # (a failed hand-off on this rank: every rank must leave together)
+                            failure = err
                     loss = ce + reg
                     loss_sum += loss
                     acc_sum += acc
@@ -306,14 +318,25 @@ class Rater(object):
                 lm.prepare(PREC_BF16)
                 v_loss = v_acc = 0.0
                 nxt = next_batch(val_gens) if val_steps else None
+                v_failure = None
                 for k in range(val_steps):
                     x, z, y = nxt
-                    lm.forward_window(x, z, y, want_probs=False)
+                    try:
+                        lm.forward_window(x, z, y, want_probs=False)
+                    except Exception as err:
+                        v_failure = v_failure or err
                     if k + 1 < val_steps:      # (generated while the GPU works, as in training)
                         nxt = next_batch(val_gens)
-                    ce, acc, _ = lm.read_loss(reset=True)
+                    try:
+                        ce, acc, _ = lm.read_loss(reset=True)
+                    except Exception as err:
+                        v_failure, ce, acc = v_failure or err, float('nan'), 0.0
                     v_loss += ce
                     v_acc += acc
+                # (as in the training loop: a rank whose validation failed must not leave the others in the all-reduce below)
+                (v_failed,) = sync.any_flag(v_failure is not None)
+                if v_failed:
+                    raise v_failure if v_failure is not None else RuntimeError('validation failed on another rank')
                 v_loss, v_acc = sync.mean_scalars(v_loss / val_steps, v_acc / val_steps)
                 history['val_loss'].append(v_loss)
                 history['val_accuracy'].append(v_acc)
