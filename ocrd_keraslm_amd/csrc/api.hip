@@ -124,6 +124,7 @@ struct kl_handle {
   bool sentinel_roll = true;    // KL_SENTINEL_ROLL=0: pre-fill all of dZ instead of re-arming two steps ahead inside the scan
   bool sentinel_bwd_all = false; // KL_SENTINEL_BWD=2: also with one row block per workgroup
   bool xcd_local_bwd = false;    // KL_XCD_LOCAL_BWD=1     // the same for the wide backward scan (KL_SENTINEL_BWD=0, or KL_SENTINEL=0: counters)
+  bool inc_small = true;        // incremental step: step_small.hip's kernels (KL_INC_SMALL=0: the launch-per-layer thin kernels + thin GEMM + softmax)
   bool fused_step = true;       // incremental step, n >= 256: cell fused into the GEMM epilogue (KL_FUSED_STEP=0: separate kernels)
   bool scan2 = true;            // second-generation wide scans where their grid plan applies (KL_SCAN2=0: first generation)
   int scan2_rows = 0;           // KL_SCAN2_ROWS = 16 / 32: rows per forward phase (0: chosen by shape)
@@ -806,6 +807,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->sentinel_roll = !(env7f && env7f[0] == '0');
   const char* env7d = getenv("KL_XCD_LOCAL_BWD");
   h->xcd_local_bwd = h->xcd_local && env7d && env7d[0] == '1';
+  const char* env6b = getenv("KL_INC_SMALL");
+  h->inc_small = !(env6b && env6b[0] == '0');
   const char* env6 = getenv("KL_FUSED_STEP");
   h->fused_step = !(env6 && env6[0] == '0');
   const char* env8 = getenv("KL_SCAN2");
@@ -1316,6 +1319,10 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
         e.W = W;
         KL_TRY(kl_launch_gemm_gates(g.out[l], d.WTperm[l], n, W, nb * Kl, 3L * Kl, &e, s));
       }
+      if (h->inc_small) {      // output layer + softmax in one launch
+        const int le = kl_launch_logits_softmax(pool, slot_ld, slot_out, 2 * (L - 1) * W, d.E_hi, split == 3 ? d.E_lo : nullptr, n, W, V, split, probs, s);
+        if (le != KL_ERR_SHAPE) return le;
+      }
       KlOperand op;
       memset(&op, 0, sizeof(op));
       op.A = pool + (size_t)2 * (L - 1) * W; op.lda = slot_ld; op.row_index = slot_out; op.a_is_f32 = 1;
@@ -1351,6 +1358,42 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
     }
     KL_TRY(kl_launch_softmax_ce(probs, V, n, V, nullptr, n, 1, 1.f, nullptr, 0, nullptr, nullptr, 0, s));
     return 0;
+  }
+  // few hypotheses (the reference's callers: at most 128 / 256 rows): coalesced state rows through LDS, 16-unit workgroups,
+  // and the output layer with its softmax in one launch (step_small.hip); KL_ERR_SHAPE: the launch-per-layer kernels below
+  if (h->inc_small) {
+    int e = 0;
+    for (int l = 0; l < L && e == 0; ++l) {
+      KlIncCellArgs a;
+      memset(&a, 0, sizeof(a));
+      a.n = n; a.W = W; a.split = split;
+      a.pool = pool; a.slot_ld = slot_ld; a.slot_in = slot_in; a.slot_out = slot_out;
+      a.h_off = 2 * l * W; a.c_off = (2 * l + 1) * W; a.x_off = l > 0 ? 2 * (l - 1) * W : -1;
+      a.UT_hi = d.UT_hi[l]; a.UT_lo = split == 3 ? d.UT_lo[l] : nullptr;
+      a.KT_hi = l > 0 ? d.KT_hi[l] : nullptr; a.KT_lo = (l > 0 && split == 3) ? d.KT_lo[l] : nullptr;
+      if (l == 0) {
+        if (prow) { a.T1 = prow; }
+        else { a.T1 = d.EK; a.i1 = idx; a.T2 = d.CtxK[0]; a.i2 = ctx; a.bias = P + h->off_b[0]; }
+      } else {
+        a.bias = P + h->off_b[l];
+      }
+      e = kl_launch_inc_cell(a, s);
+      if (e == KL_ERR_SHAPE && l > 0) return e;      // (layer 0 decides for all: the shapes are the same)
+    }
+    if (e == 0) {
+      e = kl_launch_logits_softmax(pool, slot_ld, slot_out, 2 * (L - 1) * W, d.E_hi, split == 3 ? d.E_lo : nullptr, n, W, V, split, probs, s);
+      if (e == KL_ERR_SHAPE) {
+        KlOperand op;
+        memset(&op, 0, sizeof(op));
+        op.A = pool + (size_t)2 * (L - 1) * W; op.lda = slot_ld; op.row_index = slot_out; op.a_is_f32 = 1;
+        op.WT_hi = d.E_hi; op.WT_lo = split == 3 ? d.E_lo : nullptr; op.ldw = W; op.K = W;
+        KL_TRY(kl_launch_thin_gemm(&op, n, V, probs, V, nullptr, split, s));
+        KL_TRY(kl_launch_softmax_ce(probs, V, n, V, nullptr, n, 1, 1.f, nullptr, 0, nullptr, nullptr, 0, s));
+        e = 0;
+      }
+      return e;
+    }
+    if (e != KL_ERR_SHAPE) return e;
   }
   for (int l = 0; l < L; ++l) {
     KlFwdStep S;
