@@ -1319,10 +1319,6 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
         e.W = W;
         KL_TRY(kl_launch_gemm_gates(g.out[l], d.WTperm[l], n, W, nb * Kl, 3L * Kl, &e, s));
       }
-      if (h->inc_small) {      // output layer + softmax in one launch
-        const int le = kl_launch_logits_softmax(pool, slot_ld, slot_out, 2 * (L - 1) * W, d.E_hi, split == 3 ? d.E_lo : nullptr, n, W, V, split, probs, s);
-        if (le != KL_ERR_SHAPE) return le;
-      }
       KlOperand op;
       memset(&op, 0, sizeof(op));
       op.A = pool + (size_t)2 * (L - 1) * W; op.lda = slot_ld; op.row_index = slot_out; op.a_is_f32 = 1;
@@ -1359,9 +1355,9 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
     KL_TRY(kl_launch_softmax_ce(probs, V, n, V, nullptr, n, 1, 1.f, nullptr, 0, nullptr, nullptr, 0, s));
     return 0;
   }
-  // few hypotheses (the reference's callers: at most 128 / 256 rows): coalesced state rows through LDS, 16-unit workgroups,
-  // and the output layer with its softmax in one launch (step_small.hip); KL_ERR_SHAPE: the launch-per-layer kernels below
-  if (h->inc_small) {
+  // 96..255 hypotheses (the reference's callers feed at most 128 / 256 rows): coalesced state rows through LDS, 16-unit
+  // workgroups (step_small.hip); KL_ERR_SHAPE, or fewer rows: the launch-per-layer kernels below
+  if (h->inc_small && n >= KL_SMALL_STEP_N) {
     int e = 0;
     for (int l = 0; l < L && e == 0; ++l) {
       KlIncCellArgs a;
@@ -1381,17 +1377,13 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
       if (e == KL_ERR_SHAPE && l > 0) return e;      // (layer 0 decides for all: the shapes are the same)
     }
     if (e == 0) {
-      e = kl_launch_logits_softmax(pool, slot_ld, slot_out, 2 * (L - 1) * W, d.E_hi, split == 3 ? d.E_lo : nullptr, n, W, V, split, probs, s);
-      if (e == KL_ERR_SHAPE) {
-        KlOperand op;
-        memset(&op, 0, sizeof(op));
-        op.A = pool + (size_t)2 * (L - 1) * W; op.lda = slot_ld; op.row_index = slot_out; op.a_is_f32 = 1;
-        op.WT_hi = d.E_hi; op.WT_lo = split == 3 ? d.E_lo : nullptr; op.ldw = W; op.K = W;
-        KL_TRY(kl_launch_thin_gemm(&op, n, V, probs, V, nullptr, split, s));
-        KL_TRY(kl_launch_softmax_ce(probs, V, n, V, nullptr, n, 1, 1.f, nullptr, 0, nullptr, nullptr, 0, s));
-        e = 0;
-      }
-      return e;
+      KlOperand op;
+      memset(&op, 0, sizeof(op));
+      op.A = pool + (size_t)2 * (L - 1) * W; op.lda = slot_ld; op.row_index = slot_out; op.a_is_f32 = 1;
+      op.WT_hi = d.E_hi; op.WT_lo = split == 3 ? d.E_lo : nullptr; op.ldw = W; op.K = W;
+      KL_TRY(kl_launch_thin_gemm(&op, n, V, probs, V, nullptr, split, s));
+      KL_TRY(kl_launch_softmax_ce(probs, V, n, V, nullptr, n, 1, 1.f, nullptr, 0, nullptr, nullptr, 0, s));
+      return 0;
     }
     if (e != KL_ERR_SHAPE) return e;
   }

@@ -252,7 +252,8 @@ int kl_launch_ctx_grads(const float* Ctx, const float* K0rows, long ldk, int R, 
 int kl_launch_rows_tm_to_bm(const float* in, long ld_in, float* out, int B, int T, int V, hipStream_t stream);
 
 // ---- step_small.hip -----------------------------------------------------
-// one LSTM cell step of a layer for n hypotheses with pool slots (n < KL_BIG_STEP_N), see inc_cell_kernel
+// one LSTM cell step of a layer for n hypotheses with pool slots (KL_SMALL_STEP_N <= n < KL_BIG_STEP_N), see inc_cell_kernel
+#define KL_SMALL_STEP_N 96
 struct KlIncCellArgs {
   int n, W, split;                     // split: 1 = bf16, 3 = split-bf16
   float* pool; long slot_ld;           // [slots][2L][W] f32
@@ -262,9 +263,6 @@ struct KlIncCellArgs {
   const float* T1; const int* i1; const float* T2; const int* i2; const float* bias;    // z init: T1[i1[r]] + T2[i2[r]] + bias (null: none)
 };
 int kl_launch_inc_cell(const KlIncCellArgs& a, hipStream_t stream);      // KL_ERR_SHAPE: not applicable
-// probs[n][V] = softmax(h . E^T) of the rows pool[slot_out[r]] + h_off, one launch; KL_ERR_SHAPE: not applicable
-int kl_launch_logits_softmax(const float* pool, long slot_ld, const int* slot_out, int h_off, const bf16_t* E_hi, const bf16_t* E_lo,
-                             int n, int W, int V, int split, float* probs, hipStream_t stream);
 
 // ---- step_big.hip -------------------------------------------------------
 #define KL_BIG_STEP_N 256   // from this many hypotheses on, kl_step_batch uses big-tile GEMMs

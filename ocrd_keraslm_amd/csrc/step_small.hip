@@ -1,5 +1,5 @@
-// Incremental step for FEW hypotheses (n < 256: the regime the reference's callers use -- rate_best feeds at most
-// 128 rows per call, generate at most 256; rating.py:49, 704, 809) and the fused output layer of every incremental step.
+// Incremental step for 96..255 hypotheses (the reference's callers: rate_best feeds at most 128 rows per call, generate
+// at most 256; rating.py:49, 704, 809).
 //
 // What the launch-per-layer thin kernels of lstm_step.hip cost at n = 128 (round 2: 2 x 17.5 us + 5.9 + 4.6 us): 512
 // four-unit workgroups, each gathering the f32 state rows of 32 hypotheses 16 bytes at a time (fragment-shaped loads: 64
@@ -11,8 +11,12 @@
 //    every wave then contracts a quarter of K against weight fragments it loads straight into registers (each weight
 //    element is used by exactly one wave: no staging), the four partial tiles meet in LDS and the cell update runs on the
 //    reduced tile.  A row's bytes are fetched by W/16 workgroups instead of W/4.
-//  * logits_softmax_kernel: logits = h . E^T (split precision), softmax and the store of the probabilities in one launch:
-//    a workgroup owns 16 hypotheses and ALL characters, so the row maximum and sum never leave the CU.
+// Measured at width 512, depth 2 (round 3): 128 hypotheses 36.2 us per step against 44.3 (10.4 + 17.6 us for the two layers
+// against 2 x 17.5); at 64 and 32 hypotheses the four-unit workgroups stay faster (28.8 / 27.7 us against 35.0 / 34.7: with
+// few rows the weights dominate a workgroup's bytes and the finer column split spreads them over more CUs), so the launcher
+// is only asked from 96 rows on.  Tried and dropped: the output layer with its softmax in one launch (a workgroup = 16
+// hypotheses x all characters, so that the row maximum and sum never leave the CU): 22 us at 128 hypotheses -- eight
+// workgroups each pulling all of E -- against 5.9 + 4.6 us for the thin GEMM and the softmax kernel.
 // Restates rating.py:578-639 (Rater.predict: one LSTM step per layer with explicit states, softmax over the tied
 // embedding) for the arithmetic; rows = hypotheses, state rows addressed through pool slots.
 #include <string.h>
@@ -64,13 +68,27 @@ __global__ __launch_bounds__(256) void inc_cell_kernel(const IncCell a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const plane_hi = smem;
   unsigned char* const plane_lo = smem + (size_t)ROWS * K * 2;
-  __shared__ int s_in[ROWS], s_out[ROWS];
-  if (tid < ROWS) {
-    const int r = min(r0 + tid, a.n - 1);
-    s_in[tid] = a.slot_in[r];
-    s_out[tid] = a.slot_out[r];
+  // ---- everything the epilogue will need is requested FIRST: this thread's cell = (row lr of each row tile, unit u0 + ej); the
+  // table rows, the bias and c_prev depend only on the index arrays, and a 256-thread workgroup alone on its CU has nothing to
+  // hide a late load behind
+  const int ej = tid & 15;
+  int e_in[NMT], e_out[NMT];
+  float ez[NMT][4], ecp[NMT];
+#pragma unroll
+  for (int m = 0; m < NMT; ++m) {
+    const int row = min(r0 + m * 16 + (tid >> 4), a.n - 1);
+    e_in[m] = a.slot_in[row];
+    e_out[m] = a.slot_out[row];
+    const long t1 = a.T1 ? (long)(a.i1 ? a.i1[row] : row) * 4 * W : 0, t2 = a.T2 ? (long)(a.i2 ? a.i2[row] : row) * 4 * W : 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v = a.bias ? a.bias[g * W + u0 + ej] : 0.f;
+      if (a.T1) v += a.T1[t1 + g * W + u0 + ej];
+      if (a.T2) v += a.T2[t2 + g * W + u0 + ej];
+      ez[m][g] = v;
+    }
+    ecp[m] = a.pool[(long)e_in[m] * a.slot_ld + a.c_off + u0 + ej];
   }
-  __syncthreads();
 
   // ---- weight fragments of this wave's first k-steps go out first (they do not depend on anything)
   const int nks = K >> 5, nks_x = a.x_off >= 0 ? (W >> 5) : 0;      // k-steps of 32; the first nks_x belong to x . K
@@ -101,20 +119,40 @@ __global__ __launch_bounds__(256) void inc_cell_kernel(const IncCell a) {
   };
   load_group(0);
 
-  // ---- activation rows: coalesced, split, into LDS
+  // ---- activation rows: coalesced, split, into LDS.  Eight pieces per thread are requested before the first one is used (a
+  // loop that loads, converts and stores piece by piece is a chain of sixteen or more memory latencies); the rows' slots sit
+  // in lanes 0 .. ROWS - 1 of every wave and are broadcast from there (a piece's row is the same for a whole wave)
   {
-    const int per_row = K >> 2;                    // float4 pieces per row
-    for (int e = tid; e < ROWS * per_row; e += 256) {
-      const int r = e / per_row, q = e - r * per_row;
-      const int k = q * 4;
-      const float* src = (a.x_off >= 0 && k < W) ? a.pool + (long)s_out[r] * a.slot_ld + a.x_off + k
-                                                 : a.pool + (long)s_in[r] * a.slot_ld + a.h_off + (k - (a.x_off >= 0 ? W : 0));
-      const float4 v = *reinterpret_cast<const float4*>(src);
-      uint2 hi, lo;
-      split4<LO>(v, hi, lo);
-      const unsigned off = a_off(r, k, K);
-      *reinterpret_cast<uint2*>(plane_hi + off) = hi;
-      if (LO) *reinterpret_cast<uint2*>(plane_lo + off) = lo;
+    const int my_row = min(r0 + (lane < ROWS ? lane : 0), a.n - 1);
+    const int sl_in = a.slot_in[my_row], sl_out = a.slot_out[my_row];
+    const int per_row = K >> 2;                    // float4 pieces per row (a multiple of 32: a wave's 64 pieces lie in one row or two)
+    const int total = ROWS * per_row;
+    for (int e0 = 0; e0 < total; e0 += 8 * 256) {
+      float4 v[8];
+      int rr[8], kk[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int e = e0 + i * 256 + tid;
+        const int ec = e < total ? e : total - 1;
+        rr[i] = ec / per_row;
+        kk[i] = (ec - rr[i] * per_row) * 4;
+        // (per_row >= 64: the 64 pieces of a wave instruction lie in one row -- its slot comes from one lane)
+        const int ru = __builtin_amdgcn_readfirstlane(rr[i]);
+        const int so = __builtin_amdgcn_readlane(sl_out, ru), si = __builtin_amdgcn_readlane(sl_in, ru);
+        const float* src = (a.x_off >= 0 && kk[i] < W) ? a.pool + (long)so * a.slot_ld + a.x_off + kk[i]
+                                                       : a.pool + (long)si * a.slot_ld + a.h_off + (kk[i] - (a.x_off >= 0 ? W : 0));
+        v[i] = *reinterpret_cast<const float4*>(src);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (e0 + i * 256 + tid < total) {
+          uint2 hi, lo;
+          split4<LO>(v[i], hi, lo);
+          const unsigned off = a_off(rr[i], kk[i], K);
+          *reinterpret_cast<uint2*>(plane_hi + off) = hi;
+          if (LO) *reinterpret_cast<uint2*>(plane_lo + off) = lo;
+        }
+      }
     }
   }
   __syncthreads();
@@ -163,114 +201,23 @@ __global__ __launch_bounds__(256) void inc_cell_kernel(const IncCell a) {
   // ---- cell update on the reduced tile: thread = (row, unit), NMT cells each
 #pragma unroll
   for (int m = 0; m < NMT; ++m) {
-    const int lr = m * 16 + (tid >> 4), ej = tid & 15;
-    const int row = r0 + lr;
+    const int row = r0 + m * 16 + (tid >> 4);
     if (row >= a.n) continue;
     const int u = u0 + ej;
     float z[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      float v = a.bias ? a.bias[g * W + u] : 0.f;
-      if (a.T1) v += a.T1[(long)(a.i1 ? a.i1[row] : row) * 4 * W + g * W + u];
-      if (a.T2) v += a.T2[(long)(a.i2 ? a.i2[row] : row) * 4 * W + g * W + u];
+      float v = ez[m][g];
 #pragma unroll
       for (int w = 0; w < 4; ++w) v += part[(((w * NMT + m) * 4 + g) * 16 + (tid >> 4)) * 17 + ej];
       z[g] = v;
     }
-    const float cp = a.pool[(long)s_in[lr] * a.slot_ld + a.c_off + u];
     const float gi = sigmoidf_(z[0]), gf = sigmoidf_(z[1]), gg = tanhf_(z[2]), go = sigmoidf_(z[3]);
-    const float c = gf * cp + gi * gg;
+    const float c = gf * ecp[m] + gi * gg;
     const float h = go * tanhf_(c);
-    float* out = a.pool + (long)s_out[lr] * a.slot_ld;
+    float* out = a.pool + (long)e_out[m] * a.slot_ld;
     out[a.c_off + u] = c;
     out[a.h_off + u] = h;
-  }
-}
-
-struct LogitsSoftmax {
-  int n, W, V;
-  const float* pool; long slot_ld; const int* slot_out; int h_off;
-  const bf16_t* E_hi; const bf16_t* E_lo;      // [Vp][W], rows >= V zero
-  float* probs;                                 // [n][V]
-};
-
-// grid ceil(n / 16), 512 threads = 8 waves; a wave owns the character tiles w, w + 8, ... (16 characters each)
-template <bool LO>
-__global__ __launch_bounds__(512) void logits_softmax_kernel(const LogitsSoftmax a) {
-  const int W = a.W, V = a.V;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r0 = blockIdx.x * 16;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const plane_hi = smem;
-  unsigned char* const plane_lo = smem + (size_t)16 * W * 2;
-  const int Vt = (V + 15) & ~15;
-  float* const lg = reinterpret_cast<float*>(smem + (size_t)16 * W * 4);      // [16][Vt + 1]
-  __shared__ int s_out[16];
-  if (tid < 16) s_out[tid] = a.slot_out[min(r0 + tid, a.n - 1)];
-  __syncthreads();
-  {
-    const int per_row = W >> 2;
-    for (int e = tid; e < 16 * per_row; e += 512) {
-      const int r = e / per_row, k = (e - r * per_row) * 4;
-      const float4 v = *reinterpret_cast<const float4*>(a.pool + (long)s_out[r] * a.slot_ld + a.h_off + k);
-      uint2 hi, lo;
-      split4<LO>(v, hi, lo);
-      const unsigned off = a_off(r, k, W);
-      *reinterpret_cast<uint2*>(plane_hi + off) = hi;
-      if (LO) *reinterpret_cast<uint2*>(plane_lo + off) = lo;
-    }
-  }
-  __syncthreads();
-  const int col = lane & 15, kg = lane >> 4, nks = W >> 5;
-  for (int tile = wave; tile * 16 < V; tile += 8) {
-    const long erow = (long)(tile * 16 + col) * W + kg * 8;      // (E is padded to a multiple of 32 rows: no clamp)
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    // (all fragments of up to 16 k-steps at once: 128 registers in split precision, of the 256 a 512-thread workgroup may take)
-    constexpr int GS = 16;
-    u32x4_t eh[GS], el[GS];
-    for (int k0 = 0; k0 < nks; k0 += GS) {
-#pragma unroll
-      for (int j = 0; j < GS; ++j) {
-        if (k0 + j < nks) {
-          eh[j] = *reinterpret_cast<const u32x4_t*>(a.E_hi + erow + (k0 + j) * 32);
-          if (LO) el[j] = *reinterpret_cast<const u32x4_t*>(a.E_lo + erow + (k0 + j) * 32);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < GS; ++j) {
-        if (k0 + j < nks) {
-          const unsigned off = a_off(col, (k0 + j) * 32 + kg * 8, W);
-          const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_t*>(plane_hi + off));
-          const bf16x8 wh = __builtin_bit_cast(bf16x8, eh[j]);
-          acc = mfma16(ah, wh, acc);
-          if (LO) {
-            const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_t*>(plane_lo + off));
-            acc = mfma16(al, wh, acc);
-            acc = mfma16(ah, __builtin_bit_cast(bf16x8, el[j]), acc);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) lg[(kg * 4 + r) * (Vt + 1) + tile * 16 + col] = acc[r];
-  }
-  __syncthreads();
-  // softmax: wave w takes rows w and w + 8
-  for (int lr = wave; lr < 16; lr += 8) {
-    const int row = r0 + lr;
-    if (row >= a.n) continue;
-    const float* x = lg + lr * (Vt + 1);
-    float mx = -INFINITY;
-    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, x[v]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    float sum = 0.f;
-    for (int v = lane; v < V; v += 64) sum += expf(x[v] - mx);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-    const float inv = 1.f / sum;
-    float* out = a.probs + (long)row * V;
-    for (int v = lane; v < V; v += 64) out[v] = expf(x[v] - mx) * inv;
   }
 }
 
@@ -282,7 +229,7 @@ constexpr size_t LDS_LIMIT = 150 * 1024;
 // launch-per-layer kernels of lstm_step.hip)
 int kl_launch_inc_cell(const KlIncCellArgs& p, hipStream_t stream) {
   const int W = p.W;
-  if (p.n < 1 || (W & 127) || !p.pool || !p.slot_in || !p.slot_out || !p.UT_hi) return KL_ERR_SHAPE;
+  if (p.n < 1 || (W & 255) || !p.pool || !p.slot_in || !p.slot_out || !p.UT_hi) return KL_ERR_SHAPE;
   const bool lo = p.split == 3;
   if (lo && (!p.UT_lo || (p.x_off >= 0 && !p.KT_lo))) return KL_ERR_ARG;
   if (p.x_off >= 0 && !p.KT_hi) return KL_ERR_ARG;
@@ -307,29 +254,5 @@ int kl_launch_inc_cell(const KlIncCellArgs& p, hipStream_t stream) {
   if (nmt == 2) { if (lo) KL_IC_CASE(2, true); else KL_IC_CASE(2, false); }
   else { if (lo) KL_IC_CASE(1, true); else KL_IC_CASE(1, false); }
 #undef KL_IC_CASE
-  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
-}
-
-// probs[n][V] = softmax(h . E^T) for the top layer's new states; KL_ERR_SHAPE = not applicable (thin GEMM + softmax kernel)
-int kl_launch_logits_softmax(const float* pool, long slot_ld, const int* slot_out, int h_off, const bf16_t* E_hi, const bf16_t* E_lo,
-                             int n, int W, int V, int split, float* probs, hipStream_t stream) {
-  if (n < 1 || V < 1 || (W & 127) || !pool || !slot_out || !E_hi || !probs) return KL_ERR_SHAPE;
-  const bool lo = split == 3;
-  if (lo && !E_lo) return KL_ERR_ARG;
-  const int Vt = (V + 15) & ~15;
-  const size_t lds = (size_t)16 * W * 4 + (size_t)16 * (Vt + 1) * 4;
-  if (lds > LDS_LIMIT) return KL_ERR_SHAPE;
-  LogitsSoftmax a;
-  a.n = n; a.W = W; a.V = V; a.pool = pool; a.slot_ld = slot_ld; a.slot_out = slot_out; a.h_off = h_off;
-  a.E_hi = E_hi; a.E_lo = E_lo; a.probs = probs;
-  if (lo) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&logits_softmax_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return KL_ERR_LAUNCH;
-    hipLaunchKernelGGL((logits_softmax_kernel<true>), dim3((n + 15) / 16), dim3(512), lds, stream, a);
-  } else {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&logits_softmax_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return KL_ERR_LAUNCH;
-    hipLaunchKernelGGL((logits_softmax_kernel<false>), dim3((n + 15) / 16), dim3(512), lds, stream, a);
-  }
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }

@@ -9,7 +9,7 @@ rc=$?
 grep -v amdgpu.ids $OUT/r3e_tests.log | tail -8
 if [ $rc -ne 0 ]; then echo "tests rc=$rc: stopping"; exit $rc; fi
 rm -f $OUT/r3e.log
-for n in 128 64 256 1024; do
+for n in 128 64 32 256; do
   for sm in 1 0; do
     echo "=== n=$n KL_INC_SMALL=$sm" >> $OUT/r3e.log
     KL_INC_SMALL=$sm KL_PROBE_PREC=3 timeout -k 10 120 python tools/probe_incremental.py $n 2>&1 | grep -v amdgpu.ids >> $OUT/r3e.log || exit 1
