@@ -306,6 +306,19 @@ class HipLM:
         m[0] = 1.0
         return m
 
+    def draw_dropout_masks_device(self, B):
+        """The same masks drawn in HBM (torch's generator, seeded from this engine's numpy generator on first use): at 3072
+        streams the host drew 3.1 M random numbers per step, 6-8 ms beside 26 ms of GPU work."""
+        torch = self.torch
+        if getattr(self, "_tgen", None) is None:
+            self._tgen = torch.Generator(device=self.device)
+            self._tgen.manual_seed(int(self._rng.integers(0, 2 ** 31 - 1)))
+        with torch.cuda.device(self.device):
+            keep = torch.rand((self.depth, B, self.pwidth), device=self.device, generator=self._tgen) >= DROPOUT_RATE
+            m = keep.to(torch.float32) / (1.0 - DROPOUT_RATE)
+            m[0] = 1.0
+        return m
+
     def ensure_training_buffers(self):
         torch = self.torch
         if self.grads is None:

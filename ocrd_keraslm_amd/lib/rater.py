@@ -31,7 +31,7 @@ from random import shuffle
 
 import numpy as np
 
-from . import lattice_beam, modelio, windows
+from . import lattice_beam, modelio, streams, windows
 from .node import Node
 
 PREC_BF16 = 1
@@ -145,6 +145,8 @@ class Rater(object):
         self.max_epochs = 100
         self.patience = 3
         self.seed = None
+        self.batched_streams = True          # the B streams of stateful training advanced together (streams.StreamBatcher)
+        self.batched_streams_max_chars = 1 << 30
         self._engine_factory = engine_factory
         self._pool = None
         self._stop = False
@@ -227,14 +229,35 @@ class Rater(object):
             return gens
 
         def next_batch(gens):
+            if isinstance(gens, streams.StreamBatcher):      # B streams advanced together (streams.py)
+                batch, rows = gens.next_batch()
+                if gens.train:
+                    reset_rows.update(rows)                  # ResetStatesCallback.reset (callbacks.py:50-53)
+                return batch
             xs, zs, ys = [], [], []
             for g in gens:
                 x, z, y = next(g)
                 xs.append(x); zs.append(z); ys.append(y)
             return np.stack(xs), np.stack(zs), np.stack(ys)
 
-        train_gens = make_streams(training_data, True)
-        val_gens = make_streams(validation_data, False)
+        def make_batcher(files, train):
+            per_stream = [files[rank * B + s::n_streams] or files[:1] for s in range(B)]
+            return streams.StreamBatcher(per_stream, self.length, self.mapping[0], train=train, rng=rng,
+                                         char_degradation=self.char_degradation, context_degradation=self.context_degradation,
+                                         on_unmapped=self._unmapped_input, device=getattr(lm, "device", None),
+                                         texts=getattr(self, "_texts", None))
+
+        # (the batched path keeps every file's ids in memory -- in HBM for the HIP engine --, 4 bytes per character;
+        #  corpora beyond `batched_streams_max_chars` stay on the generator per stream, which re-reads file by file)
+        if self.batched_streams and total_size <= self.batched_streams_max_chars:
+            train_gens = make_batcher(training_data, True)
+            val_gens = make_batcher(validation_data, False)
+        else:
+            train_gens = make_streams(training_data, True)
+            val_gens = make_streams(validation_data, False)
+        self._texts = {}
+        draw_masks = getattr(lm, "draw_dropout_masks_device", None) if self.batched_streams else None
+        draw_masks = draw_masks or lm.draw_dropout_masks
         steps_per_epoch = max(1, ceil(training_epoch_size / n_streams))
         val_steps = max(1, ceil(validation_epoch_size / n_streams))
         history = {'loss': [], 'accuracy': [], 'val_loss': [], 'val_accuracy': []}
@@ -264,7 +287,7 @@ class Rater(object):
                 # Streams that entered a new file while that batch was generated are reset right before
                 # it is trained, as ResetStatesCallback.on_batch_begin does.
                 # (the dropout masks of the next step are drawn there too: 2 ms of host work per 1024 streams)
-                pending = (next_batch(train_gens), sorted(reset_rows), lm.draw_dropout_masks(B))
+                pending = (next_batch(train_gens), sorted(reset_rows), draw_masks(B))
                 reset_rows.clear()
                 for step in range(steps_per_epoch):
                     (x, z, y), rows, masks = pending
@@ -284,7 +307,7 @@ class Rater(object):
                         except Exception as err:
                             failure = err
                     if step + 1 < steps_per_epoch:
-                        pending = (next_batch(train_gens), sorted(reset_rows), lm.draw_dropout_masks(B))
+                        pending = (next_batch(train_gens), sorted(reset_rows), draw_masks(B))
                         reset_rows.clear()
                     ce, acc, reg = float('nan'), 0.0, 0.0
                     if failure is None:
@@ -397,6 +420,7 @@ class Rater(object):
         if not self.stateful:
             return self._split_data_stateless(data, val_data)
         total_size = 0
+        self._texts = {}
         chars = set(self.mapping[0].keys())
         steps = self.length
         if val_data:
@@ -417,6 +441,10 @@ class Rater(object):
                 total_size += size
                 epoch_size += ceil((size - self.length) / steps / self.batch_size)
                 chars.update(set(text))
+                if self.batched_streams and total_size <= self.batched_streams_max_chars:
+                    self._texts[id(file)] = text       # (train() encodes them once more, it need not read them again)
+                else:
+                    self._texts.clear()
             sizes.append(epoch_size)
         chars = sorted(list(chars))
         self.voc_size = len(chars) + 1
