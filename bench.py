@@ -189,8 +189,13 @@ def end_to_end_leg(B, windows_per_file=201):
                 f.close()
         steps = windows_per_file - 1          # (rating.py:342: ceil((size - length) / length) full windows per file)
         chars = steps * B * LENGTH
+        t = {k: round(v, 3) for k, v in getattr(r, "timings", {}).items()}
+        steady = chars / t["train_steps"] if t.get("train_steps") else None
         return {"value": chars / el, "unit": "chars/s", "seconds": el, "train_steps": steps, "streams": B,
-                "note": "Rater.train, one epoch + validation, wall time of the whole call"}
+                "phases_s": t, "train_steps_only": steady,
+                "note": "Rater.train, one epoch + validation, wall time of the whole call; phases_s splits it into reading + "
+                        "splitting the files, mapping them to ids, the training steps, validation, checkpoint; "
+                        "train_steps_only = chars / the training-step phase (what further epochs cost)"}
 
 
 def training_leg(device, depth, width, length, n_ctx, B, steps, warmup, corpus, seed=1):

@@ -6,9 +6,9 @@ stream and step, 21.5 ms at 3072 streams against 26 ms of GPU work.  `StreamBatc
 batches (window contents, zero-padded tails, the train=True augmentations and their random numbers, the points where a
 stream enters a new file) from array state:
 
-  * every file of every stream is read, NFC-normalised and encoded ONCE into one id vector (`corpus`), kept where the
-    batches are assembled -- in HBM for the HIP engine, so a step moves a few small index vectors instead of three
-    [B, T] arrays over PCIe;
+  * every file of every stream is read and NFC-normalised ONCE; its code points go through one look-up table gather
+    into one id vector (`corpus`), made and kept where the batches are assembled -- in HBM for the HIP engine, so a
+    step moves a few small index vectors instead of three [B, T] arrays over PCIe;
   * per step the streams' states (file, next window, pending augmented copies) advance as numpy vectors; only the
     streams that change file or owe an augmented copy (about one in ten) are touched individually;
   * a batch is assembled from (start, valid length, column to zero, context to zero) per stream by one gather and a
@@ -27,9 +27,10 @@ from . import windows
 
 class StreamBatcher(object):
     def __init__(self, stream_files, length, c_i, train=False, rng=None, char_degradation=0.01, context_degradation=0.1,
-                 on_unmapped=None, device=None, texts=None):
+                 on_unmapped=None, device=None, codepoints=None):
         """stream_files: per stream, the list of open text files it cycles through (at least one each);
-        texts: optional {id(file): normalised text} of files the caller has read already (`Rater._split_data`)"""
+        codepoints: optional {id(file): uint32 code points of the normalised text} of files the caller has read
+        already (`Rater._split_data`)"""
         self.B = len(stream_files)
         self.T = int(length)
         self.train = bool(train)
@@ -37,33 +38,35 @@ class StreamBatcher(object):
         self.char_degradation = float(char_degradation)
         self.context_degradation = float(context_degradation)
         self.device = device
+        self.c_i = c_i
+        self.on_unmapped = on_unmapped
         T = self.T
-        # ---- every distinct file once: ids, size, context
-        chunks, self._file_of = [], {}
+        # ---- every distinct file once: code points, size, context.  The ids come later (`prepare`): one gather of the
+        # code points through a look-up table, where the batches are assembled (on the device for the HIP engine)
+        self._file_of = {}
         off = 0
-        f_base, f_size, f_ctx = [], [], []
+        f_base, f_size, f_ctx, self._parts = [], [], [], []
         for files in stream_files:
             assert files, "a stream needs at least one file"
             for f in files:
                 if id(f) in self._file_of:
                     continue
-                if texts is not None and id(f) in texts:
-                    text = texts[id(f)]
-                    size = len(text)
+                if codepoints is not None and id(f) in codepoints:
+                    cps = codepoints[id(f)]
                 else:
                     f.seek(0)
-                    text, size = windows.read_normalize_file(f)
-                ids = windows.encode(text, c_i, on_unmapped)
+                    cps = windows.codepoints(windows.read_normalize_file(f)[0])
+                size = len(cps)
                 self._file_of[id(f)] = len(f_base)
                 f_base.append(off)
                 f_size.append(size)
                 f_ctx.append(windows.clamp_context(windows.context_from_filename(f.name)))
-                chunks.append(ids)
+                self._parts.append(cps)
                 off += size
+        self._total = off
+        self._corpus = None
         self.n_ctx = len(f_ctx[0]) if f_ctx else 0
         assert all(len(c) == self.n_ctx for c in f_ctx), "all files must have the same number of context variables"
-        # (one trailing id so that a gather one past a file's end stays inside the vector; never selected as valid)
-        self.corpus = np.concatenate(chunks + [np.zeros(T + 1, dtype=np.int32)]) if chunks else np.zeros(T + 1, np.int32)
         self.f_base = np.asarray(f_base, dtype=np.int64)
         self.f_size = np.asarray(f_size, dtype=np.int64)
         self.f_ctx = np.asarray(f_ctx, dtype=np.int32).reshape(len(f_base), self.n_ctx)
@@ -82,6 +85,62 @@ class StreamBatcher(object):
         self.last_start = np.zeros(self.B, dtype=np.int64)     # corpus offset of the last full window (for its copies)
         self._corpus_dev = None
         self._ctx_dev = None
+
+    # ------------------------------------------------------------------ code points -> ids
+    def _report_unmapped(self, positions):
+        """`positions`: corpus offsets of code points outside the mapping, ascending"""
+        if self.on_unmapped is None:
+            return
+        for pos in positions:
+            k = int(np.searchsorted(self.f_base, pos, side='right')) - 1
+            j = int(pos - self.f_base[k])
+            self.on_unmapped(chr(int(self._parts[k][j])), j)
+
+    @property
+    def corpus(self):
+        """all ids on the host (int32; T + 1 trailing zeros so that a gather one past a file's end stays inside)"""
+        if self._corpus is None:
+            from concurrent.futures import ThreadPoolExecutor
+            import os
+            lut = windows.full_lookup_table(self.c_i)
+            out = np.zeros(self._total + self.T + 1, dtype=np.int32)
+
+            def gather(k):       # (numpy's take releases the interpreter lock: the files spread over the cores)
+                if len(self._parts[k]):
+                    np.take(lut, self._parts[k], out=out[self.f_base[k]:self.f_base[k] + self.f_size[k]], mode='clip')
+            with ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1))) as pool:
+                list(pool.map(gather, range(len(self._parts))))
+            miss = np.nonzero(out[:self._total] < 0)[0]
+            if len(miss):
+                self._report_unmapped(miss)
+                out[miss] = 0
+            self._corpus = out
+        return self._corpus
+
+    def prepare(self):
+        """map the code points to ids now (else on the first batch)"""
+        if self.device is None:
+            self.corpus
+        elif self._corpus_dev is None:
+            import torch
+            dev = self.device
+            import warnings
+            cps = torch.zeros(self._total + self.T + 1, dtype=torch.int32, device=dev)
+            with warnings.catch_warnings():      # (the vectors are views of immutable bytes; they are only read)
+                warnings.simplefilter("ignore")
+                for k, part in enumerate(self._parts):
+                    if len(part):
+                        cps[int(self.f_base[k]):int(self.f_base[k]) + len(part)].copy_(
+                            torch.from_numpy(part.view(np.int32)), non_blocking=True)
+            lut = torch.from_numpy(windows.full_lookup_table(self.c_i)).to(dev)
+            ids = lut.index_select(0, cps)
+            ids[self._total:] = 0
+            miss = torch.nonzero(ids < 0).flatten()
+            if miss.numel():
+                self._report_unmapped(miss.cpu().numpy())
+                ids.clamp_(min=0)
+            self._corpus_dev = ids
+            self._ar = torch.arange(self.T, dtype=torch.int64, device=dev)
 
     # ------------------------------------------------------------------ state machine
     def _open_next_file(self, rows, new_file_rows):
@@ -176,8 +235,7 @@ class StreamBatcher(object):
         start, vlen, zero_col, zero_ctx, ctx, _ = plan
         dev = self.device
         if self._corpus_dev is None:
-            self._corpus_dev = torch.from_numpy(self.corpus).to(dev)
-            self._ar = torch.arange(self.T, dtype=torch.int64, device=dev)
+            self.prepare()
         T, B = self.T, self.B
         # one small transfer per step: [start | vlen | zero_col | zero_ctx | ctx...]
         pack = np.concatenate([start[:, None], vlen[:, None], zero_col[:, None], zero_ctx[:, None], ctx.astype(np.int64)], axis=1)

@@ -58,6 +58,28 @@ def clamp_context(context):
     return [min(max(int(c), 0), CTX_VOCAB - 1) for c in context]
 
 
+N_CODEPOINTS = 0x110000
+
+
+def codepoints(text):
+    """the code points of a string as one uint32 vector (lone surrogates pass through)"""
+    if not text:
+        return np.zeros(0, dtype=np.uint32)
+    try:
+        return np.frombuffer(text.encode('utf-32-le', 'surrogatepass'), dtype='<u4')
+    except UnicodeEncodeError:       # pragma: no cover
+        return np.array([ord(ch) for ch in text], dtype=np.uint32)
+
+
+def full_lookup_table(c_i):
+    """code point -> id over ALL code points (-1 = unmapped): a gather through it needs no bounds handling"""
+    t = np.full(N_CODEPOINTS, -1, dtype=np.int32)
+    for ch, k in c_i.items():
+        if len(ch) == 1:
+            t[ord(ch)] = k
+    return t
+
+
 def encode(text, c_i, on_unmapped=None, base=0):
     """characters -> int32 ids (0 = unmapped).  Vectorised: code points index a look-up table of the
     mapped characters; only the (rare) unmapped positions go through Python, to be reported."""
@@ -74,16 +96,18 @@ def encode(text, c_i, on_unmapped=None, base=0):
             else:
                 ids[j] = k
         return ids
-    try:
-        cps = np.frombuffer(text.encode('utf-32-le', 'surrogatepass'), dtype='<u4')
-    except UnicodeEncodeError:       # pragma: no cover
-        cps = np.array([ord(ch) for ch in text], dtype=np.uint32)
+    cps = codepoints(text)
     lut = _lookup_table(c_i)
-    inside = cps < len(lut)
-    ids = np.where(inside, lut[np.where(inside, cps, 0)], -1).astype(np.int32)
+    if int(cps.max()) < len(lut):    # (the common case -- every code point inside the table: one gather)
+        ids = lut[cps]
+    else:
+        inside = cps < len(lut)
+        ids = np.where(inside, lut[np.where(inside, cps, 0)], -1).astype(np.int32)
     hit = ids >= 0
+    if hit.all():
+        return ids
     ids[~hit] = 0
-    if on_unmapped is not None and not hit.all():
+    if on_unmapped is not None:
         for j in np.nonzero(~hit)[0]:
             on_unmapped(text[int(j)], base + int(j))
     return ids

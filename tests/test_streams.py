@@ -14,6 +14,7 @@ from ocrd_keraslm_amd.lib import streams, windows
 class MemFile(object):
     def __init__(self, name, text):
         self.name = name
+        self.text = text
         self._f = io.StringIO(text)
 
     def read(self):
@@ -89,3 +90,22 @@ def test_batcher_on_the_golden_file_set():
         assert np.array_equal(x, np.stack([w[0] for w in want]))
         assert np.array_equal(z, np.stack([w[1] for w in want]))
         assert np.array_equal(y, np.stack([w[2] for w in want]))
+
+
+def test_batcher_reports_unmapped_characters_once_per_occurrence():
+    """the batcher maps all files in one pass: every character outside the mapping is reported with its position in its
+    file (windows.encode reports the same positions when a generator encodes the file)"""
+    T = 8
+    files = [MemFile("a_b_1800.txt", "abcpabcxab" * 3), MemFile("a_c_1810.txt", "ab" * 9), MemFile("a_d_1820.txt", "pppa" * 5)]
+    c_i = {"a": 1, "b": 2, "c": 3}
+    want = []
+    for f in files:
+        windows.encode(f.text, c_i, on_unmapped=lambda ch, pos, f=f: want.append((f.name, ch, pos)))
+    got = []
+    bat = streams.StreamBatcher([[f] for f in files], T, c_i,
+                                codepoints={id(f): windows.codepoints(f.text) for f in files[:2]},
+                                on_unmapped=lambda ch, pos: got.append((ch, pos)))
+    bat.prepare()
+    assert got == [(ch, pos) for _n, ch, pos in want] and len(got) == 6 + 15
+    (x, _z, _y), _rows = bat.next_batch()
+    assert x[0].tolist() == [1, 2, 3, 0, 1, 2, 3, 0] and x[2].tolist() == [0, 0, 0, 1, 0, 0, 0, 1]
