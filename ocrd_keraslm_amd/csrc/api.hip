@@ -124,6 +124,7 @@ struct kl_handle {
   bool sentinel_roll = true;    // KL_SENTINEL_ROLL=0: pre-fill all of dZ instead of re-arming two steps ahead inside the scan
   bool sentinel_bwd_all = false; // KL_SENTINEL_BWD=2: also with one row block per workgroup
   bool xcd_local_bwd = false;    // KL_XCD_LOCAL_BWD=1     // the same for the wide backward scan (KL_SENTINEL_BWD=0, or KL_SENTINEL=0: counters)
+  bool split_sentinel = true;   // rating windows: the split-precision scan hands over by data sentinels (KL_SPLIT_SENTINEL=0: counters)
   bool inc_small = true;        // incremental step: step_small.hip's kernels (KL_INC_SMALL=0: the launch-per-layer thin kernels + thin GEMM + softmax)
   bool fused_step = true;       // incremental step, n >= 256: cell fused into the GEMM epilogue (KL_FUSED_STEP=0: separate kernels)
   bool scan2 = true;            // second-generation wide scans where their grid plan applies (KL_SCAN2=0: first generation)
@@ -588,7 +589,15 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
     // the carried-in state as (hi, lo) planes; hand-off counters zeroed write-through
     for (int l = 0; l < L; ++l)
       KL_TRY(kl_launch_f32_to_bf16_t((const float*)w.H[l], W, B, W, w.Xhi[l], w.Xlo[l], W, 0, s));
-    KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)L * ((B + 15) / 16) * T, s));
+    a.sentinel = h->split_sentinel ? 1 : 0;
+    if (a.sentinel) {      // hand-off by data: the blocks the scan is going to publish start out as sentinels
+      for (int l = 0; l < L; ++l) {
+        KL_TRY(kl_fill_u32_async(w.Xhi[l] + BW, (size_t)T * BW * sizeof(bf16_t), 0xFFFFFFFFu, s));
+        KL_TRY(kl_fill_u32_async(w.Xlo[l] + BW, (size_t)T * BW * sizeof(bf16_t), 0xFFFFFFFFu, s));
+      }
+    } else {
+      KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)L * ((B + 15) / 16) * T, s));
+    }
     const int e = kl_launch_scan_fwd_split(a, s);
     if (e == 0) scanned = true;
     else if (e != KL_ERR_SHAPE) return e;
@@ -807,6 +816,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->sentinel_roll = !(env7f && env7f[0] == '0');
   const char* env7d = getenv("KL_XCD_LOCAL_BWD");
   h->xcd_local_bwd = h->xcd_local && env7d && env7d[0] == '1';
+  const char* env6c = getenv("KL_SPLIT_SENTINEL");
+  h->split_sentinel = !(env6c && env6c[0] == '0');
   const char* env6b = getenv("KL_INC_SMALL");
   h->inc_small = !(env6b && env6b[0] == '0');
   const char* env6 = getenv("KL_FUSED_STEP");

@@ -126,6 +126,7 @@ struct KlScanFwdSplit {
   float* C[KL_SCAN_MAXL];              // [(T+1)B][W]: block 0 read, block T written
   unsigned* counters;                  // [L][n_rb][T]
   unsigned* status;
+  int sentinel;                        // 1: hand-off by data -- blocks 1..T of Xhi / Xlo pre-filled with 0xFFFF by the caller, no counters
 };
 int kl_launch_scan_fwd_split(KlScanFwdSplit args, hipStream_t stream);
 

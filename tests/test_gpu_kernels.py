@@ -296,6 +296,13 @@ def test_forward_window_parity(depth, width, voc, B, T, n_ctx):
         assert np.abs(states[:, k] - st[k]).max() < 1e-4
 
 
+@pytest.mark.parametrize("depth,width,voc,B,T,n_ctx", [(3, 256, 30, 40, 9, 2), (2, 512, 256, 1, 64, 1)])
+def test_forward_window_counter_handoff(monkeypatch, depth, width, voc, B, T, n_ctx):
+    """the split-precision scan with its counter hand-off (KL_SPLIT_SENTINEL=0; the default hands over by data sentinels)"""
+    monkeypatch.setenv("KL_SPLIT_SENTINEL", "0")
+    test_forward_window_parity(depth, width, voc, B, T, n_ctx)
+
+
 @pytest.mark.parametrize("depth,width,voc,B,T,n_ctx", [(2, 128, 40, 20, 9, 1), (2, 512, 64, 512, 4, 1), (2, 512, 64, 1024, 3, 1),
                                                        (3, 100, 30, 5, 7, 2), (2, 1024, 40, 48, 4, 1), (6, 128, 30, 24, 5, 1)])
 def test_validation_windows_bf16(depth, width, voc, B, T, n_ctx):
