@@ -124,6 +124,10 @@ struct kl_handle {
   bool sentinel_roll = true;    // KL_SENTINEL_ROLL=0: pre-fill all of dZ instead of re-arming two steps ahead inside the scan
   bool sentinel_bwd_all = false; // KL_SENTINEL_BWD=2: also with one row block per workgroup
   bool xcd_local_bwd = false;    // KL_XCD_LOCAL_BWD=1     // the same for the wide backward scan (KL_SENTINEL_BWD=0, or KL_SENTINEL=0: counters)
+  bool w32 = true;              // width 1024: the eight-wave scans of lstm_scan_w32.hip (KL_W32=0: the thin scans)
+  bool w32_local = false;       // KL_W32_LOCAL=1: ... handing over through the XCD's own L2 where the placement allows (measured slower: 112 vs 104 ms per cfg5 step)
+  int w32_var = 0;              // (experiments, KL_W32_VAR)
+  int w32_min_rb = 8;           // ... from this many row blocks of 16 streams (KL_W32_MIN_RB)
   bool split_sentinel = true;   // rating windows: the split-precision scan hands over by data sentinels (KL_SPLIT_SENTINEL=0: counters)
   bool inc_small = true;        // incremental step: step_small.hip's kernels (KL_INC_SMALL=0: the launch-per-layer thin kernels + thin GEMM + softmax)
   bool fused_step = true;       // incremental step, n >= 256: cell fused into the GEMM epilogue (KL_FUSED_STEP=0: separate kernels)
@@ -553,16 +557,26 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       a.P1 = w.P1;
       a.counters = w.scan_cnt;
       a.status = w.scan_status;
-      KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)((B + 15) / 16) * T, s));
+      // width 1024 from eight row blocks: eight-wave workgroups of 32 units, the state tile through LDS, hand-off by
+      // data sentinels inside one XCD (lstm_scan_w32.hip); else the thin workgroups with their counters
+      const bool w32 = h->w32 && (B + 15) / 16 >= h->w32_min_rb && kl_scan_w32_applicable(B, T, W);
+      if (w32) {
+        a.sentinel = 1;
+        a.xcc_slots = h->w32_local ? w.scan_status + 4 : nullptr;
+        a.gen = (unsigned)(1 + l);                   // (the posts are zeroed once per window: a token per launch)
+        KL_TRY(kl_fill_u32_async((bf16_t*)w.H[l] + BW, (size_t)T * BW * sizeof(bf16_t), 0xFFFFFFFFu, s));
+      } else {
+        KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)((B + 15) / 16) * T, s));
+      }
       if (l == L - 1) h->trace_begin(0, s);
-      const int e = kl_launch_scan_fwd(a, s);
+      const int e = w32 ? kl_launch_scan_fwd_w32(a, s) : kl_launch_scan_fwd(a, s);
       if (e == KL_ERR_SHAPE && l == 0) {
         all = false;          // (too many row blocks: the launch-per-step path below takes the window, P1 is in place)
       } else if (e != 0) {
         return e;
       } else if (l == L - 1) {
         h->trace_persistent[0] = true;
-        h->trace_name[0] = "lstm_scan_fwd_kernel";
+        h->trace_name[0] = w32 ? "lstm_scan_fwd_w32_kernel" : "lstm_scan_fwd_kernel";
         h->trace_flops[0] = (double)B * T * (2.0 * W * 4.0 * W);
         h->trace_end(0, s);
       }
@@ -816,6 +830,14 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->sentinel_roll = !(env7f && env7f[0] == '0');
   const char* env7d = getenv("KL_XCD_LOCAL_BWD");
   h->xcd_local_bwd = h->xcd_local && env7d && env7d[0] == '1';
+  const char* env6f = getenv("KL_W32");
+  h->w32 = !(env6f && env6f[0] == '0');
+  const char* env6g = getenv("KL_W32_LOCAL");
+  h->w32_local = env6g && env6g[0] == '1';
+  const char* env6i = getenv("KL_W32_VAR");
+  h->w32_var = env6i ? atoi(env6i) : 0;
+  const char* env6h = getenv("KL_W32_MIN_RB");
+  h->w32_min_rb = env6h ? atoi(env6h) : 8;
   const char* env6c = getenv("KL_SPLIT_SENTINEL");
   h->split_sentinel = !(env6c && env6c[0] == '0');
   const char* env6b = getenv("KL_INC_SMALL");
@@ -1144,6 +1166,18 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       a.db = grads + h->off_b[l];
       if (rt) a.xcc_slots = h->rt_local ? w.scan_status + 4 : nullptr;
       int e = w.scan2_bwd ? (rt ? kl_launch_scan_bwd_regtile(a, s) : kl_launch_scan_bwd_wide2(a, s)) : (h->wide_bwd ? kl_launch_scan_bwd_wide(a, s) : KL_ERR_SHAPE);
+      bool w32 = false;
+      if (e == KL_ERR_SHAPE && !w.scan2_bwd && h->w32 && n_rb_all >= h->w32_min_rb && kl_scan_w32_applicable(B, T, W)) {
+        // width 1024: eight-wave workgroups of 32 units (lstm_scan_w32.hip); every step starts out as sentinels
+        if (a.sentinel != 1) KL_TRY(kl_fill_u32_async(w.dZ[l], (size_t)T * BW * 4 * sizeof(bf16_t), 0xFFFFFFFFu, s));
+        a.sentinel = 1;
+        a.dZT = nullptr;
+        a.xcc_slots = h->w32_local ? w.scan_status + 4 : nullptr;
+        a.gen = (unsigned)(1 + L + l);
+        a.pf_mode = h->w32_var;
+        e = kl_launch_scan_bwd_w32(a, s);
+        w32 = e == 0;
+      }
       const bool wide = e == 0;
       if (e == KL_ERR_SHAPE && w.scan2_bwd) return KL_ERR_SHAPE;      // (the forward scans wrote gate-interleaved G: planned together, plan_scan2)
       if (e == KL_ERR_SHAPE) {
@@ -1155,7 +1189,8 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       if (e != 0) return e;
       if (l == L - 1) {
         h->trace_persistent[1] = true;
-        h->trace_name[1] = w.scan2_bwd ? (rt ? "lstm_scan_bwd_regtile_kernel" : "lstm_scan_bwd_wide2_kernel") : (wide ? "lstm_scan_bwd_wide_kernel" : "lstm_scan_bwd_kernel");
+        h->trace_name[1] = w.scan2_bwd ? (rt ? "lstm_scan_bwd_regtile_kernel" : "lstm_scan_bwd_wide2_kernel")
+                                       : (w32 ? "lstm_scan_bwd_w32_kernel" : (wide ? "lstm_scan_bwd_wide_kernel" : "lstm_scan_bwd_kernel"));
         h->trace_flops[1] = (double)B * T * (2.0 * W * 4.0 * W);   // one layer's recurrent contraction
         h->trace_end(1, s);
       }

@@ -110,8 +110,13 @@ struct KlScanFwd {
   const float* mask[KL_SCAN_MAXL];     // [B][W] keep-masks (null: none)
   unsigned* counters;                  // [L][n_rb][T], zeroed by the launcher
   unsigned* status;                    // 0 = ok, 1 = a bounded spin timed out
+  int sentinel;                        // width-1024 scan only: 1 = hand-off by data sentinels (blocks 1..T of H pre-filled with 0xFFFF halfwords)
+  unsigned* xcc_slots; unsigned gen;   // width-1024 scan only: as KlScanFwdWide
 };
 int kl_launch_scan_fwd(KlScanFwd args, hipStream_t stream);
+// width 1024, one layer per launch: eight-wave workgroups of 32 units, the tile through LDS (lstm_scan_w32.hip); KL_ERR_SHAPE = not applicable
+bool kl_scan_w32_applicable(int B, int T, int W);
+int kl_launch_scan_fwd_w32(KlScanFwd args, hipStream_t stream);
 
 // split-precision (bf16 hi + lo) inference scan, all layers fused
 struct KlScanFwdSplit {
@@ -196,6 +201,7 @@ int kl_launch_scan_bwd_wide2(KlScanBwd args, hipStream_t stream);
 // eight waves, two cells per thread, the tile through registers two blocks ahead (flags only; same arguments); from
 // kl_scan_bwd_regtile_min_np() blocks per workgroup and step
 int kl_launch_scan_bwd_regtile(KlScanBwd args, hipStream_t stream);
+int kl_launch_scan_bwd_w32(KlScanBwd args, hipStream_t stream);     // width 1024 (a.sentinel must be 1, a.L 1)
 int kl_scan_bwd_regtile_min_np();
 // output projection + softmax + CE + dlogits of a training window in one pass (V = 256, width 512); KL_ERR_SHAPE = not applicable
 int kl_launch_logits_ce_ws(const bf16_t* X, const bf16_t* E, const int* tgt, bf16_t* dlogits, float* rowstat, int B, int T, int W,

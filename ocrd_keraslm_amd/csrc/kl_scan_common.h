@@ -153,6 +153,14 @@ __device__ __forceinline__ bool granule_valid(uint4 v) {
   auto bad = [](unsigned x) { return ((x & 0xFFFFu) == 0xFFFFu) || ((x >> 16) == 0xFFFFu); };
   return !(bad(v.x) || bad(v.y) || bad(v.z) || bad(v.w));
 }
+// the same test in three operations per dword, for waves that check whole tiles: a halfword of x is 0xFFFF iff the
+// halfword of ~x is zero, and (~x - 0x00010001) & x & 0x80008000 is non-zero iff ~x has a zero halfword ("haszero");
+// the bits of several dwords may be OR-ed before the mask is applied
+__device__ __forceinline__ unsigned sentinel_bits(uint4 v) {
+  auto f = [](unsigned x) { return (~x - 0x00010001u) & x; };
+  return f(v.x) | f(v.y) | f(v.z) | f(v.w);
+}
+__device__ __forceinline__ bool sentinel_free(unsigned bits) { return (bits & 0x80008000u) == 0; }
 
 // v_exp_f32 / v_rcp_f32 forms (1 ulp each): the scans are latency chains, and the
 // training path computes in bf16 anyway

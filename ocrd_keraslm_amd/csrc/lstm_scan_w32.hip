@@ -1,0 +1,565 @@
+// One-layer persistent LSTM scans for width 1024 (the cfg5 topology): eight-wave workgroups of 32 hidden units.
+//
+// Why another pair of scans: at width 1024 the recurrent weights of 64 units (the wide scans' workgroup, lstm_scan.hip /
+// lstm_scan2.hip) are 512 KiB -- the whole register file of a CU -- so round 2 ran this width through the THIN scans:
+// 256-thread workgroups of 16 units that each pull the whole 16 x 4W tile of a row block straight into registers, two
+// workgroups per CU.  Per row block that is 2 x 128 KiB into one CU in the backward scan with nothing overlapped
+// (profiles/r03_cfg5_B512_kernel_stats.csv: 18.4 ms per layer backward, 8.7 ms forward, 4.8 % / 10 % of the MFMA roof).
+//
+// Here a workgroup is 8 waves = 4 K-quarters x 2 unit groups = 32 units, one per CU (weights: 128 registers per lane,
+// the budget is 256), so W/32 = 32 workgroups produce a row block and 256 CUs serve 8 row groups -- one row group per
+// XCD, which makes the hand-off XCD-local.  The tile of a row block comes into LDS ONCE per workgroup by LDS-DMA
+// (waves 4-7, which issue nothing else but loads: their counted waits stay exact -- vmcnt is in order only among loads),
+// is shared by the eight waves, and with several row blocks per workgroup the next block's tile is requested right
+// behind this block's MFMA phase and lands behind the epilogue.  Hand-off by data sentinels (the caller pre-fills what
+// the scan is going to publish with 0xFFFF halfwords), published by waves 0-3; protocol, placement check and time-outs
+// as in the wide scans (kl_scan_common.h).
+#include <stdlib.h>
+#include <string.h>
+
+#include "kl_common.h"
+#include "kl_kernels.h"
+
+namespace {
+
+#include "kl_scan_common.h"
+
+// wait_vm for counts up to 31 (vmcnt has six bits on gfx9; an under-estimate only waits longer)
+__device__ __forceinline__ void wait_vm_wide(int k) {
+  if (k <= 15) {
+    wait_vm(k);
+    return;
+  }
+#define KL_WAIT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+  switch (k > 31 ? 31 : k) {
+    KL_WAIT_CASE(16) KL_WAIT_CASE(17) KL_WAIT_CASE(18) KL_WAIT_CASE(19) KL_WAIT_CASE(20) KL_WAIT_CASE(21) KL_WAIT_CASE(22)
+    KL_WAIT_CASE(23) KL_WAIT_CASE(24) KL_WAIT_CASE(25) KL_WAIT_CASE(26) KL_WAIT_CASE(27) KL_WAIT_CASE(28) KL_WAIT_CASE(29)
+    KL_WAIT_CASE(30) KL_WAIT_CASE(31)
+  }
+#undef KL_WAIT_CASE
+}
+
+constexpr int UN = 32;         // hidden units per workgroup
+constexpr int NT = 512;        // threads per workgroup
+
+__device__ __forceinline__ void w32_placement(int NWG_RB, int n_rg, int& cg, int& rq, int& rg, int& xcd) {
+  // XCD x = blockIdx % 8 hosts the row groups x R .. x R + R - 1 (R = ceil(n_rg / 8)), each with all its column groups
+  xcd = blockIdx.x & 7;
+  const int yy = blockIdx.x >> 3;
+  cg = yy % NWG_RB;
+  rq = yy / NWG_RB;
+  rg = xcd * ((n_rg + 7) >> 3) + rq;
+}
+
+// LDS bytes in front of the per-row-block state slots [MAXRB][512] f32
+#define KL_W32_BWD_LDS(KS) (4 * (KS) * 1024 + 8 * 16 * 17 * 4 + 4 * 16 * UN * 2 + 16)
+#define KL_W32_FWD_LDS(KS) ((KS) * 1024 + 8 * 4 * 16 * 17 * 4 + 16 * UN * 2 * 2 + 4 * 16 * UN * 2 + 16 * UN * 4 + 16)
+
+// ---------------------------------------------------------------- backward
+// dh[t] = dH[t] (from above, all steps at once by the big GEMM) + dZ[t+1] . U^T; dZ[t] from the gate derivatives; db summed here.
+template <int KSTEPS, int MAXRB>
+__global__ __launch_bounds__(NT, 1) void lstm_scan_bwd_w32_kernel(const KlScanBwd a) {
+  constexpr int W = KSTEPS * 32;
+  constexpr int NWG_RB = W / UN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq4 = wave & 3, ug = wave >> 2;
+  const int n_rg = a.n_rg, n_rb = a.n_rb, B = a.B, T = a.T;
+  int cg, rq, rg, xcd;
+  w32_placement(NWG_RB, n_rg, cg, rq, rg, xcd);
+  if (rg >= n_rg) return;
+  const int u0 = cg * UN;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* a_tile = smem;                                                              // [4 quarters][KSTEPS][1 KiB]
+  float (*zt)[16][17] = reinterpret_cast<float (*)[16][17]>(smem + 4 * KSTEPS * 1024);         // [8 waves][16][17]
+  bf16_t* pub = reinterpret_cast<bf16_t*>(smem + 4 * KSTEPS * 1024 + 8 * 16 * 17 * 4);       // [4 gates][16 rows][32 units]
+  int* flags = reinterpret_cast<int*>(smem + 4 * KSTEPS * 1024 + 8 * 16 * 17 * 4 + 4 * 16 * UN * 2);
+  int& ok_flag = flags[0];
+  float* dc_slot = reinterpret_cast<float*>(smem + KL_W32_BWD_LDS(KSTEPS)) + tid;            // [MAXRB][512]
+
+  const int kq = (lane >> 4) * 8;
+  uint4 bu[KSTEPS];
+  {
+    const long wrow = (long)(u0 + ug * 16 + (lane & 15)) * 4 * W + (long)kq4 * W;
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j) bu[j] = *reinterpret_cast<const uint4*>(a.Un[0] + wrow + j * 32 + kq);
+  }
+  const int er = tid >> 5, eu = tid & 31;          // epilogue thread = (row of 16, unit of 32)
+  float dc_one = 0.f;
+  if (MAXRB > 1) {
+    for (int i = 0; i < MAXRB; ++i) dc_slot[i * NT] = 0.f;
+  }
+  float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+  const long BW = (long)B * W;
+  const bf16_t* Gl = a.G[0];
+  const float* Cl = a.C[0];
+  const float* dH = a.dH;
+  const float* maskl = a.mask[0];
+  unsigned* status = a.status;
+  const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(a.dZ[0], (long)T * BW * 4 * 2);
+  bool alive = true;
+  constexpr bool PREF = MAXRB > 1;
+  const bool pref_ok = (B & 15) == 0;
+  const int n_raw = maskl ? 8 : 7;                 // epilogue inputs loaded at the top of a block, behind the DMA
+  const unsigned lds_a = (unsigned)(size_t)(lds_void_t*)a_tile;
+  if (tid == 0) ok_flag = 1;
+  __syncthreads();
+  bool local = false;
+  if (a.xcc_slots)
+    local = xcd_local_group(a.xcc_slots, a.gen, NWG_RB, [&](int j) { return xcd + 8 * (rq * NWG_RB + j); }, flags + 1, status);
+  const bool dma_wave = wave >= 4;
+  const int dq = wave - 4;                         // the quarter a DMA wave brings in
+  // The tile comes in two halves -- k-steps [0, KH) and [KH, KSTEPS) of every quarter -- that are requested, checked and
+  // multiplied one after the other: half A of the NEXT block is requested as soon as this block's half A has been
+  // multiplied (it travels under half B's MFMAs and the epilogue), half B behind this block's last MFMA.  With the
+  // whole tile requested only behind the MFMA phase, two thirds of its travel time was exposed (timing experiments of
+  // round 3: 6.8 of 15.5 ms per launch at 512 streams).
+  constexpr int KH = KSTEPS / 2;
+  int pf_a = 0, pf_b = 0;                          // this block's halves are in flight (requested during the block before)
+
+  // requests for half hf of the tile of block (nt, nr0): dZ[nt + 1]
+  auto request_half = [&](int hf, int nt, int nr0) {
+    const unsigned nbase = (unsigned)((((long)(nt + 1) * B + min(nr0 + (lane & 15), B - 1)) * 4 * W + (long)dq * W + kq) * 2);
+#pragma unroll
+    for (int j = 0; j < KH; ++j) {
+      const int jj = hf * KH + j;
+      if (local) glds16_nt(rs_own, nbase + jj * 64, lds_a + (dq * KSTEPS + jj) * 1024);
+      else glds16_sc1(rs_own, nbase + jj * 64, lds_a + (dq * KSTEPS + jj) * 1024);
+    }
+  };
+  // DMA waves: half hf of this block's tile is complete and free of sentinels (else re-fetched until it is).
+  // in_flight: it was requested ahead; then at most `younger` later requests of this wave may still be outstanding.
+  auto await_half = [&](int hf, int t, int r0, bool in_flight, int younger) {
+    unsigned char* frag = a_tile + (dq * KSTEPS + hf * KH) * 1024 + lane * 16;
+    const unsigned base = (unsigned)((((long)(t + 1) * B + min(r0 + (lane & 15), B - 1)) * 4 * W + (long)dq * W + kq) * 2);
+    bool ok = false;
+    if (alive) {
+      // Without a request in flight the wave first probes ONE fragment (256 workgroups spinning on whole tiles slow
+      // the publishes down) and fetches the rest once that one is there.
+      bool probe = !in_flight;
+      for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
+        if (in_flight) {
+          wait_vm_wide(younger);                 // (this wave's queue holds loads only, in order)
+        } else if (probe) {
+          const int jj = hf * KH + KH - 1;
+          if (local) glds16_nt(rs_own, base + jj * 64, lds_a + (dq * KSTEPS + jj) * 1024);
+          else glds16_sc1(rs_own, base + jj * 64, lds_a + (dq * KSTEPS + jj) * 1024);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+          request_half(hf, t, r0);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        unsigned bits = 0;
+        if (probe) {
+          bits = sentinel_bits(*reinterpret_cast<const uint4*>(frag + (KH - 1) * 1024));
+        } else {
+          uint4 v[8];
+#pragma unroll
+          for (int hh = 0; hh < KH / 8; ++hh) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const uint4*>(frag + (hh * 8 + j) * 1024);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bits |= sentinel_bits(v[j]);
+          }
+        }
+        const bool good = __all(sentinel_free(bits));
+        if (good && !probe) { ok = true; break; }
+        in_flight = false;
+        probe = !good;                             // the probe passed: now the whole half; a bad half: back to probing
+        if (!good) {
+          if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      if (!ok) {
+        __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok_flag = 0;
+      }
+    }
+    if (!ok) {
+#pragma unroll
+      for (int j = 0; j < KH; ++j) *reinterpret_cast<uint4*>(frag + j * 1024) = uint4{0, 0, 0, 0};
+    }
+  };
+
+  for (int t = T - 1; t >= 0; --t) {
+#pragma unroll 1
+    for (int i = 0; i < MAXRB; ++i) {
+      const int rb = rg + i * n_rg;
+      if (rb >= n_rb) continue;
+      const int r0 = rb * 16;
+      const int erow = min(r0 + er, B - 1);
+      // (raw loads only; they are consumed in the epilogue behind a compiler fence)
+      const bf16_t* gp = Gl + ((long)t * B + erow) * 4 * W + u0 + eu;
+      unsigned g0 = gp[0], g1 = gp[W], g2 = gp[2 * W], g3 = gp[3 * W];
+      float c = Cl[((long)(t + 1) * B + erow) * W + u0 + eu];
+      float cp = Cl[((long)t * B + erow) * W + u0 + eu];
+      float dh = dH[((long)t * B + erow) * W + u0 + eu];
+      float mkv = maskl ? maskl[(long)erow * W + u0 + eu] : 1.f;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      // the block this workgroup visits next, and whether its tile may be asked for ahead
+      int ni = i + 1, nt = t;
+      if (ni >= MAXRB || rg + ni * n_rg >= n_rb) { ni = 0; nt = t - 1; }
+      const int nr0 = (rg + ni * n_rg) * 16;
+      const bool ahead = PREF && dma_wave && pref_ok && nt >= 0 && nt < T - 1;
+      int nx_a = 0, nx_b = 0;
+      if (t < T - 1) {
+        if (dma_wave) await_half(0, t, r0, pf_a != 0, (pf_b ? KH : 0) + n_raw);
+        __syncthreads();
+        alive = ok_flag != 0;
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+          frag16 fa, fb;
+          fa.u = *reinterpret_cast<const uint4*>(a_tile + (kq4 * KSTEPS + j) * 1024 + lane * 16);
+          fb.u = bu[j];
+          acc = mfma16(fa.v, fb.v, acc);
+        }
+        __syncthreads();      // half A of the buffer is free
+        // (the epilogue inputs have long arrived; waiting for them HERE keeps the compiler's wait in front of the requests below)
+        asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(c), "+v"(cp), "+v"(dh), "+v"(mkv));
+        if (ahead && alive) {
+          request_half(0, nt, nr0);
+          nx_a = 1;
+        }
+        if (dma_wave) await_half(1, t, r0, pf_b != 0, nx_a ? KH : 0);
+        __syncthreads();
+        alive = ok_flag != 0;
+#pragma unroll
+        for (int j = KH; j < KSTEPS; ++j) {
+          frag16 fa, fb;
+          fa.u = *reinterpret_cast<const uint4*>(a_tile + (kq4 * KSTEPS + j) * 1024 + lane * 16);
+          fb.u = bu[j];
+          acc = mfma16(fa.v, fb.v, acc);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zt[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+      __syncthreads();
+      asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(c), "+v"(cp), "+v"(dh), "+v"(mkv));
+      if (ahead && alive) {      // the whole buffer is free: the rest of the next block's tile
+        if (!nx_a) {
+          request_half(0, nt, nr0);
+          nx_a = 1;
+        }
+        request_half(1, nt, nr0);
+        nx_b = 1;
+      }
+      pf_a = nx_a;
+      pf_b = nx_b;
+      const int wz = (eu >> 4) * 4;                // the four K-quarter waves of this unit group
+      dh = dh * mkv + (zt[wz][er][eu & 15] + zt[wz + 1][er][eu & 15] + zt[wz + 2][er][eu & 15] + zt[wz + 3][er][eu & 15]);
+      const float gi = bf2f((bf16_t)g0), gf = bf2f((bf16_t)g1), gg = bf2f((bf16_t)g2), go = bf2f((bf16_t)g3);
+      const float tc = fast_tanh(c);
+      const float dc = dh * go * (1.f - tc * tc) + (MAXRB > 1 ? dc_slot[i * NT] : dc_one);
+      if (MAXRB > 1) dc_slot[i * NT] = dc * gf;
+      else dc_one = dc * gf;
+      const float d_o = dh * tc, d_i = dc * gg, d_g = dc * gi, d_f = dc * cp;
+      const unsigned z0 = f2bf(d_i * gi * (1.f - gi)), z1 = f2bf(d_f * gf * (1.f - gf));
+      const unsigned z2 = f2bf(d_g * (1.f - gg * gg)), z3 = f2bf(d_o * go * (1.f - go));
+      const bool row_ok = (r0 + er) < B;
+      if (row_ok && alive) {
+        dbacc[0] += bf2f((bf16_t)z0); dbacc[1] += bf2f((bf16_t)z1); dbacc[2] += bf2f((bf16_t)z2); dbacc[3] += bf2f((bf16_t)z3);
+      }
+      pub[(0 * 16 + er) * UN + eu] = (bf16_t)z0;
+      pub[(1 * 16 + er) * UN + eu] = (bf16_t)z1;
+      pub[(2 * 16 + er) * UN + eu] = (bf16_t)z2;
+      pub[(3 * 16 + er) * UN + eu] = (bf16_t)z3;
+      __syncthreads();
+      // publish dZ[t]: waves 0-3, one 16-byte store per lane (the data is its own signal)
+      if (wave < 4) {
+        const int g = tid >> 6, prow = (tid >> 2) & 15, seg = tid & 3;
+        if (alive && r0 + prow < B) {
+          const uint4 v = *reinterpret_cast<const uint4*>(pub + (g * 16 + prow) * UN + seg * 8);
+          const unsigned off = (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2);
+          if (local) store16(rs_own, off, 0u, v);      // stays in this XCD's L2, where all its readers are
+          else store16_sc1(rs_own, off, v);
+        }
+      }
+    }
+  }
+  // db[g*W + u] += sum over this workgroup's rows and all steps
+  if (a.db) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(a_tile);     // [4 gates][16 rows][32 units]
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[(g * 16 + er) * UN + eu] = dbacc[g];
+    __syncthreads();
+    if (tid < 4 * UN) {
+      const int g = tid >> 5, u = tid & 31;
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += red[(g * 16 + r) * UN + u];
+      atomicAdd(a.db + (long)g * W + u0 + u, sum);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- forward
+// z[t] = P1[t] (input side + bias, all steps at once by the big GEMM) + h[t-1] . U; gates, c, h; G / C / Hd kept for the backward.
+template <int KSTEPS, int MAXRB>
+__global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFwd a) {
+  constexpr int W = KSTEPS * 32;
+  constexpr int KQ = KSTEPS / 4;
+  constexpr int NWG_RB = W / UN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq4 = wave & 3, ug = wave >> 2;
+  const int n_rg = a.n_rg, n_rb = a.n_rb, B = a.B, T = a.T;
+  int cg, rq, rg, xcd;
+  w32_placement(NWG_RB, n_rg, cg, rq, rg, xcd);
+  if (rg >= n_rg) return;
+  const int u0 = cg * UN;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* a_tile = smem;                                                                  // [KSTEPS][1 KiB]
+  float (*zt)[4][16][17] = reinterpret_cast<float (*)[4][16][17]>(smem + KSTEPS * 1024);          // [8 waves][4 gates][16][17]
+  bf16_t* pub = reinterpret_cast<bf16_t*>(smem + KSTEPS * 1024 + 8 * 4 * 16 * 17 * 4);           // [16 rows][32 units] h
+  bf16_t* st_hd = pub + 16 * UN;                                                                 // [16][32] masked h
+  bf16_t* st_g = st_hd + 16 * UN;                                                                // [4 gates][16][32]
+  float* st_c = reinterpret_cast<float*>(st_g + 4 * 16 * UN);                                    // [16][32]
+  int* flags = reinterpret_cast<int*>(st_c + 16 * UN);
+  int& ok_flag = flags[0];
+  float* c_slot = reinterpret_cast<float*>(smem + KL_W32_FWD_LDS(KSTEPS)) + tid;                 // [MAXRB][512]
+
+  const int kq = (lane >> 4) * 8;
+  uint4 bu[4][KQ];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const long wrow = ((long)g * W + u0 + ug * 16 + (lane & 15)) * W + (kq4 * KQ) * 32 + kq;
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) bu[g][j] = *reinterpret_cast<const uint4*>(a.UT[0] + wrow + j * 32);
+  }
+  const int er = tid >> 5, eu = tid & 31;
+  const float* maskl = a.mask[0];
+  const float* P = a.P1;
+  unsigned* status = a.status;
+  float c_one = 0.f;
+  for (int i = 0; i < MAXRB; ++i) {
+    const int rb = rg + i * n_rg;
+    const int row = min(rb * 16 + er, B - 1);
+    const float c0 = (rb < n_rb) ? a.C[0][(long)row * W + u0 + eu] : 0.f;
+    if (MAXRB > 1) c_slot[i * NT] = c0;
+    else c_one = c0;
+  }
+  const long BW = (long)B * W;
+  const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(a.H[0], (long)(T + 1) * BW * 2);
+  const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(a.C[0], (long)(T + 1) * BW * 4);
+  const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.G[0], a.G[0] ? (long)T * BW * 4 * 2 : 0);      // zero records: stores dropped
+  const __amdgpu_buffer_rsrc_t rs_hd = make_rsrc(a.Hd[0], a.Hd[0] ? (long)T * BW * 2 : 0);
+  bool alive = true;
+  constexpr bool PREF = MAXRB > 1;
+  const bool pref_ok = (B & 15) == 0;
+  const int n_raw = maskl ? 5 : 4;
+  const unsigned lds_a = (unsigned)(size_t)(lds_void_t*)a_tile;
+  int pf_issued = 0;
+  if (tid == 0) ok_flag = 1;
+  __syncthreads();
+  bool local = false;
+  if (a.xcc_slots)
+    local = xcd_local_group(a.xcc_slots, a.gen, NWG_RB, [&](int j) { return xcd + 8 * (rq * NWG_RB + j); }, flags + 1, status);
+  const bool dma_wave = wave >= 4;
+  const int dq = wave - 4;                         // DMA wave: k-steps dq*KQ .. +KQ of the tile
+
+  for (int t = 0; t < T; ++t) {
+#pragma unroll 1
+    for (int i = 0; i < MAXRB; ++i) {
+      const int rb = rg + i * n_rg;
+      if (rb >= n_rb) continue;
+      const int r0 = rb * 16;
+      const int erow = min(r0 + er, B - 1);
+      const float* p = P + ((long)t * B + erow) * 4 * W + u0 + eu;
+      float za0 = p[0], za1 = p[W], za2 = p[2 * W], za3 = p[3 * W];
+      float mk = maskl ? maskl[(long)erow * W + u0 + eu] : 1.f;
+      if (dma_wave) {
+        // k-steps dq*KQ.. of the 16 x W tile of h[t-1] (block t; block 0 is the carried-in state: never armed)
+        const int arow = min(r0 + (lane & 15), B - 1);
+        const unsigned base = (unsigned)((((long)t * B + arow) * W + (dq * KQ) * 32 + kq) * 2);
+        unsigned char* frag = a_tile + (dq * KQ) * 1024 + lane * 16;
+        bool ok = false;
+        if (alive) {
+          bool issued = PREF && pf_issued;
+          for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
+            if (issued) {
+              wait_vm(n_raw);
+            } else {
+#pragma unroll
+              for (int j = 0; j < KQ; ++j) {
+                if (local) glds16_nt(rs_h, base + j * 64, lds_a + (dq * KQ + j) * 1024);
+                else glds16_sc1(rs_h, base + j * 64, lds_a + (dq * KQ + j) * 1024);
+              }
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            unsigned bits = 0;
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) bits |= sentinel_bits(*reinterpret_cast<const uint4*>(frag + j * 1024));
+            if (__all(t == 0 || sentinel_free(bits))) { ok = true; break; }
+            issued = false;
+            if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            __builtin_amdgcn_s_sleep(2);
+          }
+          if (!ok) {
+            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok_flag = 0;
+          }
+        }
+        if (!ok) {
+#pragma unroll
+          for (int j = 0; j < KQ; ++j) *reinterpret_cast<uint4*>(frag + j * 1024) = uint4{0, 0, 0, 0};
+        }
+      }
+      __syncthreads();
+      alive = ok_flag != 0;
+      f32x4 acc[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) {
+        frag16 fa;
+        fa.u = *reinterpret_cast<const uint4*>(a_tile + (kq4 * KQ + j) * 1024 + lane * 16);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          frag16 fb;
+          fb.u = bu[g][j];
+          acc[g] = mfma16(fa.v, fb.v, acc[g]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zt[wave][g][(lane >> 4) * 4 + r][lane & 15] = acc[g][r];
+      __syncthreads();
+      asm volatile("" : "+v"(za0), "+v"(za1), "+v"(za2), "+v"(za3), "+v"(mk));
+      if (PREF) {
+        pf_issued = 0;
+        int ni = i + 1, nt = t;
+        if (ni >= MAXRB || rg + ni * n_rg >= n_rb) { ni = 0; nt = t + 1; }
+        // (the next block of the SAME step was published a whole step ago; the first block of the next step is being
+        //  published right now by the partners: too early to ask, it is polled at its top)
+        if (dma_wave && pref_ok && alive && nt == t) {
+          const int nr0 = (rg + ni * n_rg) * 16;
+          const unsigned nbase = (unsigned)((((long)nt * B + nr0 + (lane & 15)) * W + (dq * KQ) * 32 + kq) * 2);
+#pragma unroll
+          for (int j = 0; j < KQ; ++j) {
+            if (local) glds16_nt(rs_h, nbase + j * 64, lds_a + (dq * KQ + j) * 1024);
+            else glds16_sc1(rs_h, nbase + j * 64, lds_a + (dq * KQ + j) * 1024);
+          }
+          pf_issued = 1;
+        }
+      }
+      const int wz = (eu >> 4) * 4, ec = eu & 15;
+      const float z0 = za0 + zt[wz][0][er][ec] + zt[wz + 1][0][er][ec] + zt[wz + 2][0][er][ec] + zt[wz + 3][0][er][ec];
+      const float z1 = za1 + zt[wz][1][er][ec] + zt[wz + 1][1][er][ec] + zt[wz + 2][1][er][ec] + zt[wz + 3][1][er][ec];
+      const float z2 = za2 + zt[wz][2][er][ec] + zt[wz + 1][2][er][ec] + zt[wz + 2][2][er][ec] + zt[wz + 3][2][er][ec];
+      const float z3 = za3 + zt[wz][3][er][ec] + zt[wz + 1][3][er][ec] + zt[wz + 2][3][er][ec] + zt[wz + 3][3][er][ec];
+      const float gi = fast_sigmoid(z0), gf = fast_sigmoid(z1), gg = fast_tanh(z2), go = fast_sigmoid(z3);
+      const float cprev = MAXRB > 1 ? c_slot[i * NT] : c_one;
+      const float c = gf * cprev + gi * gg;
+      if (MAXRB > 1) c_slot[i * NT] = c;
+      else c_one = c;
+      const float h = go * fast_tanh(c);
+      pub[er * UN + eu] = f2bf(h);
+      st_hd[er * UN + eu] = f2bf(h * mk);
+      st_g[(0 * 16 + er) * UN + eu] = f2bf(gi);
+      st_g[(1 * 16 + er) * UN + eu] = f2bf(gf);
+      st_g[(2 * 16 + er) * UN + eu] = f2bf(gg);
+      st_g[(3 * 16 + er) * UN + eu] = f2bf(go);
+      st_c[er * UN + eu] = c;
+      __syncthreads();
+      // waves 0-3 store: the publish of h first (write-through, or plain inside one XCD), then what only later launches read
+      if (wave < 4 && alive) {
+        if (tid < 64) {
+          const int prow = tid >> 2, seg = tid & 3;
+          if (r0 + prow < B) {
+            const uint4 v = *reinterpret_cast<const uint4*>(pub + prow * UN + seg * 8);
+            const unsigned off = (unsigned)((((long)(t + 1) * B + r0 + prow) * W + u0 + seg * 8) * 2);
+            if (local) store16(rs_h, off, 0u, v);
+            else store16_sc1(rs_h, off, v);
+          }
+        }
+        {
+          const int g = tid >> 6, prow = (tid >> 2) & 15, seg = tid & 3;
+          if (r0 + prow < B)
+            store16(rs_g, (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2), 0u,
+                    *reinterpret_cast<const uint4*>(st_g + (g * 16 + prow) * UN + seg * 8));
+        }
+        if (tid >= 64 && tid < 192) {
+          const int q = tid - 64, prow = q >> 3, seg = q & 7;
+          if (r0 + prow < B)
+            store16(rs_c, (unsigned)((((long)(t + 1) * B + r0 + prow) * W + u0 + seg * 4) * 4), 0u,
+                    *reinterpret_cast<const uint4*>(st_c + prow * UN + seg * 4));
+        } else if (tid >= 192) {
+          const int q = tid - 192, prow = q >> 2, seg = q & 3;
+          if (r0 + prow < B)
+            store16(rs_hd, (unsigned)((((long)t * B + r0 + prow) * W + u0 + seg * 8) * 2), 0u,
+                    *reinterpret_cast<const uint4*>(st_hd + prow * UN + seg * 8));
+        }
+      }
+    }
+  }
+}
+
+int w32_cus() {
+  static int v = 0;
+  if (!v) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      v = prop.multiProcessorCount;
+    else
+      v = 256;
+    if (v > 256) v = 256;
+  }
+  return v;
+}
+
+bool w32_plan(int B, int T, int W, int* n_rb, int* n_rg, int* per_wg) {
+  if (W != 1024 || B < 1 || T < 1) return false;
+  *n_rb = (B + 15) / 16;
+  int g = w32_cus() / (W / UN);          // one workgroup per CU
+  if (g < 1) return false;
+  if (g > *n_rb) g = *n_rb;
+  *n_rg = g;
+  *per_wg = (*n_rb + g - 1) / g;
+  if (*per_wg > 8) return false;
+  return (long)T * B * 4 * W * 2 <= 0xfffffff0L && (long)(T + 1) * B * W * 4 <= 0xfffffff0L;   // unsigned 32-bit buffer offsets
+}
+
+}  // namespace
+
+bool kl_scan_w32_applicable(int B, int T, int W) {
+  int n_rb, n_rg, per_wg;
+  return w32_plan(B, T, W, &n_rb, &n_rg, &per_wg);
+}
+
+#define KL_W32_LAUNCH(KERNEL, RB, LDS0)                                                                              \
+  do {                                                                                                               \
+    const size_t lds = (size_t)(LDS0) + (size_t)((RB) > 1 ? (RB) : 0) * NT * sizeof(float);                          \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL<32, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)lds) != hipSuccess) return KL_ERR_LAUNCH;                                           \
+    hipLaunchKernelGGL((KERNEL<32, RB>), grid, block, lds, stream, a);                                               \
+  } while (0)
+
+// One-layer backward scan, width 1024 (a.L must be 1; a.sentinel must be 1: all of dZ pre-filled with 0xFFFF halfwords).
+int kl_launch_scan_bwd_w32(KlScanBwd a, hipStream_t stream) {
+  int per_wg = 0;
+  if (a.L != 1 || a.sentinel != 1 || !w32_plan(a.B, a.T, a.W, &a.n_rb, &a.n_rg, &per_wg)) return KL_ERR_SHAPE;
+  dim3 grid(8 * (a.W / UN) * ((a.n_rg + 7) / 8)), block(NT);
+  if (per_wg == 1) KL_W32_LAUNCH(lstm_scan_bwd_w32_kernel, 1, KL_W32_BWD_LDS(32));
+  else if (per_wg == 2) KL_W32_LAUNCH(lstm_scan_bwd_w32_kernel, 2, KL_W32_BWD_LDS(32));
+  else if (per_wg <= 4) KL_W32_LAUNCH(lstm_scan_bwd_w32_kernel, 4, KL_W32_BWD_LDS(32));
+  else KL_W32_LAUNCH(lstm_scan_bwd_w32_kernel, 8, KL_W32_BWD_LDS(32));
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+// One-layer forward scan, width 1024 (a.L must be 1; a.sentinel must be 1: blocks 1..T of H pre-filled; input side in P1).
+int kl_launch_scan_fwd_w32(KlScanFwd a, hipStream_t stream) {
+  int per_wg = 0;
+  if (a.L != 1 || a.sentinel != 1 || !a.P1 || !w32_plan(a.B, a.T, a.W, &a.n_rb, &a.n_rg, &per_wg)) return KL_ERR_SHAPE;
+  dim3 grid(8 * (a.W / UN) * ((a.n_rg + 7) / 8)), block(NT);
+  if (per_wg == 1) KL_W32_LAUNCH(lstm_scan_fwd_w32_kernel, 1, KL_W32_FWD_LDS(32));
+  else if (per_wg == 2) KL_W32_LAUNCH(lstm_scan_fwd_w32_kernel, 2, KL_W32_FWD_LDS(32));
+  else if (per_wg <= 4) KL_W32_LAUNCH(lstm_scan_fwd_w32_kernel, 4, KL_W32_FWD_LDS(32));
+  else KL_W32_LAUNCH(lstm_scan_fwd_w32_kernel, 8, KL_W32_FWD_LDS(32));
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}

@@ -399,6 +399,23 @@ def test_train_window_scan2(monkeypatch, depth, width, voc, B, T, n_ctx, use_mas
     check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks, want_kernel="lstm_scan_fwd_wide2_kernel")
 
 
+@pytest.mark.parametrize("depth,width,voc,B,T,n_ctx,use_masks,env", [
+    (2, 1024, 40, 16, 5, 1, True, {}),                          # one row block, one workgroup per column group
+    (4, 1024, 64, 48, 4, 2, True, {}),                          # three row groups; the cfg5 topology
+    (2, 1024, 40, 40, 4, 1, False, {}),                         # ragged last row block (no prefetch: partial tiles)
+    (2, 1024, 40, 144, 5, 1, True, {}),                         # nine row blocks on eight row groups: two visits, uneven; prefetched tiles
+    (2, 1024, 40, 512, 3, 1, True, {}),                         # four row blocks per workgroup (the cfg5 bench shape's plan)
+    (1, 1024, 40, 1024, 2, 0, False, {}),                       # eight per workgroup; one layer, no context, no dropout
+    (2, 1024, 40, 256, 4, 1, True, {"KL_W32_LOCAL": "1"})])     # publishes through the XCD's own L2
+def test_train_window_width_1024_scans(monkeypatch, depth, width, voc, B, T, n_ctx, use_masks, env):
+    """Width 1024: the eight-wave scans of lstm_scan_w32.hip (32 units per workgroup, the tile through LDS, data sentinels),
+    forced on from one row block: gradients, loss and carried state against the f64 oracle."""
+    monkeypatch.setenv("KL_W32_MIN_RB", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks, want_kernel="lstm_scan_bwd_w32_kernel")
+
+
 def test_flag_handoff_survives_changing_shapes():
     """The backward scan's flag hand-off keeps ONE set of flag words and an epoch per engine: windows of changing size and
     length on the same engine (hipGraph replays in between) must give what a fresh engine gives for the same inputs --
