@@ -53,7 +53,7 @@ __device__ __forceinline__ void w32_placement(int NWG_RB, int n_rg, int& cg, int
 
 // LDS bytes in front of the per-row-block state slots [MAXRB][512] f32
 #define KL_W32_BWD_LDS(KS) (4 * (KS) * 1024 + 8 * 16 * 17 * 4 + 4 * 16 * UN * 2 + 16)
-#define KL_W32_FWD_LDS(KS) ((KS) * 1024 + 8 * 4 * 16 * 17 * 4 + 16 * UN * 2 * 2 + 4 * 16 * UN * 2 + 16 * UN * 4 + 16)
+#define KL_W32_FWD_LDS(KS) (2 * (KS) * 1024 + 8 * 4 * 16 * 17 * 4 + 16 * UN * 2 * 2 + 4 * 16 * UN * 2 + 16 * UN * 4 + 16)
 
 // ---------------------------------------------------------------- backward
 // dh[t] = dH[t] (from above, all steps at once by the big GEMM) + dZ[t+1] . U^T; dZ[t] from the gate derivatives; db summed here.
@@ -312,9 +312,9 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
   const int u0 = cg * UN;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* a_tile = smem;                                                                  // [KSTEPS][1 KiB]
-  float (*zt)[4][16][17] = reinterpret_cast<float (*)[4][16][17]>(smem + KSTEPS * 1024);          // [8 waves][4 gates][16][17]
-  bf16_t* pub = reinterpret_cast<bf16_t*>(smem + KSTEPS * 1024 + 8 * 4 * 16 * 17 * 4);           // [16 rows][32 units] h
+  unsigned char* a_tile = smem;                                                                  // [2 buffers][KSTEPS][1 KiB]
+  float (*zt)[4][16][17] = reinterpret_cast<float (*)[4][16][17]>(smem + 2 * KSTEPS * 1024);      // [8 waves][4 gates][16][17]
+  bf16_t* pub = reinterpret_cast<bf16_t*>(smem + 2 * KSTEPS * 1024 + 8 * 4 * 16 * 17 * 4);       // [16 rows][32 units] h
   bf16_t* st_hd = pub + 16 * UN;                                                                 // [16][32] masked h
   bf16_t* st_g = st_hd + 16 * UN;                                                                // [4 gates][16][32]
   float* st_c = reinterpret_cast<float*>(st_g + 4 * 16 * UN);                                    // [16][32]
@@ -352,7 +352,6 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
   const bool pref_ok = (B & 15) == 0;
   const int n_raw = maskl ? 5 : 4;
   const unsigned lds_a = (unsigned)(size_t)(lds_void_t*)a_tile;
-  int pf_issued = 0;
   if (tid == 0) ok_flag = 1;
   __syncthreads();
   bool local = false;
@@ -360,6 +359,28 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
     local = xcd_local_group(a.xcc_slots, a.gen, NWG_RB, [&](int j) { return xcd + 8 * (rq * NWG_RB + j); }, flags + 1, status);
   const bool dma_wave = wave >= 4;
   const int dq = wave - 4;                         // DMA wave: k-steps dq*KQ .. +KQ of the tile
+  // Two tile buffers: the NEXT block's tile is requested as soon as this block's has arrived and travels under this
+  // block's MFMAs, epilogue and stores.  The epilogue inputs (P1 rows, mask) are loaded a block ahead as well, right
+  // behind that request, so that a DMA wave's queue reads [tile n+1][inputs n+1] and the counted wait for the tile
+  // (at most n_raw younger loads outstanding) is exact -- the compiler's own wait for the inputs, one block later,
+  // finds them long arrived.
+  int cur = 0, pf_issued = 0;
+  auto request_tile = [&](int buf, int nt, int nr0) {
+    const unsigned nbase = (unsigned)((((long)nt * B + min(nr0 + (lane & 15), B - 1)) * W + (dq * KQ) * 32 + kq) * 2);
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) {
+      if (local) glds16_nt(rs_h, nbase + j * 64, lds_a + buf * (KSTEPS * 1024) + (dq * KQ + j) * 1024);
+      else glds16_sc1(rs_h, nbase + j * 64, lds_a + buf * (KSTEPS * 1024) + (dq * KQ + j) * 1024);
+    }
+  };
+  // the first block's inputs
+  float zn0, zn1, zn2, zn3, mkn;
+  {
+    const int erow = min(rg * 16 + er, B - 1);
+    const float* p = P + (long)erow * 4 * W + u0 + eu;
+    zn0 = p[0]; zn1 = p[W]; zn2 = p[2 * W]; zn3 = p[3 * W];
+    mkn = maskl ? maskl[(long)erow * W + u0 + eu] : 1.f;
+  }
 
   for (int t = 0; t < T; ++t) {
 #pragma unroll 1
@@ -367,15 +388,11 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
       const int rb = rg + i * n_rg;
       if (rb >= n_rb) continue;
       const int r0 = rb * 16;
-      const int erow = min(r0 + er, B - 1);
-      const float* p = P + ((long)t * B + erow) * 4 * W + u0 + eu;
-      float za0 = p[0], za1 = p[W], za2 = p[2 * W], za3 = p[3 * W];
-      float mk = maskl ? maskl[(long)erow * W + u0 + eu] : 1.f;
+      float za0 = zn0, za1 = zn1, za2 = zn2, za3 = zn3, mk = mkn;
+      unsigned char* tile = a_tile + cur * (KSTEPS * 1024);
       if (dma_wave) {
         // k-steps dq*KQ.. of the 16 x W tile of h[t-1] (block t; block 0 is the carried-in state: never armed)
-        const int arow = min(r0 + (lane & 15), B - 1);
-        const unsigned base = (unsigned)((((long)t * B + arow) * W + (dq * KQ) * 32 + kq) * 2);
-        unsigned char* frag = a_tile + (dq * KQ) * 1024 + lane * 16;
+        unsigned char* frag = tile + (dq * KQ) * 1024 + lane * 16;
         bool ok = false;
         if (alive) {
           bool issued = PREF && pf_issued;
@@ -383,11 +400,7 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
             if (issued) {
               wait_vm(n_raw);
             } else {
-#pragma unroll
-              for (int j = 0; j < KQ; ++j) {
-                if (local) glds16_nt(rs_h, base + j * 64, lds_a + (dq * KQ + j) * 1024);
-                else glds16_sc1(rs_h, base + j * 64, lds_a + (dq * KQ + j) * 1024);
-              }
+              request_tile(cur, t, r0);
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             unsigned bits = 0;
@@ -410,13 +423,34 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
       }
       __syncthreads();
       alive = ok_flag != 0;
+      // (this block's inputs were loaded a block ago: the wait the compiler puts here is free, and it keeps that wait in
+      //  front of the requests below)
+      asm volatile("" : "+v"(za0), "+v"(za1), "+v"(za2), "+v"(za3), "+v"(mk));
+      {
+        // the block this workgroup visits next: its tile (with several blocks per workgroup it was published at least
+        // a block ago; with one, it is being published right now: polled at its top) and its inputs
+        int ni = i + 1, nt = t;
+        if (ni >= MAXRB || rg + ni * n_rg >= n_rb) { ni = 0; nt = t + 1; }
+        const int nr0 = (rg + ni * n_rg) * 16;
+        pf_issued = 0;
+        if (PREF && dma_wave && pref_ok && alive && nt < T) {
+          request_tile(cur ^ 1, nt, nr0);
+          pf_issued = 1;
+        }
+        if (nt < T) {
+          const int nrow = min(nr0 + er, B - 1);
+          const float* p = P + ((long)nt * B + nrow) * 4 * W + u0 + eu;
+          zn0 = p[0]; zn1 = p[W]; zn2 = p[2 * W]; zn3 = p[3 * W];
+          mkn = maskl ? maskl[(long)nrow * W + u0 + eu] : 1.f;
+        }
+      }
       f32x4 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < KQ; ++j) {
         frag16 fa;
-        fa.u = *reinterpret_cast<const uint4*>(a_tile + (kq4 * KQ + j) * 1024 + lane * 16);
+        fa.u = *reinterpret_cast<const uint4*>(tile + (kq4 * KQ + j) * 1024 + lane * 16);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           frag16 fb;
@@ -428,25 +462,8 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int r = 0; r < 4; ++r) zt[wave][g][(lane >> 4) * 4 + r][lane & 15] = acc[g][r];
+      cur ^= 1;
       __syncthreads();
-      asm volatile("" : "+v"(za0), "+v"(za1), "+v"(za2), "+v"(za3), "+v"(mk));
-      if (PREF) {
-        pf_issued = 0;
-        int ni = i + 1, nt = t;
-        if (ni >= MAXRB || rg + ni * n_rg >= n_rb) { ni = 0; nt = t + 1; }
-        // (the next block of the SAME step was published a whole step ago; the first block of the next step is being
-        //  published right now by the partners: too early to ask, it is polled at its top)
-        if (dma_wave && pref_ok && alive && nt == t) {
-          const int nr0 = (rg + ni * n_rg) * 16;
-          const unsigned nbase = (unsigned)((((long)nt * B + nr0 + (lane & 15)) * W + (dq * KQ) * 32 + kq) * 2);
-#pragma unroll
-          for (int j = 0; j < KQ; ++j) {
-            if (local) glds16_nt(rs_h, nbase + j * 64, lds_a + (dq * KQ + j) * 1024);
-            else glds16_sc1(rs_h, nbase + j * 64, lds_a + (dq * KQ + j) * 1024);
-          }
-          pf_issued = 1;
-        }
-      }
       const int wz = (eu >> 4) * 4, ec = eu & 15;
       const float z0 = za0 + zt[wz][0][er][ec] + zt[wz + 1][0][er][ec] + zt[wz + 2][0][er][ec] + zt[wz + 3][0][er][ec];
       const float z1 = za1 + zt[wz][1][er][ec] + zt[wz + 1][1][er][ec] + zt[wz + 2][1][er][ec] + zt[wz + 3][1][er][ec];
