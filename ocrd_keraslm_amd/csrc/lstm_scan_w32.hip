@@ -4,7 +4,7 @@
 // lstm_scan2.hip) are 512 KiB -- the whole register file of a CU -- so round 2 ran this width through the THIN scans:
 // 256-thread workgroups of 16 units that each pull the whole 16 x 4W tile of a row block straight into registers, two
 // workgroups per CU.  Per row block that is 2 x 128 KiB into one CU in the backward scan with nothing overlapped
-// (profiles/r03_cfg5_B512_kernel_stats.csv: 18.4 ms per layer backward, 8.7 ms forward, 4.8 % / 10 % of the MFMA roof).
+// (profiles/r03_cfg5_B512_thin_scans_start_of_round_kernel_stats.csv: 18.4 ms per layer backward, 8.7 ms forward, 4.8 % / 10 % of the MFMA roof).
 //
 // Here a workgroup is 8 waves = 4 K-quarters x 2 unit groups = 32 units, one per CU (weights: 128 registers per lane,
 // the budget is 256), so W/32 = 32 workgroups produce a row block and 256 CUs serve 8 row groups -- one row group per
