@@ -699,7 +699,10 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
       SSTAMP(18);
       alive = ok_flag != 0;
       const int arow = min(r0 + (lane & 15), B - 1);
+      // (two partial sums per contraction: with one wave per SIMD -- few streams -- a single accumulator makes every MFMA
+      //  wait out the one before it, ~0.5 us per contraction and step at width 512)
       f32x4 acc_up = f32x4{0.f, 0.f, 0.f, 0.f}, acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 acc_up2 = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
       if (UP && alive && has_up) {
         uint4 av[UP ? KSTEPS : 1];
         const unsigned base = (unsigned)((((long)t * B + arow) * 4 * W + (long)wave * W + kq) * 2);
@@ -710,7 +713,8 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
           frag16 fa, fb;
           fa.u = av[j];
           fb.u = bk[j];
-          acc_up = mfma16(fa.v, fb.v, acc_up);
+          if (j & 1) acc_up2 = mfma16(fa.v, fb.v, acc_up2);
+          else acc_up = mfma16(fa.v, fb.v, acc_up);
         }
       }
       if (alive && t < T - 1) {
@@ -727,12 +731,13 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a
             frag16 fa, fb;
             fa.u = av[j];
             fb.u = bu[c0 + j];
-            acc = mfma16(fa.v, fb.v, acc);
+            if (j & 1) acc2 = mfma16(fa.v, fb.v, acc2);
+            else acc = mfma16(fa.v, fb.v, acc);
           }
         }
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) zt[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r] + acc_up[r] * omask[r];
+      for (int r = 0; r < 4; ++r) zt[wave][(lane >> 4) * 4 + r][lane & 15] = (acc[r] + acc2[r]) + (acc_up[r] + acc_up2[r]) * omask[r];
       SSTAMP(19);
       __syncthreads();
       SSTAMP(20);

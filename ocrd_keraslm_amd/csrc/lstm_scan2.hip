@@ -36,6 +36,10 @@
 #include "kl_common.h"
 #include "kl_kernels.h"
 
+#ifndef KL_FWD_VAR
+#define KL_FWD_VAR 0      /* timing experiments on the forward scan only (tools/gpu_variants.sh) */
+#endif
+
 namespace {
 
 #define KL_STAMP_ARRAY kl_scan2_stamps
@@ -513,7 +517,10 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide2_kernel(const KlSc
         for (int s = 0; s < NB; ++s) fr[0][s] = *reinterpret_cast<const u32x4*>(tb + frag_lane + s * 16 * 1024);
 #pragma unroll
         for (int q = 0; q < KSTEPS; ++q) {
-          if (q + 1 < KSTEPS) {
+#if KL_FWD_VAR & 1       /* timing experiments only (tools/gpu_variants.sh): 1 = no MFMA phase, 2 = half the fragment reads, 4 = half the MFMAs */
+          continue;
+#endif
+          if (q + 1 < KSTEPS && !((KL_FWD_VAR & 2) && (q & 1))) {
             const int q1 = q + 1;
             const unsigned char* ap = tb + (frag_lane ^ (unsigned)(64 * (q1 >> 2))) + 256 * (q1 & 3);
 #pragma unroll
@@ -521,8 +528,10 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_fwd_wide2_kernel(const KlSc
           }
           __builtin_amdgcn_sched_barrier(0);
           const bf16x8 fb = __builtin_bit_cast(bf16x8, bu[4 * (q & 3) + (q >> 2)]);
+          if (!((KL_FWD_VAR & 4) && (q & 1))) {
 #pragma unroll
-          for (int s = 0; s < NB; ++s) acc[s] = mfma16(__builtin_bit_cast(bf16x8, fr[q & 1][s]), fb, acc[s]);
+            for (int s = 0; s < NB; ++s) acc[s] = mfma16(__builtin_bit_cast(bf16x8, fr[q & 1][s]), fb, acc[s]);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }

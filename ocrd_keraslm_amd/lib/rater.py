@@ -146,6 +146,7 @@ class Rater(object):
         self.max_epochs = 100
         self.patience = 3
         self.seed = None
+        self.device_dropout_masks = True     # ... and their dropout masks drawn on the device (False: by the host generator, as without batching)
         self.batched_streams = True          # the B streams of stateful training advanced together (streams.StreamBatcher)
         self.batched_streams_max_chars = 1 << 30
         self._engine_factory = engine_factory
@@ -264,7 +265,7 @@ class Rater(object):
             train_gens = make_streams(training_data, True)
             val_gens = make_streams(validation_data, False)
         self._texts = {}
-        draw_masks = getattr(lm, "draw_dropout_masks_device", None) if self.batched_streams else None
+        draw_masks = getattr(lm, "draw_dropout_masks_device", None) if (self.batched_streams and self.device_dropout_masks) else None
         draw_masks = draw_masks or lm.draw_dropout_masks
         steps_per_epoch = max(1, ceil(training_epoch_size / n_streams))
         val_steps = max(1, ceil(validation_epoch_size / n_streams))

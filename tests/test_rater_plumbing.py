@@ -87,6 +87,48 @@ def test_train_save_load_rate(factory, width, length, size):
             os.chdir(cwd)
 
 
+@pytest.mark.parametrize("factory,width,length,streams", [
+    pytest.param(OracleLM, 16, 8, 3, id="oracle-cpu"),
+    pytest.param(hip_factory, 128, 32, 5, id="hip", marks=pytest.mark.gpu)])
+def test_train_batched_streams_equal_one_generator_per_stream(factory, width, length, streams):
+    """Rater.train with several stateful streams: the batched window generation (streams.StreamBatcher, batches gathered
+    where the engine lives) and the reference-shaped path (one generator per stream) see the same batches in the same
+    order -- same loss history, same weights (the dropout masks come from the engine's generator either way: drawn on the
+    host in both runs here: `device_dropout_masks = False`)"""
+    histories, weights = [], []
+    with tempfile.TemporaryDirectory() as tmp:
+        names = synth_files(tmp, n=2 * streams + 3, size=40 * length + 7, seed=4)
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            for batched in (True, False):
+                random.seed(3)
+                r = Rater(engine_factory=factory)
+                r.width, r.depth, r.length = width, 2, length
+                r.max_epochs = 2
+                r.seed = 5
+                r.streams = streams
+                r.batched_streams = batched
+                r.device_dropout_masks = False
+                r.configure()
+                r.train([open(n) for n in names])
+                assert r.status == 2
+                histories.append(r.history)
+                weights.append(r.model.get_weights())
+        finally:
+            os.chdir(cwd)
+    # (the oracle engine is deterministic: bitwise equal; the HIP engine accumulates its weight gradients with f32 atomics
+    #  over split-K partial products, whose order differs from run to run)
+    exact = factory is OracleLM
+    for key in ("loss", "accuracy", "val_loss", "val_accuracy"):
+        assert np.allclose(histories[0][key], histories[1][key], rtol=1e-6 if exact else 2e-3, atol=1e-7 if exact else 1e-4), (key, histories)
+    for k, v in weights[0].items():
+        if exact:
+            assert np.array_equal(v, weights[1][k]), k
+        else:
+            assert np.abs(v - weights[1][k]).max() <= 1e-4 + 1e-2 * np.abs(v).max(), k
+
+
 def test_embedding_plots(tmp_path):
     """the three offline views of the embeddings (rating.py:1169-1237) write PNG files of the right size"""
     pytest.importorskip("matplotlib")
