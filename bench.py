@@ -493,9 +493,42 @@ def main():
             cfg5["incremental"] = dict(incremental_leg(lm5, device, D5, W5, C5, 1024, 128), unit="hypotheses*chars/s",
                                        precision="split-bf16 (3 MFMA passes)")
             cfg5["incremental_n128"] = dict(incremental_leg(lm5, device, D5, W5, C5, 128, 128), unit="hypotheses*chars/s")
+            # the rating window at the reference's batching: 1 stream x 512 chars, split precision
+            lm5.reset_states(1)
+            r5 = np.random.default_rng(12)
+            xi5 = torch.from_numpy(r5.integers(1, VOC, size=(1, T5)).astype(np.int32)).to(device)
+            ci5 = torch.from_numpy(r5.integers(0, 200, size=(1, 1, C5)).repeat(T5, axis=1).astype(np.int32)).to(device)
+            for _ in range(3):
+                lm5.forward_window(xi5, ci5)
+            torch.cuda.synchronize()
+            t5 = time.perf_counter()
+            for _ in range(20):
+                lm5.forward_window(xi5, ci5)
+            torch.cuda.synchronize()
+            ms5 = (time.perf_counter() - t5) / 20 * 1e3
+            cfg5["rating_window"] = {"value": T5 / ms5 * 1e3, "unit": "chars/s", "ms_per_window": ms5, "streams": 1, "seq_len": T5,
+                                     "precision": "split-bf16 (3 MFMA passes)"}
             del lm5
         except Exception as err:
             cfg5 = dict(cfg5 or {}, error=repr(err))
+        torch.cuda.empty_cache()
+
+    # ---- the reference's own model sizes (README.md:252-254: the published model is depth 2, width 128, length 256;
+    # its README example width 64): training at 1024 streams and at the reference's batching
+    ref_models = None
+    if rank == 0 and world == 1 and not args.no_extra_shapes:
+        ref_models = {}
+        for Wm in (128, 64):
+            try:
+                entry = {}
+                for Bs, st in ((1024, 50), (1, 100)):
+                    leg, lmm = training_leg(device, DEPTH, Wm, LENGTH, N_CTX, Bs, st, 5, corpus[:max(Bs, 64) * (CORPUS // 1024)])
+                    del lmm
+                    entry["streams_%d" % Bs] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps")}
+                ref_models["width_%d" % Wm] = entry
+            except Exception as err:
+                ref_models["width_%d" % Wm] = {"error": repr(err)}
+        ref_models["note"] = "depth 2, length 256, V=256, 1 context; width 128 = the published model's topology (README.md:252-254)"
         torch.cuda.empty_cache()
 
     # ---- end to end: Rater.train over synthetic files (rank 0, one GPU): what the Python above the ABI costs
@@ -529,7 +562,7 @@ def main():
                        # (a throughput run: the timed steps pass over each stream's windows several times, the loss means nothing)
                        "corpus_passes": (args.warmup + args.steps) / max(n_windows, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_torch": cpu_torch, "incremental": incremental,
-            "rating_window": rating, "small_batch": small_batch, "cfg5": cfg5, "end_to_end": end_to_end,
+            "rating_window": rating, "small_batch": small_batch, "cfg5": cfg5, "reference_models": ref_models, "end_to_end": end_to_end,
         }
         print(json.dumps(line))
     if world > 1:

@@ -584,6 +584,38 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
     if (all) scanned = true;
     else KL_TRY(kl_launch_p1_gather(d.EK, ctxk.data(), c.n_ctx, P + h->off_b[0], idx, ctx, B, T, 4 * W, w.P1, s));
   }
+  // rating windows in split precision at width 1024 (cfg5): the (hi, lo) planes of the recurrent weights of 16 units are a
+  // workgroup's whole register budget, so the layers run one after the other -- per layer ONE split-precision product
+  // over all steps for the input side (layer 0: the table gather above), then the persistent scan with U alone
+  // (was: a launch per step and layer wavefront, 18 ms per 1 x 512 window)
+  if (!scanned && !training && split == KL_PREC_SPLIT && h->scan_enabled && h->split_sentinel && W == 1024 &&
+      (B + 15) / 16 <= 16 && (long)(T + 1) * B * W * 2 <= 0x7fffffffL) {
+    for (int l = 0; l < L; ++l) {
+      if (l > 0) {
+        KlOperand op;
+        memset(&op, 0, sizeof(op));
+        op.A = (float*)w.H[l - 1] + BW; op.lda = W; op.a_is_f32 = 1;
+        op.WT_hi = d.KT_hi[l]; op.WT_lo = d.KT_lo[l]; op.ldw = W; op.K = W;
+        KL_TRY(kl_launch_thin_gemm(&op, B * T, 4 * W, w.P1, 4 * W, P + h->off_b[l], KL_PREC_SPLIT, s));
+      }
+      KlScanFwdSplit a;
+      memset(&a, 0, sizeof(a));
+      a.B = B; a.T = T; a.W = W; a.L = 1;
+      a.UT_hi[0] = d.UT_hi[l]; a.UT_lo[0] = d.UT_lo[l];
+      a.Xhi[0] = w.Xhi[l]; a.Xlo[0] = w.Xlo[l];
+      a.Hf[0] = (float*)w.H[l];
+      a.C[0] = w.C[l];
+      a.P1 = w.P1;
+      a.counters = w.scan_cnt;
+      a.status = w.scan_status;
+      a.sentinel = 1;
+      KL_TRY(kl_launch_f32_to_bf16_t((const float*)w.H[l], W, B, W, w.Xhi[l], w.Xlo[l], W, 0, s));
+      KL_TRY(kl_fill_u32_async(w.Xhi[l] + BW, (size_t)T * BW * sizeof(bf16_t), 0xFFFFFFFFu, s));
+      KL_TRY(kl_fill_u32_async(w.Xlo[l] + BW, (size_t)T * BW * sizeof(bf16_t), 0xFFFFFFFFu, s));
+      KL_TRY(kl_launch_scan_fwd_split(a, s));
+    }
+    scanned = true;
+  }
   // rating windows in split precision: one persistent launch for all layers and steps
   if (!scanned && !training && split == KL_PREC_SPLIT && h->scan_enabled && L <= KL_SCAN_MAXL) {
     KlScanFwdSplit a;

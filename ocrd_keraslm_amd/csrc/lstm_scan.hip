@@ -437,7 +437,10 @@ __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_kernel(const KlSca
 // h = o * tanh(c) lies inside (-1, 1) and its bf16 remainder is smaller still: bit 14 of every valid halfword (the top
 // exponent bit) is 0 and the check is an OR over the loaded dwords.  Block 0 (the carried-in state, any value) is not
 // polled.  One workgroup barrier per step: the partial tiles alternate between two LDS buffers.
-template <int KSTEPS, int MAXRB>
+// IN = false: one layer per launch whose input side arrives precomputed in P1 (width 1024: the recurrent weights of 16
+// units as (hi, lo) planes alone are 256 registers per lane; the caller runs the layers one after the other and forms
+// P1 = X . K^T + b for all steps by one split-precision GEMM in between).
+template <int KSTEPS, int MAXRB, bool IN = true>
 __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_sent_kernel(const KlScanFwdSplit a) {
   constexpr int KW = KSTEPS < 4 ? KSTEPS : 4;
   constexpr int KQ = KSTEPS / KW;
@@ -451,14 +454,14 @@ __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_sent_kernel(const 
   id -= l * NUG * n_rg;
   const int ug = id / n_rg, rg = id % n_rg;
   const int u0 = ug * 16;
-  const bool has_in = l > 0;
+  const bool has_in = IN && l > 0;
   const bool kactive = wave < KW;
   const int kw = kactive ? wave : 0;
 
   __shared__ float zt[2][4][4][16][17];
 
   const int kq = (lane >> 4) * 8;
-  uint4 bu[2][4][KQ], bk[2][4][KQ];     // [hi/lo][gate][k-step]
+  uint4 bu[2][4][KQ], bk[2][4][IN ? KQ : 1];     // [hi/lo][gate][k-step]
   {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -467,8 +470,10 @@ __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_sent_kernel(const 
       for (int j = 0; j < KQ; ++j) {
         bu[0][g][j] = *reinterpret_cast<const uint4*>(a.UT_hi[l] + wrow + j * 32);
         bu[1][g][j] = *reinterpret_cast<const uint4*>(a.UT_lo[l] + wrow + j * 32);
-        bk[0][g][j] = has_in ? *reinterpret_cast<const uint4*>(a.KT_hi[l] + wrow + j * 32) : uint4{0, 0, 0, 0};
-        bk[1][g][j] = has_in ? *reinterpret_cast<const uint4*>(a.KT_lo[l] + wrow + j * 32) : uint4{0, 0, 0, 0};
+        if (IN) {
+          bk[0][g][j] = has_in ? *reinterpret_cast<const uint4*>(a.KT_hi[l] + wrow + j * 32) : uint4{0, 0, 0, 0};
+          bk[1][g][j] = has_in ? *reinterpret_cast<const uint4*>(a.KT_lo[l] + wrow + j * 32) : uint4{0, 0, 0, 0};
+        }
       }
     }
   }
@@ -544,10 +549,10 @@ __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_sent_kernel(const 
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
       uint4 ahi[KQ], alo[KQ];
-      if (has_in) {      // (the layer below runs ahead: normally there at the first look)
+      if (IN && has_in) {      // (the layer below runs ahead: normally there at the first look)
         fetch(rs_ihi, rs_ilo, abase, true, ahi, alo);
 #pragma unroll
-        for (int j = 0; j < KQ; ++j) {
+        for (int j = 0; j < (IN ? KQ : 1); ++j) {
           frag16 fh, fl;
           fh.u = ahi[j];
           fl.u = alo[j];
@@ -1678,6 +1683,23 @@ int kl_launch_scan_fwd_wide(KlScanFwdWide a, hipStream_t stream) {
 // Split-precision inference scan (all layers fused).  KL_ERR_SHAPE = not applicable.
 int kl_launch_scan_fwd_split(KlScanFwdSplit a, hipStream_t stream) {
   const int W = a.W;
+  if (W == 1024) {
+    // one layer per launch, the input side precomputed in P1, data sentinels only (the caller's layer-sequential path)
+    if (a.L != 1 || !a.sentinel || a.B < 1 || a.T < 1) return KL_ERR_SHAPE;
+    if ((long)(a.T + 1) * a.B * W * 2 > 0x7fffffffL) return KL_ERR_SHAPE;
+    a.n_rb = (a.B + 15) / 16;
+    int g = scan_cus() / (W / 16);
+    if (g < 1) return KL_ERR_SHAPE;
+    if (g > a.n_rb) g = a.n_rb;
+    a.n_rg = g;
+    const int per_wg = (a.n_rb + g - 1) / g;
+    if (per_wg > 4) return KL_ERR_SHAPE;
+    dim3 grid((W / 16) * g), block(256);
+    if (per_wg == 1) hipLaunchKernelGGL((lstm_scan_fwd_split_sent_kernel<32, 1, false>), grid, block, 0, stream, a);
+    else if (per_wg == 2) hipLaunchKernelGGL((lstm_scan_fwd_split_sent_kernel<32, 2, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((lstm_scan_fwd_split_sent_kernel<32, 4, false>), grid, block, 0, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+  }
   if (W != 512 && W != 256 && W != 128 && W != 64) return KL_ERR_SHAPE;
   if (a.L < 1 || a.L > KL_SCAN_MAXL || a.B < 1 || a.T < 1) return KL_ERR_SHAPE;
   const int col_tasks = a.L * (W / 16);

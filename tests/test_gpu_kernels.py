@@ -416,6 +416,14 @@ def test_train_window_width_1024_scans(monkeypatch, depth, width, voc, B, T, n_c
     check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks, want_kernel="lstm_scan_bwd_w32_kernel")
 
 
+@pytest.mark.parametrize("B,T", [(144, 4), (512, 3)])
+def test_width_1024_scans_consecutive_windows(monkeypatch, B, T):
+    """the width-1024 scans over consecutive windows (sentinels re-armed per window, carried state, replayed graph),
+    forced on from one row block: uneven visits with prefetched tiles / four row blocks per workgroup"""
+    monkeypatch.setenv("KL_W32_MIN_RB", "1")
+    test_train_consecutive_windows_reuse_buffers(2, 1024, 40, B, T)
+
+
 def test_flag_handoff_survives_changing_shapes():
     """The backward scan's flag hand-off keeps ONE set of flag words and an epoch per engine: windows of changing size and
     length on the same engine (hipGraph replays in between) must give what a fresh engine gives for the same inputs --

@@ -17,7 +17,8 @@ p = 1.0 / (np.arange(1, bench.VOC) + 1.0)
 p /= p.sum()
 corpus = rng.choice(bench.VOC - 1, size=bench.CORPUS, p=p).astype(np.int32) + 1
 if "small" in what:
-    for Bs, st in ((1, 200), (16, 100), (64, 100)):
+    sizes = [int(x) for x in os.environ.get("KL_SMALL_B", "1,16,64").split(",")]
+    for Bs, st in [(b, 200 if b == 1 else 100) for b in sizes]:
         leg, lm = bench.training_leg(device, bench.DEPTH, bench.WIDTH, bench.LENGTH, bench.N_CTX, Bs, st, 10,
                                      corpus[:Bs * (bench.CORPUS // 64)])
         del lm
