@@ -591,7 +591,15 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
   if (!scanned && !training && split == KL_PREC_SPLIT && h->scan_enabled && h->split_sentinel && W == 1024 &&
       (B + 15) / 16 <= 16 && (long)(T + 1) * B * W * 2 <= 0x7fffffffL) {
     for (int l = 0; l < L; ++l) {
-      if (l > 0) {
+      if (l > 0 && B * T >= 2048) {
+        // many rows: the three products of the split (hi.hi + bias, lo.hi, hi.lo) on the big-tile GEMM, over the (hi, lo)
+        // planes the scan below left behind (the thin GEMM re-reads the weights per 32 rows: 2.9 ms per layer at 16 x 512 rows)
+        const bf16_t* xh = w.Xhi[l - 1] + BW;
+        const bf16_t* xl = w.Xlo[l - 1] + BW;
+        KL_TRY(kl_launch_gemm_tn(xh, d.KT_hi[l], w.P1, P + h->off_b[l], B * T, 4 * W, W, W, W, 4 * W, 0, 1, 1.f, s));
+        KL_TRY(kl_launch_gemm_tn(xl, d.KT_hi[l], w.P1, nullptr, B * T, 4 * W, W, W, W, 4 * W, 2, 1, 1.f, s));
+        KL_TRY(kl_launch_gemm_tn(xh, d.KT_lo[l], w.P1, nullptr, B * T, 4 * W, W, W, W, 4 * W, 2, 1, 1.f, s));
+      } else if (l > 0) {
         KlOperand op;
         memset(&op, 0, sizeof(op));
         op.A = (float*)w.H[l - 1] + BW; op.lda = W; op.a_is_f32 = 1;
