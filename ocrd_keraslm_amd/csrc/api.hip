@@ -126,7 +126,6 @@ struct kl_handle {
   bool xcd_local_bwd = false;    // KL_XCD_LOCAL_BWD=1     // the same for the wide backward scan (KL_SENTINEL_BWD=0, or KL_SENTINEL=0: counters)
   bool w32 = true;              // width 1024: the eight-wave scans of lstm_scan_w32.hip (KL_W32=0: the thin scans)
   bool w32_local = false;       // KL_W32_LOCAL=1: ... handing over through the XCD's own L2 where the placement allows (measured slower: 112 vs 104 ms per cfg5 step)
-  int w32_var = 0;              // (experiments, KL_W32_VAR)
   int w32_min_rb = 8;           // ... from this many row blocks of 16 streams (KL_W32_MIN_RB)
   bool split_sentinel = true;   // rating windows: the split-precision scan hands over by data sentinels (KL_SPLIT_SENTINEL=0: counters)
   bool inc_small = true;        // incremental step: step_small.hip's kernels (KL_INC_SMALL=0: the launch-per-layer thin kernels + thin GEMM + softmax)
@@ -874,8 +873,6 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->w32 = !(env6f && env6f[0] == '0');
   const char* env6g = getenv("KL_W32_LOCAL");
   h->w32_local = env6g && env6g[0] == '1';
-  const char* env6i = getenv("KL_W32_VAR");
-  h->w32_var = env6i ? atoi(env6i) : 0;
   const char* env6h = getenv("KL_W32_MIN_RB");
   h->w32_min_rb = env6h ? atoi(env6h) : 8;
   const char* env6c = getenv("KL_SPLIT_SENTINEL");
@@ -1214,7 +1211,6 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
         a.dZT = nullptr;
         a.xcc_slots = h->w32_local ? w.scan_status + 4 : nullptr;
         a.gen = (unsigned)(1 + L + l);
-        a.pf_mode = h->w32_var;
         e = kl_launch_scan_bwd_w32(a, s);
         w32 = e == 0;
       }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3: kernel times of the cfg5 training step (rocprofv3 kernel stats); env of the caller selects the variant
-# usage: bash tools/gpu_r3j.sh <tag> [small|cfg5]
+# usage: bash tools/gpu_shape_kstats.sh <tag> [small|cfg5]
 set -o pipefail
 export TMPDIR=/tmp
 OUT=gpurun_out
