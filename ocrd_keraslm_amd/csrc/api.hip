@@ -127,6 +127,7 @@ struct kl_handle {
   bool w32 = true;              // width 1024: the eight-wave scans of lstm_scan_w32.hip (KL_W32=0: the thin scans)
   bool w32_local = false;       // KL_W32_LOCAL=1: ... handing over through the XCD's own L2 where the placement allows (measured slower: 112 vs 104 ms per cfg5 step)
   int w32_min_rb = 8;           // ... from this many row blocks of 16 streams (KL_W32_MIN_RB)
+  bool split8 = true;           // width-1024 rating windows with up to 32 streams: two layers per launch, eight units per workgroup (KL_SPLIT8=0: layer by layer)
   bool split_sentinel = true;   // rating windows: the split-precision scan hands over by data sentinels (KL_SPLIT_SENTINEL=0: counters)
   bool inc_small = true;        // incremental step: step_small.hip's kernels (KL_INC_SMALL=0: the launch-per-layer thin kernels + thin GEMM + softmax)
   bool fused_step = true;       // incremental step, n >= 256: cell fused into the GEMM epilogue (KL_FUSED_STEP=0: separate kernels)
@@ -587,6 +588,40 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
   // workgroup's whole register budget, so the layers run one after the other -- per layer ONE split-precision product
   // over all steps for the input side (layer 0: the table gather above), then the persistent scan with U alone
   // (was: a launch per step and layer wavefront, 18 ms per 1 x 512 window)
+  // ... and with few streams (two row blocks at most): eight units per workgroup, so that U and K fit and TWO layers
+  // run as a wavefront per launch (256 workgroups, one per CU): half the chain
+  if (!scanned && !training && split == KL_PREC_SPLIT && h->scan_enabled && h->split_sentinel && h->split8 && W == 1024 &&
+      (B + 15) / 16 <= 2 && (long)(T + 1) * B * W * 2 <= 0x7fffffffL) {
+    bool all = true;
+    for (int l0 = 0; l0 < L && all; l0 += 2) {
+      const int nl = L - l0 < 2 ? L - l0 : 2;
+      KlScanFwdSplit a;
+      memset(&a, 0, sizeof(a));
+      a.B = B; a.T = T; a.W = W; a.L = nl; a.l0 = l0; a.units8 = 1;
+      if (l0 + nl > KL_SCAN_MAXL) { all = false; break; }
+      for (int l = (l0 > 0 ? l0 - 1 : 0); l < l0 + nl; ++l) {
+        a.UT_hi[l] = d.UT_hi[l]; a.UT_lo[l] = d.UT_lo[l];
+        a.KT_hi[l] = l > 0 ? d.KT_hi[l] : nullptr; a.KT_lo[l] = l > 0 ? d.KT_lo[l] : nullptr;
+        a.bias[l] = l > 0 ? P + h->off_b[l] : nullptr;
+        a.Xhi[l] = w.Xhi[l]; a.Xlo[l] = w.Xlo[l];
+        a.Hf[l] = (float*)w.H[l];
+        a.C[l] = w.C[l];
+      }
+      a.P1 = w.P1;
+      a.counters = w.scan_cnt;
+      a.status = w.scan_status;
+      a.sentinel = 1;
+      for (int l = l0; l < l0 + nl; ++l) {
+        KL_TRY(kl_launch_f32_to_bf16_t((const float*)w.H[l], W, B, W, w.Xhi[l], w.Xlo[l], W, 0, s));
+        KL_TRY(kl_fill_u32_async(w.Xhi[l] + BW, (size_t)T * BW * sizeof(bf16_t), 0xFFFFFFFFu, s));
+        KL_TRY(kl_fill_u32_async(w.Xlo[l] + BW, (size_t)T * BW * sizeof(bf16_t), 0xFFFFFFFFu, s));
+      }
+      const int e = kl_launch_scan_fwd_split(a, s);
+      if (e == KL_ERR_SHAPE && l0 == 0) all = false;      // (fewer than 256 CUs: layer by layer below)
+      else if (e != 0) return e;
+    }
+    if (all) scanned = true;
+  }
   if (!scanned && !training && split == KL_PREC_SPLIT && h->scan_enabled && h->split_sentinel && W == 1024 &&
       (B + 15) / 16 <= 16 && (long)(T + 1) * B * W * 2 <= 0x7fffffffL) {
     for (int l = 0; l < L; ++l) {
@@ -875,6 +910,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->w32_local = env6g && env6g[0] == '1';
   const char* env6h = getenv("KL_W32_MIN_RB");
   h->w32_min_rb = env6h ? atoi(env6h) : 8;
+  const char* env6j = getenv("KL_SPLIT8");
+  h->split8 = !(env6j && env6j[0] == '0');
   const char* env6c = getenv("KL_SPLIT_SENTINEL");
   h->split_sentinel = !(env6c && env6c[0] == '0');
   const char* env6b = getenv("KL_INC_SMALL");

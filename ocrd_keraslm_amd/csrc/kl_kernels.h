@@ -132,6 +132,7 @@ struct KlScanFwdSplit {
   unsigned* counters;                  // [L][n_rb][T]
   unsigned* status;
   int sentinel;                        // 1: hand-off by data -- blocks 1..T of Xhi / Xlo pre-filled with 0xFFFF by the caller, no counters
+  int units8, l0;                      // width 1024: eight units per workgroup, layers l0 .. l0 + L - 1 (L <= 2) as a wavefront (the arrays are indexed by absolute layer)
 };
 int kl_launch_scan_fwd_split(KlScanFwdSplit args, hipStream_t stream);
 

@@ -619,6 +619,193 @@ __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_sent_kernel(const 
   }
 }
 
+// EIGHT units per workgroup (width 1024, few streams): with 16 units the (hi, lo) planes of U AND K are 512 registers per
+// lane, which is why the kernel above runs width 1024 layer by layer (IN = false) and the rating window of the cfg5
+// topology is a chain of depth x T steps.  Here a workgroup's 32 columns are 4 gates x 8 units -- MFMA column tile c
+// holds gates 2c, 2c + 1 -- so U and K fit (256 registers), W/8 = 128 workgroups make a layer and TWO layers run as a
+// wavefront per launch on the 256 CUs (a.l0 = the launch's first layer; its input planes, if any, are complete).
+template <int KSTEPS, int MAXRB>
+__global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_sent8_kernel(const KlScanFwdSplit a) {
+  constexpr int KW = KSTEPS < 4 ? KSTEPS : 4;
+  constexpr int KQ = KSTEPS / KW;
+  static_assert(KSTEPS % KW == 0, "K split");
+  constexpr int W = KSTEPS * 32;
+  constexpr int NUG = W / 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int id = blockIdx.x;
+  const int n_rg = a.n_rg, n_rb = a.n_rb, B = a.B, T = a.T;
+  const int lrel = id / (NUG * n_rg);
+  id -= lrel * NUG * n_rg;
+  const int l = a.l0 + lrel;
+  const int ug = id / n_rg, rg = id % n_rg;
+  const int u0 = ug * 8;
+  const bool has_in = l > 0;
+  const bool kactive = wave < KW;
+  const int kw = kactive ? wave : 0;
+
+  __shared__ float zt[2][4][2][16][17];      // [buffer][wave][column tile][row][gate-of-pair * 8 + unit]
+
+  const int kq = (lane >> 4) * 8;
+  uint4 bu[2][2][KQ], bk[2][2][KQ];     // [hi/lo][column tile][k-step]
+  {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const long wrow = ((long)(2 * g + ((lane & 15) >> 3)) * W + u0 + (lane & 7)) * W + (kw * KQ) * 32 + kq;
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) {
+        bu[0][g][j] = *reinterpret_cast<const uint4*>(a.UT_hi[l] + wrow + j * 32);
+        bu[1][g][j] = *reinterpret_cast<const uint4*>(a.UT_lo[l] + wrow + j * 32);
+        bk[0][g][j] = has_in ? *reinterpret_cast<const uint4*>(a.KT_hi[l] + wrow + j * 32) : uint4{0, 0, 0, 0};
+        bk[1][g][j] = has_in ? *reinterpret_cast<const uint4*>(a.KT_lo[l] + wrow + j * 32) : uint4{0, 0, 0, 0};
+      }
+    }
+  }
+  const int er = (tid >> 3) & 15, eu = tid & 7;      // epilogue threads: tid < 128 = (row, unit)
+  const bool ethread = tid < 128;
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (has_in) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = a.bias[l][(long)g * W + u0 + eu];
+  }
+  float* Cl = a.C[l];
+  float* Hf = a.Hf[l];
+  bf16_t* Xhi = a.Xhi[l];
+  bf16_t* Xlo = a.Xlo[l];
+  const float* P1 = a.P1;
+  unsigned* status = a.status;
+  float c_reg[MAXRB];
+#pragma unroll
+  for (int i = 0; i < MAXRB; ++i) {
+    const int rb = rg + i * n_rg;
+    const int row = min(rb * 16 + er, B - 1);
+    c_reg[i] = (rb < n_rb) ? Cl[(long)row * W + u0 + eu] : 0.f;
+  }
+  const long BW = (long)B * W;
+  const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc(Xhi, (long)(T + 1) * BW * 2);
+  const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(Xlo, (long)(T + 1) * BW * 2);
+  // input rows of step t = outputs of the layer below at block t + 1 (always a polled block)
+  const __amdgpu_buffer_rsrc_t rs_ihi = make_rsrc(has_in ? a.Xhi[l - 1] + BW : Xhi, (long)T * BW * 2);
+  const __amdgpu_buffer_rsrc_t rs_ilo = make_rsrc(has_in ? a.Xlo[l - 1] + BW : Xlo, (long)T * BW * 2);
+  bool alive = true;                 // (wave-uniform: false once this wave or any other has given up)
+  int par = 0;
+
+  // the fragments of one operand, loaded until none of them is a sentinel (`poll` false: loaded once)
+  auto fetch = [&](const __amdgpu_buffer_rsrc_t& rh, const __amdgpu_buffer_rsrc_t& rl, unsigned abase, bool poll,
+                   uint4 (&fh)[KQ], uint4 (&fl)[KQ]) {
+    for (unsigned spin = 0;; ++spin) {
+      unsigned any = 0;
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) {
+        fh[j] = load16_sc1(rh, abase + j * 64);
+        fl[j] = load16_sc1(rl, abase + j * 64);
+      }
+#pragma unroll
+      for (int j = 0; j < KQ; ++j)
+        any |= fh[j].x | fh[j].y | fh[j].z | fh[j].w | fl[j].x | fl[j].y | fl[j].z | fl[j].w;
+      if (!poll || !alive || __all((any & 0x40004000u) == 0)) break;
+      if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) alive = false;
+      if (spin >= SPIN_LIMIT) {
+        __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        alive = false;
+      }
+    }
+  };
+
+  for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int i = 0; i < MAXRB; ++i) {
+      const int rb = rg + i * n_rg;
+      if (rb >= n_rb) continue;
+      const int r0 = rb * 16;
+      const int erow = min(r0 + er, B - 1);
+      float zin[4];
+      if (!has_in) {
+        const float* p = P1 + ((long)t * B + erow) * 4 * W + u0 + eu;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) zin[g] = p[(long)g * W];
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) zin[g] = bias4[g];
+      }
+      const int arow = min(r0 + (lane & 15), B - 1);
+      const unsigned abase = (unsigned)((((long)t * B + arow) * W + (kw * KQ) * 32 + kq) * 2);
+      f32x4 acc[2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      uint4 ahi[KQ], alo[KQ];
+      if (has_in) {      // (the layer below runs ahead: normally there at the first look)
+        fetch(rs_ihi, rs_ilo, abase, true, ahi, alo);
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+          frag16 fh, fl;
+          fh.u = ahi[j];
+          fl.u = alo[j];
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            frag16 wh, wl;
+            wh.u = bk[0][g][j];
+            wl.u = bk[1][g][j];
+            acc[g] = mfma16(fl.v, wh.v, acc[g]);
+            acc[g] = mfma16(fh.v, wl.v, acc[g]);
+            acc[g] = mfma16(fh.v, wh.v, acc[g]);
+          }
+        }
+      }
+      fetch(rs_hi, rs_lo, abase, t > 0, ahi, alo);
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) {
+        frag16 fh, fl;
+        fh.u = ahi[j];
+        fl.u = alo[j];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          frag16 wh, wl;
+          wh.u = bu[0][g][j];
+          wl.u = bu[1][g][j];
+          acc[g] = mfma16(fl.v, wh.v, acc[g]);
+          acc[g] = mfma16(fh.v, wl.v, acc[g]);
+          acc[g] = mfma16(fh.v, wh.v, acc[g]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zt[par][wave][g][(lane >> 4) * 4 + r][lane & 15] = kactive ? acc[g][r] : 0.f;
+      __syncthreads();
+      float z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ct = g >> 1, cc = (g & 1) * 8 + eu;      // gate g sits in column tile g / 2, columns (g % 2) * 8 + unit
+        z[g] = zin[g] + zt[par][0][ct][er][cc] + zt[par][1][ct][er][cc] + zt[par][2][ct][er][cc] + zt[par][3][ct][er][cc];
+      }
+      par ^= 1;
+      const float gi = sigmoidf_(z[0]), gf = sigmoidf_(z[1]), gg = tanhf_(z[2]), go = sigmoidf_(z[3]);
+      const float c = gf * c_reg[i] + gi * gg;
+      c_reg[i] = c;
+      float h = go * tanhf_(c);
+      // (a non-finite or out-of-range h -- broken weights -- must not look like a sentinel to the consumers: they would
+      //  spin until the time-out; the f32 output keeps the value as computed)
+      const float hx = (h > -1.f && h < 1.f) ? h : (h >= 1.f ? 1.f : (h <= -1.f ? -1.f : 0.f));
+      const bool row_ok = (r0 + er) < B;
+      const unsigned hh = f2bf(hx);
+      const unsigned hl = f2bf(hx - bf2f((bf16_t)hh));
+      const unsigned hh_n = __shfl_xor(hh, 1), hl_n = __shfl_xor(hl, 1);
+      const long orow = (long)t * B + r0 + er;
+      if (ethread && row_ok && (eu & 1) == 0) {
+        __hip_atomic_store(reinterpret_cast<unsigned*>(Xhi + (orow + B) * W + u0 + eu), hh | (hh_n << 16), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned*>(Xlo + (orow + B) * W + u0 + eu), hl | (hl_n << 16), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (ethread && row_ok) {
+        Hf[(orow + B) * W + u0 + eu] = h;
+        if (t == T - 1) Cl[(orow + B) * W + u0 + eu] = c;
+      }
+    }
+  }
+}
+
+
 // ---------------------------------------------------------------- backward scan
 // block = 256 threads; output tile = dh of 16 rows x 16 units; wave w contracts
 // over gate w's K range (W of the 4W columns) of dZ_l[t+1] . U_l^T and, below the
@@ -1683,6 +1870,23 @@ int kl_launch_scan_fwd_wide(KlScanFwdWide a, hipStream_t stream) {
 // Split-precision inference scan (all layers fused).  KL_ERR_SHAPE = not applicable.
 int kl_launch_scan_fwd_split(KlScanFwdSplit a, hipStream_t stream) {
   const int W = a.W;
+  if (W == 1024 && a.units8) {
+    // a.L (one or two) layers from a.l0 as a wavefront, eight units per workgroup, one workgroup per CU
+    if (a.L < 1 || a.L > 2 || !a.sentinel || a.B < 1 || a.T < 1) return KL_ERR_SHAPE;
+    if ((long)(a.T + 1) * a.B * W * 2 > 0x7fffffffL) return KL_ERR_SHAPE;
+    a.n_rb = (a.B + 15) / 16;
+    const int col_tasks = a.L * (W / 8);
+    int g = scan_cus() / col_tasks;
+    if (g < 1) return KL_ERR_SHAPE;
+    if (g > a.n_rb) g = a.n_rb;
+    a.n_rg = g;
+    const int per_wg = (a.n_rb + g - 1) / g;
+    if (per_wg > 2) return KL_ERR_SHAPE;
+    dim3 grid(col_tasks * g), block(256);
+    if (per_wg == 1) hipLaunchKernelGGL((lstm_scan_fwd_split_sent8_kernel<32, 1>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((lstm_scan_fwd_split_sent8_kernel<32, 2>), grid, block, 0, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+  }
   if (W == 1024) {
     // one layer per launch, the input side precomputed in P1, data sentinels only (the caller's layer-sequential path)
     if (a.L != 1 || !a.sentinel || a.B < 1 || a.T < 1) return KL_ERR_SHAPE;

@@ -263,8 +263,11 @@ def test_step_batch_bf16_within_1e3():
                                                        # persistent split-precision scan: row blocks > workgroups, 3 layers,
                                                        # the cfg2 rating window
                                                        (3, 256, 30, 40, 9, 2), (2, 512, 64, 200, 5, 1), (2, 512, 256, 1, 256, 1),
-                                                       # cfg5 topology
-                                                       (4, 1024, 64, 2, 6, 2),
+                                                       # cfg5 topology (two layers per launch, eight units per workgroup); three
+                                                       # layers (a pair and a single one), two row blocks, one layer
+                                                       (4, 1024, 64, 2, 6, 2), (3, 1024, 40, 20, 5, 1), (1, 1024, 30, 1, 9, 0),
+                                                       # ... more than two row blocks: layer by layer
+                                                       (2, 1024, 40, 40, 4, 1),
                                                        # zero-padded widths
                                                        (2, 100, 50, 3, 12, 1), (1, 33, 20, 20, 5, 0),
                                                        # deeper than four layers (launch-per-step kernels, packs of four layers)
@@ -294,6 +297,12 @@ def test_forward_window_parity(depth, width, voc, B, T, n_ctx):
     states = lm.get_states()
     for k in range(2 * depth):
         assert np.abs(states[:, k] - st[k]).max() < 1e-4
+
+
+def test_forward_window_width_1024_layer_by_layer(monkeypatch):
+    """width 1024, few streams, with the two-layer launches switched off (KL_SPLIT8=0): one persistent scan per layer"""
+    monkeypatch.setenv("KL_SPLIT8", "0")
+    test_forward_window_parity(4, 1024, 64, 2, 6, 2)
 
 
 @pytest.mark.parametrize("depth,width,voc,B,T,n_ctx", [(3, 256, 30, 40, 9, 2), (2, 512, 256, 1, 64, 1)])
