@@ -10,5 +10,6 @@ grep -v amdgpu.ids $OUT/r3h_tests.log | tail -8
 if [ $rc -ne 0 ]; then echo "tests rc=$rc: stopping"; exit $rc; fi
 for B in 1 16 64; do
   KL_SPLIT_SENTINEL=0 timeout -k 10 120 python tools/probe_rate_window.py $B 2>&1 | grep "rating window" | sed 's/^/counters: /' || exit 1
-  timeout -k 10 120 python tools/probe_rate_window.py $B 2>&1 | grep "rating window" | sed 's/^/sentinel: /' || exit 1
+  KL_SPLIT8=0 timeout -k 10 120 python tools/probe_rate_window.py $B 2>&1 | grep "rating window" | sed 's/^/sentinels, 16 units per workgroup: /' || exit 1
+  timeout -k 10 120 python tools/probe_rate_window.py $B 2>&1 | grep "rating window" | sed 's/^/sentinels, 8 units where they apply: /' || exit 1
 done | tee $OUT/r3h_rate.log
