@@ -415,6 +415,9 @@ def test_train_window_scan2(monkeypatch, depth, width, voc, B, T, n_ctx, use_mas
     (2, 1024, 40, 144, 5, 1, True, {}),                         # nine row blocks on eight row groups: two visits, uneven; prefetched tiles
     (2, 1024, 40, 512, 3, 1, True, {}),                         # four row blocks per workgroup (the cfg5 bench shape's plan)
     (1, 1024, 40, 1024, 2, 0, False, {}),                       # eight per workgroup; one layer, no context, no dropout
+    (2, 1024, 40, 17, 1, 1, False, {}),                         # a single step (no tile at all), ragged second row block
+    (2, 1024, 40, 272, 2, 1, True, {}),                         # 17 row blocks on 8 row groups: three visits for one group, two for the others
+    (2, 1024, 40, 328, 3, 1, True, {}),                         # ... ragged (328 = 20.5 blocks): no tiles requested ahead
     (2, 1024, 40, 256, 4, 1, True, {"KL_W32_LOCAL": "1"})])     # publishes through the XCD's own L2
 def test_train_window_width_1024_scans(monkeypatch, depth, width, voc, B, T, n_ctx, use_masks, env):
     """Width 1024: the eight-wave scans of lstm_scan_w32.hip (32 units per workgroup, the tile through LDS, data sentinels),
