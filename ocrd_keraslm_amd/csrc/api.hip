@@ -131,6 +131,8 @@ struct kl_handle {
   bool split_sentinel = true;   // rating windows: the split-precision scan hands over by data sentinels (KL_SPLIT_SENTINEL=0: counters)
   bool inc_small = true;        // incremental step: step_small.hip's kernels (KL_INC_SMALL=0: the launch-per-layer thin kernels + thin GEMM + softmax)
   bool fused_step = true;       // incremental step, n >= 256: cell fused into the GEMM epilogue (KL_FUSED_STEP=0: separate kernels)
+  bool inc_tile = true;         // incremental step, n >= 256: step_tile.hip's one launch per layer (KL_INC_TILE=0: gather + [hi|lo|hi] GEMM)
+  int tile_var = 0;             // KL_TILE_VAR: timing variants of inc_tile_kernel (never in production)
   bool scan2 = true;            // second-generation wide scans where their grid plan applies (KL_SCAN2=0: first generation)
   int scan2_rows = 0;           // KL_SCAN2_ROWS = 16 / 32: rows per forward phase (0: chosen by shape)
   int scan2_pf = -1;            // KL_SCAN2_PF: where the forward scan requests its next tile (0: top of a phase, 1: behind the MFMA phase, 2: two phases ahead; -1: by shape)
@@ -918,6 +920,10 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->inc_small = !(env6b && env6b[0] == '0');
   const char* env6 = getenv("KL_FUSED_STEP");
   h->fused_step = !(env6 && env6[0] == '0');
+  const char* env6k = getenv("KL_INC_TILE");
+  h->inc_tile = !(env6k && env6k[0] == '0');
+  const char* env6l = getenv("KL_TILE_VAR");
+  h->tile_var = env6l ? atoi(env6l) : 0;
   const char* env8 = getenv("KL_SCAN2");
   if (env8) h->scan2 = atoi(env8) != 0;
   const char* env8b = getenv("KL_SCAN2_ROWS");
@@ -1407,6 +1413,42 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
     // rows are hypotheses: treat as B = n streams, T = 1
     KL_TRY(kl_launch_p1_gather(d.EK, ctxk.data(), c.n_ctx, P + h->off_b[0], idx, ctx, n, 1, 4 * W, prow, s));
   }
+  // the output layer of every path below: logits over the tied embedding from the top layer's new h, softmax in place
+  auto output_layer = [&]() -> int {
+    KlOperand op;
+    memset(&op, 0, sizeof(op));
+    op.A = pool + (size_t)2 * (L - 1) * W; op.lda = slot_ld; op.row_index = slot_out; op.a_is_f32 = 1;
+    op.WT_hi = d.E_hi; op.WT_lo = split == 3 ? d.E_lo : nullptr; op.ldw = W; op.K = W;
+    KL_TRY(kl_launch_thin_gemm(&op, n, V, probs, V, nullptr, split, s));
+    return kl_launch_softmax_ce(probs, V, n, V, nullptr, n, 1, 1.f, nullptr, 0, nullptr, nullptr, 0, s);
+  };
+  auto cell_args = [&](int l) {
+    KlIncCellArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = n; a.W = W; a.split = split;
+    a.pool = pool; a.slot_ld = slot_ld; a.slot_in = slot_in; a.slot_out = slot_out;
+    a.h_off = 2 * l * W; a.c_off = (2 * l + 1) * W; a.x_off = l > 0 ? 2 * (l - 1) * W : -1;
+    a.UT_hi = d.UT_hi[l]; a.UT_lo = split == 3 ? d.UT_lo[l] : nullptr;
+    a.KT_hi = l > 0 ? d.KT_hi[l] : nullptr; a.KT_lo = (l > 0 && split == 3) ? d.KT_lo[l] : nullptr;
+    if (l == 0) {
+      if (prow) { a.T1 = prow; }
+      else { a.T1 = d.EK; a.i1 = idx; a.T2 = d.CtxK[0]; a.i2 = ctx; a.bias = P + h->off_b[0]; }
+    } else {
+      a.bias = P + h->off_b[l];
+    }
+    return a;
+  };
+  // 256 hypotheses or more, widths of 256, 384, 512, ...: one launch per layer, tiles of 64 hypotheses x 32 units with the
+  // state rows read through the pool slots and the weights from the hi / lo arrays as they are (step_tile.hip)
+  if (n >= KL_BIG_STEP_N && h->inc_tile && V < 1024) {
+    int e = 0;
+    for (int l = 0; l < L && e == 0; ++l) {
+      e = kl_launch_inc_tile(cell_args(l), h->tile_var, s);
+      if (e == KL_ERR_SHAPE && l > 0) return e;      // (layer 0 decides for all: the shapes are the same)
+    }
+    if (e == 0) return output_layer();
+    if (e != KL_ERR_SHAPE) return e;
+  }
   if (n >= KL_BIG_STEP_N && ws && ws_bytes >= kl_step_workspace_bytes(h, n)) {
     if (!h->inc_ready) KL_TRY(prepare_incremental(h, s));
     // big-tile path: gather+split -> one bf16 GEMM over the 3x contraction -> gates
@@ -1479,31 +1521,10 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
   if (h->inc_small && n >= KL_SMALL_STEP_N) {
     int e = 0;
     for (int l = 0; l < L && e == 0; ++l) {
-      KlIncCellArgs a;
-      memset(&a, 0, sizeof(a));
-      a.n = n; a.W = W; a.split = split;
-      a.pool = pool; a.slot_ld = slot_ld; a.slot_in = slot_in; a.slot_out = slot_out;
-      a.h_off = 2 * l * W; a.c_off = (2 * l + 1) * W; a.x_off = l > 0 ? 2 * (l - 1) * W : -1;
-      a.UT_hi = d.UT_hi[l]; a.UT_lo = split == 3 ? d.UT_lo[l] : nullptr;
-      a.KT_hi = l > 0 ? d.KT_hi[l] : nullptr; a.KT_lo = (l > 0 && split == 3) ? d.KT_lo[l] : nullptr;
-      if (l == 0) {
-        if (prow) { a.T1 = prow; }
-        else { a.T1 = d.EK; a.i1 = idx; a.T2 = d.CtxK[0]; a.i2 = ctx; a.bias = P + h->off_b[0]; }
-      } else {
-        a.bias = P + h->off_b[l];
-      }
-      e = kl_launch_inc_cell(a, s);
+      e = kl_launch_inc_cell(cell_args(l), s);
       if (e == KL_ERR_SHAPE && l > 0) return e;      // (layer 0 decides for all: the shapes are the same)
     }
-    if (e == 0) {
-      KlOperand op;
-      memset(&op, 0, sizeof(op));
-      op.A = pool + (size_t)2 * (L - 1) * W; op.lda = slot_ld; op.row_index = slot_out; op.a_is_f32 = 1;
-      op.WT_hi = d.E_hi; op.WT_lo = split == 3 ? d.E_lo : nullptr; op.ldw = W; op.K = W;
-      KL_TRY(kl_launch_thin_gemm(&op, n, V, probs, V, nullptr, split, s));
-      KL_TRY(kl_launch_softmax_ce(probs, V, n, V, nullptr, n, 1, 1.f, nullptr, 0, nullptr, nullptr, 0, s));
-      return 0;
-    }
+    if (e == 0) return output_layer();
     if (e != KL_ERR_SHAPE) return e;
   }
   for (int l = 0; l < L; ++l) {

@@ -272,6 +272,9 @@ struct KlIncCellArgs {
 };
 int kl_launch_inc_cell(const KlIncCellArgs& a, hipStream_t stream);      // KL_ERR_SHAPE: not applicable
 
+// ---- step_tile.hip: the same for n >= KL_BIG_STEP_N, TR x 128 tiles with the operands read once (variant: timing builds, 0)
+int kl_launch_inc_tile(const KlIncCellArgs& a, int variant, hipStream_t stream);      // KL_ERR_SHAPE: not applicable
+
 // ---- step_big.hip -------------------------------------------------------
 #define KL_BIG_STEP_N 256   // from this many hypotheses on, kl_step_batch uses big-tile GEMMs
 int kl_launch_split_gather(const float* s0, long ld0, const int* i0, int w0, const float* s1, long ld1, const int* i1,
