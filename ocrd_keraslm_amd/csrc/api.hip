@@ -49,6 +49,8 @@ struct Derived {
   std::vector<bf16_t*> UT_hi, UT_lo, KT_hi, KT_lo, Un, Kn;   // per layer (KT/Kn of layer 0 = rows [0,W) of K0)
   bf16_t *E_hi = nullptr, *E_lo = nullptr, *ET = nullptr;
   std::vector<bf16_t*> WTcat;    // [4W][3*K_l] = [hi | hi | lo] blocks, K_0 = W (U), K_l = 2W (K then U): big-n step path
+  std::vector<bf16_t*> UF, KF;   // per layer: U^T / K^T fragment-major (hi and lo planes per 16 x 32 block), step_tile.hip (W % 128 == 0)
+  bf16_t* EF = nullptr;          // the embedding likewise
   std::vector<bf16_t*> WTperm;   // WTcat with rows in (unit block of 32, gate, unit) order: fused cell epilogue (W % 32 == 0)
   bf16_t* Ecat = nullptr;        // [Vp][3W]
   float* EK = nullptr;
@@ -133,6 +135,8 @@ struct kl_handle {
   bool fused_step = true;       // incremental step, n >= 256: cell fused into the GEMM epilogue (KL_FUSED_STEP=0: separate kernels)
   bool inc_tile = true;         // incremental step, n >= 256: step_tile.hip's one launch per layer (KL_INC_TILE=0: gather + [hi|lo|hi] GEMM)
   int tile_var = 0;             // KL_TILE_VAR: timing variants of inc_tile_kernel (never in production)
+  bool out_fused = true;        // incremental step: logits + softmax in one launch (KL_OUT_FUSED=0: thin GEMM + softmax kernel)
+  int out_fused_min = 96;       // ... from this many hypotheses on (KL_OUT_FUSED_MIN)
   bool scan2 = true;            // second-generation wide scans where their grid plan applies (KL_SCAN2=0: first generation)
   int scan2_rows = 0;           // KL_SCAN2_ROWS = 16 / 32: rows per forward phase (0: chosen by shape)
   int scan2_pf = -1;            // KL_SCAN2_PF: where the forward scan requests its next tile (0: top of a phase, 1: behind the MFMA phase, 2: two phases ahead; -1: by shape)
@@ -243,6 +247,15 @@ size_t carve_derived(const kl_handle* h, void* base, Derived* d) {
   if ((W & 31) == 0)
     for (int l = 0; l < c.depth; ++l) o.WTperm[l] = cv.take<bf16_t>(4 * W * 3 * (l == 0 ? W : 2 * W));
   o.Ecat = cv.take<bf16_t>(Vp * 3 * W);
+  o.UF.assign(c.depth, nullptr);
+  o.KF.assign(c.depth, nullptr);
+  if ((W & 127) == 0) {
+    for (int l = 0; l < c.depth; ++l) {
+      o.UF[l] = cv.take<bf16_t>(4 * W * W * 2);
+      if (l > 0) o.KF[l] = cv.take<bf16_t>(4 * W * W * 2);
+    }
+    o.EF = cv.take<bf16_t>(Vp * W * 2);
+  }
   o.CtxK.assign(c.n_ctx, nullptr);
   for (int n = 0; n < c.n_ctx; ++n) o.CtxK[n] = cv.take<float>((size_t)c.ctx_vocab * 4 * W);
   o.KTp.assign(c.depth, nullptr);
@@ -409,6 +422,13 @@ int prepare_incremental(kl_handle* h, hipStream_t s) {
     KL_TRY(kl_launch_f32_to_bf16_t(U, 4 * W, W, 4 * W, base + uoff, split ? base + 2 * Kl + uoff : nullptr, ld, 1, s));
     if (split) KL_TRY(kl_launch_f32_to_bf16_t(U, 4 * W, W, 4 * W, base + Kl + uoff, nullptr, ld, 1, s));
     if (d.WTperm[l]) KL_TRY(kl_launch_permute_gate_rows(base, d.WTperm[l], W, ld, s));
+  }
+  if (d.EF) {      // fragment-major copies of the [4W][W] / [Vp][W] hi / lo arrays kl_prepare keeps
+    for (int l = 0; l < c.depth; ++l) {
+      KL_TRY(kl_launch_frag_major(d.UT_hi[l], split ? d.UT_lo[l] : nullptr, 4 * W, W, W, d.UF[l], s));
+      if (l > 0) KL_TRY(kl_launch_frag_major(d.KT_hi[l], split ? d.KT_lo[l] : nullptr, 4 * W, W, W, d.KF[l], s));
+    }
+    KL_TRY(kl_launch_frag_major(d.E_hi, split ? d.E_lo : nullptr, Vp, W, W, d.EF, s));
   }
   KL_TRY(kl_zero_async(d.Ecat, (size_t)Vp * 3 * W * sizeof(bf16_t), s));
   KL_TRY(kl_launch_f32_to_bf16_t(E, W, V, W, d.Ecat, split ? d.Ecat + 2 * W : nullptr, 3 * W, 0, s));
@@ -924,6 +944,10 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->inc_tile = !(env6k && env6k[0] == '0');
   const char* env6l = getenv("KL_TILE_VAR");
   h->tile_var = env6l ? atoi(env6l) : 0;
+  const char* env6m = getenv("KL_OUT_FUSED");
+  h->out_fused = !(env6m && env6m[0] == '0');
+  const char* env6n = getenv("KL_OUT_FUSED_MIN");
+  if (env6n) h->out_fused_min = atoi(env6n);
   const char* env8 = getenv("KL_SCAN2");
   if (env8) h->scan2 = atoi(env8) != 0;
   const char* env8b = getenv("KL_SCAN2_ROWS");
@@ -1415,6 +1439,11 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
   }
   // the output layer of every path below: logits over the tied embedding from the top layer's new h, softmax in place
   auto output_layer = [&]() -> int {
+    if (h->out_fused && n >= h->out_fused_min && d.EF) {
+      if (!h->inc_ready) KL_TRY(prepare_incremental(h, s));
+      const int e = kl_launch_out_softmax(pool, slot_ld, slot_out, 2 * (L - 1) * W, d.EF, split, n, W, V, probs, V, s);
+      if (e != KL_ERR_SHAPE) return e;
+    }
     KlOperand op;
     memset(&op, 0, sizeof(op));
     op.A = pool + (size_t)2 * (L - 1) * W; op.lda = slot_ld; op.row_index = slot_out; op.a_is_f32 = 1;
@@ -1440,10 +1469,13 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
   };
   // 256 hypotheses or more, widths of 256, 384, 512, ...: one launch per layer, tiles of 64 hypotheses x 32 units with the
   // state rows read through the pool slots and the weights from the hi / lo arrays as they are (step_tile.hip)
-  if (n >= KL_BIG_STEP_N && h->inc_tile && V < 1024) {
+  if (n >= KL_BIG_STEP_N && h->inc_tile && V < 1024 && d.EF) {
+    if (!h->inc_ready) KL_TRY(prepare_incremental(h, s));
     int e = 0;
     for (int l = 0; l < L && e == 0; ++l) {
-      e = kl_launch_inc_tile(cell_args(l), h->tile_var, s);
+      KlIncCellArgs ta = cell_args(l);
+      ta.UT_hi = d.UF[l]; ta.KT_hi = d.KF[l]; ta.UT_lo = ta.KT_lo = nullptr;      // (fragment-major, planes interleaved)
+      e = kl_launch_inc_tile(ta, h->tile_var, s);
       if (e == KL_ERR_SHAPE && l > 0) return e;      // (layer 0 decides for all: the shapes are the same)
     }
     if (e == 0) return output_layer();

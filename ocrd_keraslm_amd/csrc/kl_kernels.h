@@ -273,7 +273,12 @@ struct KlIncCellArgs {
 int kl_launch_inc_cell(const KlIncCellArgs& a, hipStream_t stream);      // KL_ERR_SHAPE: not applicable
 
 // ---- step_tile.hip: the same for n >= KL_BIG_STEP_N, TR x 128 tiles with the operands read once (variant: timing builds, 0)
-int kl_launch_inc_tile(const KlIncCellArgs& a, int variant, hipStream_t stream);      // KL_ERR_SHAPE: not applicable
+int kl_launch_inc_tile(const KlIncCellArgs& a, int variant, hipStream_t stream);      // KL_ERR_SHAPE: not applicable; a.UT_hi / a.KT_hi = FRAGMENT-MAJOR arrays
+// output layer in one launch: probs[n][V] = softmax(h_top . E^T), h_top rows through slot_out (V <= 256, W % 128 == 0)
+int kl_launch_out_softmax(const float* pool, long slot_ld, const int* slot_out, int h_off, const bf16_t* EF, int split,
+                          int n, int W, int V, float* probs, long ldp, hipStream_t stream);      // KL_ERR_SHAPE: not applicable
+// [rows][K] bf16 hi (+ lo) -> fragment-major [rows / 16][K / 32][planes][64][8] (the operands of the two launchers above)
+int kl_launch_frag_major(const bf16_t* hi, const bf16_t* lo, int rows, int K, long ld, bf16_t* out, hipStream_t stream);
 
 // ---- step_big.hip -------------------------------------------------------
 #define KL_BIG_STEP_N 256   // from this many hypotheses on, kl_step_batch uses big-tile GEMMs

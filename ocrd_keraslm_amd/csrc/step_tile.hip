@@ -34,7 +34,7 @@ struct IncTile {
   float* pool; long slot_ld;
   const int* slot_in; const int* slot_out;
   int h_off, c_off, x_off;          // float offsets inside a slot: this layer's h and c, the layer below's h (-1: layer 0)
-  const bf16_t* UT_hi; const bf16_t* UT_lo; const bf16_t* KT_hi; const bf16_t* KT_lo;      // [4W][W]
+  const bf16_t* UF; const bf16_t* KF;                 // fragment-major weights (frag_major_kernel): [4W / 16][W / 32][planes][64][8]
   const float* T1; const int* i1; const float* T2; const int* i2; const float* bias;       // z init (tables [.][4W], bias [4W])
   int nx, ny, px, py;               // tile grid (unit blocks x row tiles) and its partition over the XCDs (px * py == 8, or 0)
 };
@@ -77,18 +77,21 @@ __device__ __forceinline__ float gate_tanh(float x) {
 
 template <int TR, bool LO, int VAR>
 __global__ __launch_bounds__(512, 1) void inc_tile_kernel(const IncTile a) {
-  constexpr int WM = 2, WN = 4;                       // 8 waves: wave = (TR / 2) rows x 32 columns
-  constexpr int RF = TR / 16 / WM, NT = 2;            // 16 x 16 fragments per wave
+  // 8 waves, wave w = all TR rows x columns 16 w .. 16 w + 15 of the tile (gate w / 2, units 16 (w % 2) ..): every weight
+  // element is used by exactly one wave, so the weight fragments go straight from global memory into MFMA operands (lane
+  // (column c, quarter q) holds k = 8 q .. 8 q + 7 of a 32-deep block: 16 bytes of row c of the [4W][W] array) -- no LDS
+  // store, no LDS read, no barrier on their way; four k-steps of them are in flight per wave.  Only the state rows, which
+  // every wave needs and which have to be split first, go through LDS (two stages of hi + lo planes, 32 KiB).
+  constexpr int RF = TR / 16;                         // 16-row fragments
   constexpr int APC = TR * 16 / 512;                  // float4 pieces of A per thread and k-step
-  constexpr int BPC = LO ? 4 : 2;                     // 16-byte pieces of B per thread and k-step
   constexpr int NPL = LO ? 2 : 1;
-  constexpr int A_PLANE = TR * 128, B_PLANE = TC * 128;
-  constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
+  constexpr int A_PLANE = TR * 128;
+  constexpr int STAGE = NPL * A_PLANE;
   static_assert(TR == 64, "the epilogue's thread = (row, four units) map takes 64 rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
   const int W = a.W;
 
   // ---- tile of this workgroup
@@ -110,8 +113,9 @@ __global__ __launch_bounds__(512, 1) void inc_tile_kernel(const IncTile a) {
   const int nkt = (Kx + W) / BK, nkx = Kx / BK;
 
   // ---- every index this thread will need, in one round trip: the slots of its A rows (piece j: row j * 32 + tid / 16, floats
-  // 4 * (tid % 16) .. + 3 of the k-step) and of its epilogue cells (row tid / 8, units u0 + 4 * (tid % 8) .. + 3: 16-byte loads and stores -- a
-  // dword access costs the CU's address unit as much as a 16-byte one, and there are 13 loads per thread this way, not 44)
+  // 4 * (tid % 16) .. + 3 of the k-step) and of its epilogue cells (row tid / 8, units u0 + 4 * (tid % 8) .. + 3: 16-byte
+  // loads and stores -- a dword access costs the CU's address unit as much as a 16-byte one, and there are 13 loads per
+  // thread this way, not 44)
   int a_si[APC], a_so[APC];
 #pragma unroll
   for (int j = 0; j < APC; ++j) {
@@ -122,44 +126,40 @@ __global__ __launch_bounds__(512, 1) void inc_tile_kernel(const IncTile a) {
   const int erow = min(m0 + (tid >> 3), a.n - 1);
   const int e_si = a.slot_in[erow], e_out = a.slot_out[erow];
   const int e_i1 = a.i1 ? a.i1[erow] : erow, e_i2 = a.i2 ? a.i2[erow] : erow;
-  // B piece j: plane j / 2, column (j % 2) * 64 + tid / 8 = gate * 32 + unit, chunk tid % 8
-  unsigned bo[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = j * 64 + (tid >> 3);
-    bo[j] = (unsigned)(((col >> 5) * W + u0 + (col & 31)) * W + (tid & 7) * 8);
-  }
-  struct Regs {
-    float4 av[APC];
-    uint4 bv[BPC];
+
+  // this wave's 16 weight rows are row tile (gate * W + u0 + 16 * (wave % 2)) / 16 of the fragment-major arrays: block
+  // (row tile, 32-deep block kb, plane) is 1 KiB in lane order -- a wave instruction reads 1 KiB of contiguous memory.
+  // (Read from the [4W][W] arrays instead, the same fragment is 16 rows x 64 bytes, every lane a cache line of its own:
+  // measured 27 GB/s per CU that way, the whole step slower than with the weights staged through LDS.)
+  const int nkb = W >> 5;
+  const unsigned bo = (unsigned)((((wave >> 1) * W + u0 + (wave & 1) * 16) >> 4) * nkb * NPL * 512 + lane * 8);
+  struct BRegs {
+    uint4 h[2], l[2];                                 // the two 32-deep blocks of a k-step, hi and lo
   };
-  auto load_b = [&](Regs& r, int kt) __attribute__((always_inline)) {
+  struct ARegs {
+    float4 v[APC];
+  };
+  auto load_b = [&](BRegs& r, int kt) __attribute__((always_inline)) {
     const bool is_x = kt < nkx;
-    const bf16_t* wh = is_x ? a.KT_hi : a.UT_hi;
-    const bf16_t* wl = is_x ? a.KT_lo : a.UT_lo;
-    const int kw = is_x ? kt * BK : kt * BK - Kx;
+    const bf16_t* wf = (is_x ? a.KF : a.UF) + bo + (is_x ? kt * 2 : kt * 2 - 2 * nkx) * NPL * 512;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) r.bv[j] = *reinterpret_cast<const uint4*>(wh + bo[j] + kw);
+    for (int s = 0; s < 2; ++s) r.h[s] = *reinterpret_cast<const uint4*>(wf + s * NPL * 512);
     if (LO) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) r.bv[2 + j] = *reinterpret_cast<const uint4*>(wl + bo[j] + kw);
+      for (int s = 0; s < 2; ++s) r.l[s] = *reinterpret_cast<const uint4*>(wf + s * NPL * 512 + 512);
     }
   };
   const float* ax[APC];
   const float* ah[APC];
-  auto load_a = [&](Regs& r, int kt) __attribute__((always_inline)) {
+  auto load_a = [&](ARegs& r, int kt) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < APC; ++j) r.av[j] = *reinterpret_cast<const float4*>((kt < nkx ? ax[j] : ah[j]) + kt * BK);
+    for (int j = 0; j < APC; ++j) r.v[j] = *reinterpret_cast<const float4*>((kt < nkx ? ax[j] : ah[j]) + kt * BK);
   };
-  auto load = [&](Regs& r, int kt) __attribute__((always_inline)) {
-    load_b(r, kt);
-    load_a(r, kt);
-  };
-  auto stage_write = [&](const Regs& r, int stage) __attribute__((always_inline)) {
+  auto stage_write = [&](const ARegs& r, int stage) __attribute__((always_inline)) {
     unsigned char* const st = smem + stage * STAGE;
 #pragma unroll
     for (int j = 0; j < APC; ++j) {
-      const float4 v = r.av[j];
+      const float4 v = r.v[j];
       const unsigned h01 = cvt_pk(v.x, v.y), h23 = cvt_pk(v.z, v.w);
       const int off = pl_off(j * 32 + (tid >> 4), (tid & 15) >> 1) + (tid & 1) * 8;
       *reinterpret_cast<uint2*>(st + off) = uint2{h01, h23};
@@ -169,30 +169,28 @@ __global__ __launch_bounds__(512, 1) void inc_tile_kernel(const IncTile a) {
         *reinterpret_cast<uint2*>(st + A_PLANE + off) = uint2{l01, l23};
       }
     }
-#pragma unroll
-    for (int j = 0; j < BPC; ++j) {
-      const int col = (j & 1) * 64 + (tid >> 3);
-      *reinterpret_cast<uint4*>(st + NPL * A_PLANE + (j >> 1) * B_PLANE + pl_off(col, tid & 7)) = r.bv[j];
-    }
   };
 
-  // ---- the weights of the first two k-steps need no index: they go out behind the index loads; then ONE wait for the
-  // indices, and everything that hangs on them -- the state rows of the two k-steps, the epilogue's inputs -- goes out
-  Regs r0, r1;
+  // ---- the weights of the first four k-steps need no index: they go out behind the index loads; then ONE wait for the
+  // indices, and everything that hangs on them -- the state rows of two k-steps, the epilogue's inputs -- goes out
+  ARegs a0, a1;
+  BRegs b0, b1, b2, b3;
   constexpr bool run_main = VAR != 2;
   if (run_main) {
-    load_b(r0, 0);
-    load_b(r1, 1);
+    load_b(b0, 0);
+    load_b(b1, 1);
+    load_b(b2, 2);
+    load_b(b3, 3);
   }
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * BPC) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(run_main ? 4 * 2 * NPL : 0) : "memory");
 #pragma unroll
   for (int j = 0; j < APC; ++j) {
     ax[j] = a.pool + (long)a_so[j] * a.slot_ld + (a.x_off >= 0 ? a.x_off : 0) + (tid & 15) * 4;
     ah[j] = a.pool + (long)a_si[j] * a.slot_ld + a.h_off + (tid & 15) * 4 - Kx;
   }
   if (run_main) {
-    load_a(r0, 0);
-    load_a(r1, 1);
+    load_a(a0, 0);
+    load_a(a1, 1);
   }
 
   // ---- epilogue inputs: requested now, used after the loop (whole groups under uniform branches: no wait in between)
@@ -215,68 +213,75 @@ __global__ __launch_bounds__(512, 1) void inc_tile_kernel(const IncTile a) {
     for (int g = 0; g < 4; ++g) et2[g] = *reinterpret_cast<const f32x4*>(a.T2 + (long)e_i2 * 4 * W + g * W + eu);
   }
 
-  f32x4 acc[RF][NT];
+  f32x4 acc[RF];
 #pragma unroll
-  for (int i = 0; i < RF; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < RF; ++i) acc[i] = zero4;
 
-  const int fr = lane & 15, fq = lane >> 4;
-  auto contract = [&](int stage) __attribute__((always_inline)) {
-    const unsigned char* const st = smem + stage * STAGE;
-    const unsigned char* const a_hi = st;
-    const unsigned char* const b_hi = st + NPL * A_PLANE;
+  auto contract = [&](int stage, const BRegs& b) __attribute__((always_inline)) {
+    const unsigned char* const a_hi = smem + stage * STAGE;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      frag16 fah[RF], fal[RF], fbh[NT], fbl[NT];
+      frag16 fah[RF], fal[RF], fbh, fbl;
+      fbh.u = b.h[s];
+      if (LO) fbl.u = b.l[s];
 #pragma unroll
       for (int i = 0; i < RF; ++i) {
-        const int off = pl_off(wm * (TR / WM) + i * 16 + fr, s * 4 + fq);
+        const int off = pl_off(i * 16 + fr, s * 4 + fq);
         fah[i].u = *reinterpret_cast<const uint4*>(a_hi + off);
         if (LO) fal[i].u = *reinterpret_cast<const uint4*>(a_hi + A_PLANE + off);
       }
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int off = pl_off(wn * 32 + j * 16 + fr, s * 4 + fq);
-        fbh[j].u = *reinterpret_cast<const uint4*>(b_hi + off);
-        if (LO) fbl[j].u = *reinterpret_cast<const uint4*>(b_hi + B_PLANE + off);
-      }
-#pragma unroll
-      for (int i = 0; i < RF; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          acc[i][j] = mfma16(fah[i].v, fbh[j].v, acc[i][j]);
-          if (LO) {
-            acc[i][j] = mfma16(fal[i].v, fbh[j].v, acc[i][j]);
-            acc[i][j] = mfma16(fah[i].v, fbl[j].v, acc[i][j]);
-          }
+      for (int i = 0; i < RF; ++i) {
+        acc[i] = mfma16(fah[i].v, fbh.v, acc[i]);
+        if (LO) {
+          acc[i] = mfma16(fal[i].v, fbh.v, acc[i]);
+          acc[i] = mfma16(fah[i].v, fbl.v, acc[i]);
         }
+      }
     }
   };
 
-  // ---- main loop, two k-steps per turn: registers -> stage, the k-step two ahead requested into the registers just
-  // emptied, one barrier, MFMAs.  A stage is rewritten two k-steps later: every wave has passed the barrier in between,
-  // which it reaches with that stage's fragment reads retired.  (The last turn is peeled so that the compiler counts its
-  // waits over a fixed sequence of loads, the first one so that the epilogue's inputs stay in flight behind it; nkt >= 4.)
+  // ---- main loop, four k-steps per turn (nkt is a multiple of 4).  Per k-step: state registers -> stage, the state rows two
+  // k-steps ahead requested into the registers just emptied, one barrier, MFMAs, the weight fragments four k-steps ahead
+  // requested into the registers just used.  A stage is rewritten two k-steps later: every wave has passed the barrier in
+  // between, which it reaches with that stage's fragment reads retired.  (The last turn is peeled so that the compiler
+  // counts its waits over a fixed sequence of loads, the first one so that the epilogue's inputs stay in flight behind it.)
   if (run_main) {
     auto turn = [&](int kt, auto more) __attribute__((always_inline)) {
       constexpr bool MORE = decltype(more)::value;
-      stage_write(r0, 0);
-      if (MORE) load(r0, kt + 2);
+      stage_write(a0, 0);
+      load_a(a0, kt + 2);
       wg_barrier();
-      contract(0);
-      stage_write(r1, 1);
-      if (MORE) load(r1, kt + 3);
+      contract(0, b0);
+      if (MORE) load_b(b0, kt + 4);
+      stage_write(a1, 1);
+      load_a(a1, kt + 3);
       wg_barrier();
-      contract(1);
+      contract(1, b1);
+      if (MORE) load_b(b1, kt + 5);
+      stage_write(a0, 0);
+      if (MORE) load_a(a0, kt + 4);
+      wg_barrier();
+      contract(0, b2);
+      if (MORE) load_b(b2, kt + 6);
+      stage_write(a1, 1);
+      if (MORE) load_a(a1, kt + 5);
+      wg_barrier();
+      contract(1, b3);
+      if (MORE) load_b(b3, kt + 7);
     };
-    turn(0, std::true_type{});
-    int kt = 2;
-    for (; kt + 2 < nkt; kt += 2) turn(kt, std::true_type{});
+    int kt = 0;
+    if (nkt > 4) {
+      turn(0, std::true_type{});
+      for (kt = 4; kt + 4 < nkt; kt += 4) turn(kt, std::true_type{});
+    }
     turn(kt, std::false_type{});
   }
   if (VAR == 1) {
-    if (acc[0][0][0] == 12345.678f) a.pool[0] = 0.f;
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < RF; ++i) t += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (t == 12345.678f) a.pool[0] = 0.f;
     return;
   }
 
@@ -287,9 +292,7 @@ __global__ __launch_bounds__(512, 1) void inc_tile_kernel(const IncTile a) {
 #pragma unroll
   for (int i = 0; i < RF; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ct[(wm * (TR / WM) + i * 16 + fq * 4 + r) * LDP + wn * 32 + j * 16 + fr] = acc[i][j][r];
+    for (int r = 0; r < 4; ++r) ct[(i * 16 + fq * 4 + r) * LDP + wave * 16 + fr] = acc[i][r];
   wg_barrier();
   if (m0 + (tid >> 3) < a.n) {
     f32x4 z[4];
@@ -309,23 +312,221 @@ __global__ __launch_bounds__(512, 1) void inc_tile_kernel(const IncTile a) {
   }
 }
 
+
+// ---------------------------------------------------------------- output layer: logits over the tied embedding + softmax
+// One launch instead of a thin GEMM and a softmax kernel: a workgroup = 16 hypotheses x all characters (V <= 256), so that a
+// row's maximum and sum never leave the CU.  The 16 state rows (the top layer's new h, through slot_out) come in coalesced,
+// are split and laid into LDS once; wave w contracts characters 32 w .. 32 w + 31 over all of K against embedding fragments
+// it loads straight into MFMA operands (each element is used by exactly one wave: no staging, no barrier in the loop), four
+// 32-deep blocks in flight per wave.
+struct OutSoftmax {
+  int n, W, V;
+  const float* pool; long slot_ld; const int* slot_out; int h_off;
+  const bf16_t* EF; int lo;                           // fragment-major embedding [round_up(V, 32) / 16][W / 32][planes][64][8], pad rows zero
+  float* probs; long ldp;
+};
+
+// byte offset inside a [16][K] bf16 plane of element k (k % 4 == 0) of row `row`: 16-byte chunks XOR-swizzled by row inside
+// groups of 16 chunks (K a multiple of 128), so that the 16 rows of a fragment read fall on different banks
+__device__ __forceinline__ unsigned o_off(int row, int k, int K) {
+  const int chunk = k >> 3;
+  const int pos = (chunk & ~15) | ((chunk ^ row) & 15);
+  return (unsigned)((row * K + pos * 8 + (k & 7)) * 2);
+}
+
+template <bool LO>
+__global__ __launch_bounds__(512, 1) void out_softmax_kernel(const OutSoftmax a) {
+  constexpr int LDC = 260;
+  const int W = a.W;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int r0 = blockIdx.x * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const plane_hi = smem;
+  unsigned char* const plane_lo = smem + (size_t)16 * W * 2;
+  float* const ct = reinterpret_cast<float*>(smem + (size_t)(LO ? 2 : 1) * 16 * W * 2);
+
+  const int my_row = min(r0 + (lane & 15), a.n - 1);
+  const int my_slot = a.slot_out[my_row];             // lanes 0..15 of every wave: the 16 rows' slots
+
+  // ---- embedding fragments of the first four blocks (they need no index)
+  const bool has_cols = wave * 32 < a.V;
+  constexpr int NPL = LO ? 2 : 1;
+  const int nkb = W >> 5;
+  const unsigned eo = (unsigned)(wave * 2 * nkb * NPL * 512 + lane * 8);      // column tile 2 w; tile 2 w + 1 = + nkb blocks
+  struct ERegs {
+    uint4 h[2], l[2];
+  };
+  auto load_e = [&](ERegs& r, int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) r.h[j] = *reinterpret_cast<const uint4*>(a.EF + eo + (j * nkb + ks) * NPL * 512);
+    if (LO) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) r.l[j] = *reinterpret_cast<const uint4*>(a.EF + eo + (j * nkb + ks) * NPL * 512 + 512);
+    }
+  };
+  ERegs e0, e1, e2, e3;
+  if (has_cols) {
+    load_e(e0, 0);
+    load_e(e1, 1);
+    load_e(e2, 2);
+    load_e(e3, 3);
+  }
+
+  // ---- state rows: coalesced (a wave instruction = 1 KiB of one row), split, into LDS; four pieces per thread in flight
+  {
+    const int per_row = W >> 2;                       // float4 pieces per row (a multiple of 32)
+    const int total = 16 * per_row;
+    for (int p0 = 0; p0 < total; p0 += 4 * 512) {
+      float4 v[4];
+      int rr[4], kk[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = min(p0 + i * 512 + tid, total - 1);
+        rr[i] = e / per_row;
+        kk[i] = (e - rr[i] * per_row) * 4;
+        // (per_row >= 64 or the wave's 64 pieces split over two rows at a 32-lane boundary: the slot comes per lane)
+        const int sl = __shfl(my_slot, rr[i] & 15);
+        v[i] = *reinterpret_cast<const float4*>(a.pool + (long)sl * a.slot_ld + a.h_off + kk[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (p0 + i * 512 + tid < total) {
+          const unsigned h01 = cvt_pk(v[i].x, v[i].y), h23 = cvt_pk(v[i].z, v[i].w);
+          const unsigned off = o_off(rr[i], kk[i], W);
+          *reinterpret_cast<uint2*>(plane_hi + off) = uint2{h01, h23};
+          if (LO) {
+            const unsigned l01 = cvt_pk(sub_f32(v[i].x, __builtin_bit_cast(float, h01 << 16)), sub_f32(v[i].y, __builtin_bit_cast(float, h01 & 0xffff0000u)));
+            const unsigned l23 = cvt_pk(sub_f32(v[i].z, __builtin_bit_cast(float, h23 << 16)), sub_f32(v[i].w, __builtin_bit_cast(float, h23 & 0xffff0000u)));
+            *reinterpret_cast<uint2*>(plane_lo + off) = uint2{l01, l23};
+          }
+        }
+      }
+    }
+  }
+  wg_barrier();
+
+  // ---- contraction (W / 32 blocks, a multiple of 4), no barrier: turns of four blocks, each set of fragments reloaded
+  // four blocks ahead right behind its use; the last turn peeled (its waits are counted over a fixed sequence of loads)
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  if (has_cols) {
+    auto contract = [&](int ks, const ERegs& e) __attribute__((always_inline)) {
+      const unsigned off = o_off(fr, ks * 32 + fq * 8, W);
+      frag16 ah, al, bh, bl;
+      ah.u = *reinterpret_cast<const uint4*>(plane_hi + off);
+      if (LO) al.u = *reinterpret_cast<const uint4*>(plane_lo + off);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bh.u = e.h[j];
+        acc[j] = mfma16(ah.v, bh.v, acc[j]);
+        if (LO) {
+          bl.u = e.l[j];
+          acc[j] = mfma16(al.v, bh.v, acc[j]);
+          acc[j] = mfma16(ah.v, bl.v, acc[j]);
+        }
+      }
+    };
+    auto turn = [&](int ks, auto more) __attribute__((always_inline)) {
+      constexpr bool MORE = decltype(more)::value;
+      contract(ks, e0);
+      if (MORE) load_e(e0, ks + 4);
+      contract(ks + 1, e1);
+      if (MORE) load_e(e1, ks + 5);
+      contract(ks + 2, e2);
+      if (MORE) load_e(e2, ks + 6);
+      contract(ks + 3, e3);
+      if (MORE) load_e(e3, ks + 7);
+    };
+    const int nks = W >> 5;
+    int ks = 0;
+    for (; ks + 4 < nks; ks += 4) turn(ks, std::true_type{});
+    turn(ks, std::false_type{});
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ct[(fq * 4 + r) * LDC + wave * 32 + j * 16 + fr] = acc[j][r];
+  }
+  wg_barrier();
+
+  // ---- softmax: wave w takes rows 2 w and 2 w + 1, a lane four characters
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int lr = wave * 2 + q;
+    const int row = r0 + lr;
+    if (row >= a.n) continue;
+    const int v0 = lane * 4;
+    float e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = v0 + k < a.V ? ct[lr * LDC + v0 + k] : -INFINITY;
+    float mx = fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      e[k] = v0 + k < a.V ? expf(e[k] - mx) : 0.f;
+      sum += e[k];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float inv = 1.f / sum;
+    float* out = a.probs + (long)row * a.ldp + v0;
+    if (v0 + 3 < a.V && (a.ldp & 3) == 0 && ((size_t)a.probs & 15) == 0) {
+      *reinterpret_cast<float4*>(out) = float4{e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv};
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (v0 + k < a.V) out[k] = e[k] * inv;
+    }
+  }
+}
+
+
+// in [rows][K] (row stride ld) bf16, hi and (lo or null) -> fragment-major out [rows / 16][K / 32][planes][64 lanes][8]: lane
+// (column c = lane % 16, quarter q = lane / 16) of block (row tile rt, kb) holds in[rt * 16 + c][kb * 32 + 8 q .. + 7], the
+// B operand of one MFMA 16x16x32 in the order its lanes take it
+__global__ void frag_major_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo, int rows, int K, long ld,
+                                  bf16_t* __restrict__ out) {
+  const int npl = lo ? 2 : 1;
+  const long total = (long)(rows >> 4) * (K >> 5) * npl * 64;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(e & 63);
+    const long blk = e >> 6;
+    const int plane = (int)(blk % npl);
+    const long t = blk / npl;
+    const int kb = (int)(t % (K >> 5));
+    const int rt = (int)(t / (K >> 5));
+    const bf16_t* src = (plane ? lo : hi) + (long)(rt * 16 + (lane & 15)) * ld + kb * 32 + (lane >> 4) * 8;
+    *reinterpret_cast<uint4*>(out + e * 8) = *reinterpret_cast<const uint4*>(src);
+  }
+}
+
 }  // namespace
 
 // one LSTM cell step of a layer for n hypotheses with pool slots; KL_ERR_SHAPE = not applicable (the caller takes
 // step_big.hip's gather + GEMM path)
+int kl_launch_frag_major(const bf16_t* hi, const bf16_t* lo, int rows, int K, long ld, bf16_t* out, hipStream_t stream) {
+  if ((rows & 15) || (K & 31) || (ld & 7) || !hi || !out) return KL_ERR_SHAPE;
+  long g = ((long)(rows >> 4) * (K >> 5) * (lo ? 2 : 1) * 64 + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(frag_major_kernel, dim3((unsigned)g), dim3(256), 0, stream, hi, lo, rows, K, ld, out);
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+// (p.UT_hi / p.KT_hi: the FRAGMENT-MAJOR arrays of the layer, hi and lo planes interleaved per block when p.split == 3)
 int kl_launch_inc_tile(const KlIncCellArgs& p, int variant, hipStream_t stream) {
   const int W = p.W;
-  if (p.n < 1 || (W & 127) || W < 256 || !p.pool || !p.slot_in || !p.slot_out || !p.UT_hi) return KL_ERR_SHAPE;
-  if ((long)4 * W * W >= (1L << 31)) return KL_ERR_SHAPE;
+  if (p.n < 1 || (W & 255) || !p.pool || !p.slot_in || !p.slot_out || !p.UT_hi) return KL_ERR_SHAPE;
+  if ((long)8 * W * W >= (1L << 31)) return KL_ERR_SHAPE;
   const bool lo = p.split == 3;
-  if (lo && (!p.UT_lo || (p.x_off >= 0 && !p.KT_lo))) return KL_ERR_ARG;
   if (p.x_off >= 0 && !p.KT_hi) return KL_ERR_ARG;
   constexpr int TR = 64;
   IncTile a;
   memset(&a, 0, sizeof(a));
   a.n = p.n; a.W = W; a.pool = p.pool; a.slot_ld = p.slot_ld; a.slot_in = p.slot_in; a.slot_out = p.slot_out;
   a.h_off = p.h_off; a.c_off = p.c_off; a.x_off = p.x_off;
-  a.UT_hi = p.UT_hi; a.UT_lo = p.UT_lo; a.KT_hi = p.KT_hi; a.KT_lo = p.KT_lo;
+  a.UF = p.UT_hi; a.KF = p.KT_hi;
   a.T1 = p.T1; a.i1 = p.i1; a.T2 = p.T2; a.i2 = p.i2; a.bias = p.bias;
   a.nx = W / 32;
   a.ny = (p.n + TR - 1) / TR;
@@ -340,8 +541,8 @@ int kl_launch_inc_tile(const KlIncCellArgs& p, int variant, hipStream_t stream) 
       if (best < 0 || cost < best) { best = cost; a.px = px; a.py = py; }
     }
   }
-  const size_t lds = (size_t)2 * (lo ? 2 : 1) * (TR + TC) * 128;
-  static_assert((size_t)TR * (TC + 4) * 4 <= (size_t)2 * (TR + TC) * 128, "the epilogue's tile fits in the stages");
+  size_t lds = (size_t)2 * (lo ? 2 : 1) * TR * 128;      // two stages of the state rows' planes ...
+  if (lds < (size_t)TR * (TC + 4) * 4) lds = (size_t)TR * (TC + 4) * 4;      // ... or the epilogue's f32 tile
 #define KL_IT_CASE(LO_, VAR_)                                                                                               \
   do {                                                                                                                      \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&inc_tile_kernel<TR, LO_, VAR_>),                                \
@@ -353,5 +554,29 @@ int kl_launch_inc_tile(const KlIncCellArgs& p, int variant, hipStream_t stream) 
   else if (variant == 2) KL_IT_CASE(true, 2);
   else KL_IT_CASE(true, 0);
 #undef KL_IT_CASE
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+// probs[n][V] = softmax(h_top . E^T) for the top layer's new h rows (pool slots slot_out); KL_ERR_SHAPE = not applicable (the
+// caller takes the thin GEMM + the softmax kernel)
+int kl_launch_out_softmax(const float* pool, long slot_ld, const int* slot_out, int h_off, const bf16_t* EF, int split,
+                          int n, int W, int V, float* probs, long ldp, hipStream_t stream) {
+  if (n < 1 || V < 1 || V > 256 || (W & 127) || !pool || !slot_out || !EF || !probs) return KL_ERR_SHAPE;
+  OutSoftmax a;
+  memset(&a, 0, sizeof(a));
+  a.n = n; a.W = W; a.V = V; a.pool = pool; a.slot_ld = slot_ld; a.slot_out = slot_out; a.h_off = h_off;
+  a.EF = EF; a.probs = probs; a.ldp = ldp;
+  const bool lo = split == 3;
+  a.lo = lo;
+  const size_t lds = (size_t)(lo ? 2 : 1) * 16 * W * 2 + (size_t)16 * 260 * 4;
+  if (lds > 150 * 1024) return KL_ERR_SHAPE;
+  const dim3 grid((n + 15) / 16);
+  if (lo) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&out_softmax_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;
+    hipLaunchKernelGGL(out_softmax_kernel<true>, grid, dim3(512), lds, stream, a);
+  } else {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&out_softmax_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;
+    hipLaunchKernelGGL(out_softmax_kernel<false>, grid, dim3(512), lds, stream, a);
+  }
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }

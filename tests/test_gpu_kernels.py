@@ -150,10 +150,10 @@ def make_model(depth, width, voc, n_ctx=1, seed=4, emb_std=0.5):
                                                      (1, 512, 64, 97, 0),
                                                      # n >= 256: big-tile path (step_big.hip)
                                                      (2, 512, 256, 300, 1), (3, 96, 30, 260, 2), (1, 128, 40, 257, 1),
-                                                     # n >= 256, widths of 256, 384, 512, ...: one launch per layer on 64 x 128 tiles with the state
+                                                     # n >= 256, widths of 256, 512, 768, ...: one launch per layer on 64 x 128 tiles with the state
                                                      # rows read through the pool slots (step_tile.hip): whole and ragged row tiles, tile grids that
                                                      # are / are not dealt to the XCDs as rectangles, 0 / 1 / 2 context variables
-                                                     (2, 256, 40, 320, 1), (3, 384, 50, 512, 0), (2, 512, 256, 1024, 1), (2, 512, 64, 449, 2),
+                                                     (2, 256, 40, 320, 1), (3, 768, 50, 512, 0), (2, 512, 256, 1024, 1), (2, 512, 64, 449, 2),
                                                      # cfg5 topology (small and big-n paths)
                                                      (4, 1024, 64, 20, 2), (4, 1024, 64, 272, 2),
                                                      # wide vocabulary (V >= 1024): output projection through the big GEMM too

@@ -10,11 +10,17 @@ rc=$?
 grep -v amdgpu.ids $OUT/r3q_tests.log | tail -8
 if [ $rc -ne 0 ]; then echo "tests rc=$rc: stopping"; exit $rc; fi
 rm -f $OUT/r3q.log
-for n in 1024 256 512 2048; do
+for n in 1024 256 2048; do
   for sm in 1 0; do
     echo "=== n=$n KL_INC_TILE=$sm" >> $OUT/r3q.log
     KL_INC_TILE=$sm KL_PROBE_PREC=3 timeout -k 10 120 python tools/probe_incremental.py $n 2>&1 | grep -v amdgpu.ids >> $OUT/r3q.log || exit 1
   done
+done
+for n in 1024 128; do
+  echo "=== n=$n KL_OUT_FUSED=0" >> $OUT/r3q.log
+  KL_OUT_FUSED=0 KL_PROBE_PREC=3 timeout -k 10 120 python tools/probe_incremental.py $n 2>&1 | grep -v amdgpu.ids >> $OUT/r3q.log || exit 1
+  echo "=== n=$n KL_OUT_FUSED=1" >> $OUT/r3q.log
+  KL_PROBE_PREC=3 timeout -k 10 120 python tools/probe_incremental.py $n 2>&1 | grep -v amdgpu.ids >> $OUT/r3q.log || exit 1
 done
 for v in 1 2; do
   echo "=== n=1024 KL_TILE_VAR=$v" >> $OUT/r3q.log
