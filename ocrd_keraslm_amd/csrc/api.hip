@@ -136,7 +136,8 @@ struct kl_handle {
   bool inc_tile = true;         // incremental step, n >= 256: step_tile.hip's one launch per layer (KL_INC_TILE=0: gather + [hi|lo|hi] GEMM)
   int tile_var = 0;             // KL_TILE_VAR: timing variants of inc_tile_kernel (never in production)
   bool out_fused = true;        // incremental step: logits + softmax in one launch (KL_OUT_FUSED=0: thin GEMM + softmax kernel)
-  int out_fused_min = 96;       // ... from this many hypotheses on (KL_OUT_FUSED_MIN)
+  int out_fused_min = 512;      // ... from this many hypotheses on (KL_OUT_FUSED_MIN; width 512: 128 rows 25.7 us per step against 24.2, 256 rows 35.8 / 35.1, 1024 rows 41.3 / 43.5)
+  int inc_small_min = KL_SMALL_STEP_N;      // step_small.hip's kernel from this many hypotheses on (KL_INC_SMALL_MIN)
   bool scan2 = true;            // second-generation wide scans where their grid plan applies (KL_SCAN2=0: first generation)
   int scan2_rows = 0;           // KL_SCAN2_ROWS = 16 / 32: rows per forward phase (0: chosen by shape)
   int scan2_pf = -1;            // KL_SCAN2_PF: where the forward scan requests its next tile (0: top of a phase, 1: behind the MFMA phase, 2: two phases ahead; -1: by shape)
@@ -948,6 +949,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->out_fused = !(env6m && env6m[0] == '0');
   const char* env6n = getenv("KL_OUT_FUSED_MIN");
   if (env6n) h->out_fused_min = atoi(env6n);
+  const char* env6o = getenv("KL_INC_SMALL_MIN");
+  if (env6o) h->inc_small_min = atoi(env6o);
   const char* env8 = getenv("KL_SCAN2");
   if (env8) h->scan2 = atoi(env8) != 0;
   const char* env8b = getenv("KL_SCAN2_ROWS");
@@ -1550,10 +1553,13 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
   }
   // 96..255 hypotheses (the reference's callers feed at most 128 / 256 rows): coalesced state rows through LDS, 16-unit
   // workgroups (step_small.hip); KL_ERR_SHAPE, or fewer rows: the launch-per-layer kernels below
-  if (h->inc_small && n >= KL_SMALL_STEP_N) {
-    int e = 0;
+  if (h->inc_small && n >= h->inc_small_min) {
+    int e = d.EF ? 0 : KL_ERR_SHAPE;
+    if (e == 0 && !h->inc_ready) KL_TRY(prepare_incremental(h, s));
     for (int l = 0; l < L && e == 0; ++l) {
-      e = kl_launch_inc_cell(cell_args(l), s);
+      KlIncCellArgs ta = cell_args(l);
+      ta.UT_hi = d.UF[l]; ta.KT_hi = d.KF[l]; ta.UT_lo = ta.KT_lo = nullptr;      // (fragment-major, planes interleaved)
+      e = kl_launch_inc_cell(ta, s);
       if (e == KL_ERR_SHAPE && l > 0) return e;      // (layer 0 decides for all: the shapes are the same)
     }
     if (e == 0) return output_layer();

@@ -261,7 +261,7 @@ int kl_launch_rows_tm_to_bm(const float* in, long ld_in, float* out, int B, int 
 
 // ---- step_small.hip -----------------------------------------------------
 // one LSTM cell step of a layer for n hypotheses with pool slots (KL_SMALL_STEP_N <= n < KL_BIG_STEP_N), see inc_cell_kernel
-#define KL_SMALL_STEP_N 96
+#define KL_SMALL_STEP_N 16
 struct KlIncCellArgs {
   int n, W, split;                     // split: 1 = bf16, 3 = split-bf16
   float* pool; long slot_ld;           // [slots][2L][W] f32

@@ -1,22 +1,21 @@
-// Incremental step for 96..255 hypotheses (the reference's callers: rate_best feeds at most 128 rows per call, generate
+// Incremental step for 16..255 hypotheses (the reference's callers: rate_best feeds at most 128 rows per call, generate
 // at most 256; rating.py:49, 704, 809).
 //
-// What the launch-per-layer thin kernels of lstm_step.hip cost at n = 128 (round 2: 2 x 17.5 us + 5.9 + 4.6 us): 512
-// four-unit workgroups, each gathering the f32 state rows of 32 hypotheses 16 bytes at a time (fragment-shaped loads: 64
-// different 64-byte segments per wave instruction) -- 192 KB per workgroup for 48 MFMAs per wave -- and a separate thin GEMM
-// and softmax for the tied output projection.  Here:
-//  * inc_cell_kernel: one workgroup = 16 hidden units x 4 gates (four MFMA column tiles) x 16 or 32 hypotheses, all of K.
-//    The state rows come in COALESCED (whole 2 KiB rows, 1 KiB per wave instruction), are split into bf16 hi + lo once and
-//    laid into LDS (16-byte chunks XOR-swizzled by row, so that the 16 rows of an MFMA fragment fall on different banks);
-//    every wave then contracts a quarter of K against weight fragments it loads straight into registers (each weight
-//    element is used by exactly one wave: no staging), the four partial tiles meet in LDS and the cell update runs on the
-//    reduced tile.  A row's bytes are fetched by W/16 workgroups instead of W/4.
-// Measured at width 512, depth 2 (round 3): 128 hypotheses 36.2 us per step against 44.3 (10.4 + 17.6 us for the two layers
-// against 2 x 17.5); at 64 and 32 hypotheses the four-unit workgroups stay faster (28.8 / 27.7 us against 35.0 / 34.7: with
-// few rows the weights dominate a workgroup's bytes and the finer column split spreads them over more CUs), so the launcher
-// is only asked from 96 rows on.  Tried and dropped: the output layer with its softmax in one launch (a workgroup = 16
-// hypotheses x all characters, so that the row maximum and sum never leave the CU): 22 us at 128 hypotheses -- eight
-// workgroups each pulling all of E -- against 5.9 + 4.6 us for the thin GEMM and the softmax kernel.
+// inc_cell_kernel: one workgroup = 16 hidden units x 4 gates (four MFMA column tiles) x 16 or 32 hypotheses, all of K, eight
+// waves.  The state rows come in COALESCED (a wave stages whole rows, 1 KiB per wave instruction, through the pool slots),
+// are split into bf16 hi + lo once and laid into LDS (16-byte chunks XOR-swizzled by row, so that the 16 rows of an MFMA
+// fragment fall on different banks); every wave then contracts an eighth of K against weight fragments it loads straight
+// into registers from the FRAGMENT-MAJOR copies of the weights (step_tile.hip's frag_major_kernel: a fragment = 1 KiB of
+// contiguous memory; each weight element is used by exactly one wave: no staging), the eight partial tiles meet in LDS and
+// the cell update runs on the reduced tile.
+// Measured at width 512, depth 2, split precision (round 3), us per step of the whole incremental step:
+//   128 hypotheses: 43.6 (round 2: four-unit thin workgroups) -> 35.8 (first cut of this kernel: 4 waves, fragments from the
+//   [4W][W] arrays) -> 29.0 (fragment-major weights) -> 24.2 (8 waves, scalar base addresses, exp2 / rcp gates; the kernel
+//   itself 10.9 -> 8.3 us per layer); 16 / 32 / 64 / 80 hypotheses 22.3 / 22.6 / 22.9 / 23.2 against 23.7 / 27.6 / 28.6 / 39.8
+//   with the thin kernels, which now only serve fewer than 16 rows and widths that are not multiples of 256.
+// What the stamps say about the rest (tools/probe_inc_stamps.py): of a launch's ~11 000 (layer 0) / ~18 000 clocks, 2 500-6 000
+// pass between the request of the slot indices and their arrival, ~1 500 more until the rows are in LDS -- the chain
+// indices -> rows -> LDS -> MFMA -> exchange -> cell, every link a memory round trip, is the launch.
 // Restates rating.py:578-639 (Rater.predict: one LSTM step per layer with explicit states, softmax over the tied
 // embedding) for the arithmetic; rows = hypotheses, state rows addressed through pool slots.
 #include <string.h>
@@ -48,127 +47,206 @@ __device__ __forceinline__ unsigned a_off(int row, int k, int K) {      // byte 
   return (unsigned)((row * K + pos * 8 + (k & 7)) * 2);
 }
 
+// diagnostic build only (-DKL_STAMP, tools/probe_inc_stamps.py): shader clock at the phases of one workgroup's wave 0,
+// layer 0 in [0, 16), the layers above in [16, 32)
+#ifdef KL_STAMP
+__device__ unsigned long long kl_inc_stamps[32];
+#define ISTAMP(i)                                                                              \
+  do {                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    if (blockIdx.x == 5 && blockIdx.y == 3 && threadIdx.x == 0) kl_inc_stamps[(a.x_off >= 0 ? 16 : 0) + (i)] = clock64(); \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+  } while (0)
+#define IWAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define ISTAMP(i)
+#define IWAIT()
+#endif
+
 struct IncCell {
   int n, W;
   float* pool; long slot_ld;
   const int* slot_in; const int* slot_out;
   int h_off, c_off, x_off;          // float offsets inside a slot: this layer's h and c, the layer below's h (-1: layer 0)
-  const bf16_t* UT_hi; const bf16_t* UT_lo; const bf16_t* KT_hi; const bf16_t* KT_lo;      // [4W][W]
+  const bf16_t* UF; const bf16_t* KF;      // fragment-major [4W / 16][W / 32][planes][64][8]
   const float* T1; const int* i1; const float* T2; const int* i2; const float* bias;       // z init (tables [.][4W], bias [4W])
 };
 
-// grid (W / 16, ceil(n / (16 NMT))), 256 threads = 4 waves (K split)
+// hardware exp2 / reciprocal gates (1 ulp each; step_tile.hip's): the ocml forms cost ~250 instructions per cell
+__device__ __forceinline__ float gate_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float gate_tanh(float x) {
+  return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.f;
+}
+
+// grid (W / 16, ceil(n / (16 NMT))), 512 threads = 8 waves (K split).
+// What the stamps of the 4-wave form showed (tools/probe_inc_stamps.py, 128 hypotheses, width 512: 19 000 - 24 000 clocks per
+// launch): the launch is bound by INSTRUCTION ISSUE, not by memory -- ~4 000 straight-line instructions per wave at one wave
+// per SIMD and 4-5 clocks each; a third of them 64-bit address arithmetic on the vector unit, because the wave index was not
+// known to be uniform.  Hence: eight waves (two per SIMD, half the k-steps and half the staging each), the wave index
+// through readfirstlane so that every base address is computed on the scalar unit (loads take the SGPR-base form), no
+// division in the staging (a wave stages whole rows), hardware exp2 / rcp gates.
 template <int NMT, bool LO>
-__global__ __launch_bounds__(256) void inc_cell_kernel(const IncCell a) {
-  constexpr int ROWS = 16 * NMT;
+__global__ __launch_bounds__(512) void inc_cell_kernel(const IncCell a) {
+  constexpr int ROWS = 16 * NMT, NW = 8, RPW = ROWS / NW, NPL = LO ? 2 : 1;
   const int W = a.W;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int u0 = blockIdx.x * 16, r0 = blockIdx.y * ROWS;
-  const int K = a.x_off >= 0 ? 2 * W : W;          // [x | h] or h alone
+  const int Kx = a.x_off >= 0 ? W : 0;
+  const int K = Kx + W;                            // [x | h] or h alone
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const plane_hi = smem;
   unsigned char* const plane_lo = smem + (size_t)ROWS * K * 2;
-  // ---- everything the epilogue will need is requested FIRST: this thread's cell = (row lr of each row tile, unit u0 + ej); the
-  // table rows, the bias and c_prev depend only on the index arrays, and a 256-thread workgroup alone on its CU has nothing to
-  // hide a late load behind
-  const int ej = tid & 15;
-  int e_in[NMT], e_out[NMT];
-  float ez[NMT][4], ecp[NMT];
+  // ---- order of the requests (loads return in order, and a CU serves its requests in order): the index arrays; ONE k-step
+  // of weights (it depends on nothing); -- one wait for the indices --; the state rows of the first staging round (the head of
+  // the chain rows -> LDS -> barrier -> MFMA: whatever is issued ahead of them delays them); the rest of the first weight group;
+  // the epilogue's inputs (table rows, bias, c_prev: needed last).
+  ISTAMP(0);
+  const int ej = tid & 15, er = (tid >> 4) & 15;   // epilogue cell of threads 0 .. 255: (row er of each row tile, unit u0 + ej)
+  int e_in[NMT], e_out[NMT], e_i1[NMT], e_i2[NMT];
 #pragma unroll
   for (int m = 0; m < NMT; ++m) {
-    const int row = min(r0 + m * 16 + (tid >> 4), a.n - 1);
+    const int row = min(r0 + m * 16 + er, a.n - 1);
     e_in[m] = a.slot_in[row];
     e_out[m] = a.slot_out[row];
-    const long t1 = a.T1 ? (long)(a.i1 ? a.i1[row] : row) * 4 * W : 0, t2 = a.T2 ? (long)(a.i2 ? a.i2[row] : row) * 4 * W : 0;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float v = a.bias ? a.bias[g * W + u0 + ej] : 0.f;
-      if (a.T1) v += a.T1[t1 + g * W + u0 + ej];
-      if (a.T2) v += a.T2[t2 + g * W + u0 + ej];
-      ez[m][g] = v;
-    }
-    ecp[m] = a.pool[(long)e_in[m] * a.slot_ld + a.c_off + u0 + ej];
+    e_i1[m] = a.i1 ? a.i1[row] : row;
+    e_i2[m] = a.i2 ? a.i2[row] : row;
   }
+  // (the rows' slots sit in lanes 0 .. ROWS - 1 of every wave and are broadcast from there)
+  const int my_row = min(r0 + (lane < ROWS ? lane : 0), a.n - 1);
+  const int sl_in = a.slot_in[my_row], sl_out = a.slot_out[my_row];
 
-  // ---- weight fragments of this wave's first k-steps go out first (they do not depend on anything)
-  const int nks = K >> 5, nks_x = a.x_off >= 0 ? (W >> 5) : 0;      // k-steps of 32; the first nks_x belong to x . K
+  const int nks = K >> 5, nks_x = Kx >> 5;         // k-steps of 32; the first nks_x belong to x . K
   const int col = lane & 15, kg = lane >> 4;
-  auto wfrag = [&](int ks, int g, bool lo) -> u32x4_t {
+  // (fragment-major arrays: block (row tile, 32-deep block, plane) = 1 KiB in lane order, see step_tile.hip's frag_major_kernel
+  // -- read from the [4W][W] arrays a fragment is 16 rows x 64 bytes, every lane a cache line of its own: 20-27 GB/s per CU)
+  const int nkb = W >> 5;
+  auto wfrag = [&](int ks, int g, int plane) -> u32x4_t {
     const bool is_x = ks < nks_x;
-    const bf16_t* base = is_x ? (lo ? a.KT_lo : a.KT_hi) : (lo ? a.UT_lo : a.UT_hi);
-    const int kk = (is_x ? ks : ks - nks_x) * 32 + kg * 8;
-    return *reinterpret_cast<const u32x4_t*>(base + (long)(g * W + u0 + col) * W + kk);
+    const bf16_t* base = (is_x ? a.KF : a.UF) + ((long)(((g * W + u0) >> 4) * nkb + (is_x ? ks : ks - nks_x)) * NPL + plane) * 512;
+    return *reinterpret_cast<const u32x4_t*>(base + lane * 8);
   };
-  // One wave per SIMD: nothing hides a load but the loads issued beside it.  So ALL weight fragments of up to GS k-steps of this
-  // wave go out at once (GS x 8 fragments = 256 registers in split precision -- a 256-thread workgroup may take 512), in front of
-  // the activation staging; width 512 needs one such group per layer, width 1024 two for the layers above the first.
-  constexpr int GS = 8;
+  // ALL weight fragments of up to GS k-steps of this wave go out at once (GS x 8 fragments = 128 registers in split precision)
+  constexpr int GS = 4;
   u32x4_t bh[GS][4], bl[GS][4];
-  const int my_steps = (nks - wave + 3) >> 2;      // k-steps wave, wave + 4, ...
-  auto load_group = [&](int s0) __attribute__((always_inline)) {
+  const int my_steps = (nks - wave + NW - 1) / NW;      // k-steps wave, wave + 8, ...
+  auto load_group = [&](int s0, int j0, int j1) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < GS; ++j) {
-      if (s0 + j < my_steps) {
+      if (j >= j0 && j < j1 && s0 + j < my_steps) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          bh[j][g] = wfrag(wave + 4 * (s0 + j), g, false);
-          if (LO) bl[j][g] = wfrag(wave + 4 * (s0 + j), g, true);
+          bh[j][g] = wfrag(wave + NW * (s0 + j), g, 0);
+          if (LO) bl[j][g] = wfrag(wave + NW * (s0 + j), g, 1);
         }
       }
     }
   };
-  load_group(0);
+  load_group(0, 0, 1);
+  ISTAMP(1);
 
-  // ---- activation rows: coalesced, split, into LDS.  Eight pieces per thread are requested before the first one is used (a
-  // loop that loads, converts and stores piece by piece is a chain of sixteen or more memory latencies); the rows' slots sit
-  // in lanes 0 .. ROWS - 1 of every wave and are broadcast from there (a piece's row is the same for a whole wave)
-  {
-    const int my_row = min(r0 + (lane < ROWS ? lane : 0), a.n - 1);
-    const int sl_in = a.slot_in[my_row], sl_out = a.slot_out[my_row];
-    const int per_row = K >> 2;                    // float4 pieces per row (a multiple of 32: a wave's 64 pieces lie in one row or two)
-    const int total = ROWS * per_row;
-    for (int e0 = 0; e0 < total; e0 += 8 * 256) {
-      float4 v[8];
-      int rr[8], kk[8];
+  // ---- activation rows: wave w stages rows RPW w .. RPW w + RPW - 1, whole rows (a wave instruction = 256 consecutive floats
+  // of one row: K / 256 pieces per lane and row), split, into LDS; AP pieces per thread and round
+  constexpr int AP = 8;
+  const int cpr = K >> 8;
+  const int npc = RPW * cpr;
+  const bool cpr_pow2 = (cpr & (cpr - 1)) == 0;
+  const int cshift = __builtin_ctz(cpr);
+  float4 av[AP];
+  auto piece = [&](int p, int& row, int& c) __attribute__((always_inline)) {
+    const int rr = cpr_pow2 ? p >> cshift : p / cpr;
+    c = p - rr * cpr;
+    row = wave * RPW + rr;
+  };
+  auto rows_load = [&](int p0) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int e = e0 + i * 256 + tid;
-        const int ec = e < total ? e : total - 1;
-        rr[i] = ec / per_row;
-        kk[i] = (ec - rr[i] * per_row) * 4;
-        // (per_row >= 64: the 64 pieces of a wave instruction lie in one row -- its slot comes from one lane)
-        const int ru = __builtin_amdgcn_readfirstlane(rr[i]);
-        const int so = __builtin_amdgcn_readlane(sl_out, ru), si = __builtin_amdgcn_readlane(sl_in, ru);
-        const float* src = (a.x_off >= 0 && kk[i] < W) ? a.pool + (long)so * a.slot_ld + a.x_off + kk[i]
-                                                       : a.pool + (long)si * a.slot_ld + a.h_off + (kk[i] - (a.x_off >= 0 ? W : 0));
-        v[i] = *reinterpret_cast<const float4*>(src);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (e0 + i * 256 + tid < total) {
-          uint2 hi, lo;
-          split4<LO>(v[i], hi, lo);
-          const unsigned off = a_off(rr[i], kk[i], K);
-          *reinterpret_cast<uint2*>(plane_hi + off) = hi;
-          if (LO) *reinterpret_cast<uint2*>(plane_lo + off) = lo;
-        }
+    for (int i = 0; i < AP; ++i) {
+      if (p0 + i < npc) {
+        int row, c;
+        piece(p0 + i, row, c);
+        const int so = __builtin_amdgcn_readlane(sl_out, row), si = __builtin_amdgcn_readlane(sl_in, row);
+        const int k0 = c * 256;                    // (W is a multiple of 256: a piece lies in x or in h)
+        const float* src = k0 < Kx ? a.pool + (long)so * a.slot_ld + a.x_off + k0 : a.pool + (long)si * a.slot_ld + a.h_off + (k0 - Kx);
+        av[i] = *reinterpret_cast<const float4*>(src + lane * 4);
       }
     }
+  };
+  auto rows_store = [&](int p0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      if (p0 + i < npc) {
+        int row, c;
+        piece(p0 + i, row, c);
+        uint2 hi, lo;
+        split4<LO>(av[i], hi, lo);
+        const unsigned off = a_off(row, c * 256 + lane * 4, K);
+        *reinterpret_cast<uint2*>(plane_hi + off) = hi;
+        if (LO) *reinterpret_cast<uint2*>(plane_lo + off) = lo;
+      }
+    }
+  };
+  rows_load(0);
+  ISTAMP(2);
+  load_group(0, 1, GS);
+
+  // ---- the epilogue's inputs (threads 0 .. 255)
+  float eb[4], et1[NMT][4], et2[NMT][4], ecp[NMT];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) eb[g] = 0.f;
+#pragma unroll
+  for (int m = 0; m < NMT; ++m) {
+    ecp[m] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) et1[m][g] = et2[m][g] = 0.f;
+  }
+  if (wave < 4) {
+    if (a.bias) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) eb[g] = a.bias[g * W + u0 + ej];
+    }
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) ecp[m] = a.pool[(long)e_in[m] * a.slot_ld + a.c_off + u0 + ej];
+    if (a.T1) {
+#pragma unroll
+      for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) et1[m][g] = a.T1[(long)e_i1[m] * 4 * W + g * W + u0 + ej];
+    }
+    if (a.T2) {
+#pragma unroll
+      for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) et2[m][g] = a.T2[(long)e_i2[m] * 4 * W + g * W + u0 + ej];
+    }
+  }
+  ISTAMP(3);
+  rows_store(0);
+  ISTAMP(5);
+  for (int p0 = AP; p0 < npc; p0 += AP) {
+    rows_load(p0);
+    rows_store(p0);
   }
   __syncthreads();
+  ISTAMP(6);
+#ifdef KL_STAMP
+  IWAIT();
+  ISTAMP(7);
+#endif
 
-  // ---- contraction: wave w takes k-steps w, w + 4, ...; 3 MFMAs per (row tile, gate) and k-step in split precision
+  // ---- contraction: wave w takes k-steps w, w + 8, ...; 3 MFMAs per (row tile, gate) and k-step in split precision
   f32x4 acc[NMT][4];
 #pragma unroll
   for (int m = 0; m < NMT; ++m)
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[m][g] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int s0 = 0; s0 < my_steps; s0 += GS) {
-    if (s0 > 0) load_group(s0);
+    if (s0 > 0) load_group(s0, 0, GS);
 #pragma unroll
     for (int j = 0; j < GS; ++j) {
       if (s0 + j < my_steps) {
-        const int ks = wave + 4 * (s0 + j);
+        const int ks = wave + NW * (s0 + j);
 #pragma unroll
         for (int m = 0; m < NMT; ++m) {
           const unsigned off = a_off(m * 16 + col, ks * 32 + kg * 8, K);
@@ -188,8 +266,9 @@ __global__ __launch_bounds__(256) void inc_cell_kernel(const IncCell a) {
       }
     }
   }
+  ISTAMP(8);
   __syncthreads();      // (every wave has read its last fragments: the planes make room for the partial tiles)
-  float* const part = reinterpret_cast<float*>(smem);      // [4 waves][NMT][4 gates][16 rows][17]
+  float* const part = reinterpret_cast<float*>(smem);      // [8 waves][NMT][4 gates][16 rows][17]
 #pragma unroll
   for (int m = 0; m < NMT; ++m)
 #pragma unroll
@@ -198,58 +277,71 @@ __global__ __launch_bounds__(256) void inc_cell_kernel(const IncCell a) {
       for (int r = 0; r < 4; ++r) part[(((wave * NMT + m) * 4 + g) * 16 + kg * 4 + r) * 17 + col] = acc[m][g][r];
   __syncthreads();
 
-  // ---- cell update on the reduced tile: thread = (row, unit), NMT cells each
+  ISTAMP(9);
+  // ---- cell update on the reduced tile: thread = (row, unit), NMT cells each, threads 0 .. 255
+  if (wave < 4) {
 #pragma unroll
-  for (int m = 0; m < NMT; ++m) {
-    const int row = r0 + m * 16 + (tid >> 4);
-    if (row >= a.n) continue;
-    const int u = u0 + ej;
-    float z[4];
+    for (int m = 0; m < NMT; ++m) {
+      const int row = r0 + m * 16 + er;
+      if (row >= a.n) continue;
+      const int u = u0 + ej;
+      float z[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float v = ez[m][g];
+      for (int g = 0; g < 4; ++g) {
+        float v = eb[g] + et1[m][g] + et2[m][g];
 #pragma unroll
-      for (int w = 0; w < 4; ++w) v += part[(((w * NMT + m) * 4 + g) * 16 + (tid >> 4)) * 17 + ej];
-      z[g] = v;
+        for (int w = 0; w < NW; ++w) v += part[(((w * NMT + m) * 4 + g) * 16 + er) * 17 + ej];
+        z[g] = v;
+      }
+      const float gi = gate_sigmoid(z[0]), gf = gate_sigmoid(z[1]), gg = gate_tanh(z[2]), go = gate_sigmoid(z[3]);
+      const float c = gf * ecp[m] + gi * gg;
+      const float h = go * gate_tanh(c);
+      float* out = a.pool + (long)e_out[m] * a.slot_ld;
+      out[a.c_off + u] = c;
+      out[a.h_off + u] = h;
     }
-    const float gi = sigmoidf_(z[0]), gf = sigmoidf_(z[1]), gg = tanhf_(z[2]), go = sigmoidf_(z[3]);
-    const float c = gf * ecp[m] + gi * gg;
-    const float h = go * tanhf_(c);
-    float* out = a.pool + (long)e_out[m] * a.slot_ld;
-    out[a.c_off + u] = c;
-    out[a.h_off + u] = h;
   }
+  ISTAMP(10);
+#ifdef KL_STAMP
+  IWAIT();
+  ISTAMP(11);
+#endif
 }
 
 constexpr size_t LDS_LIMIT = 150 * 1024;
 
 }  // namespace
 
+#ifdef KL_STAMP
+extern "C" int kl_test_read_inc_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(kl_inc_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+#endif
+
 // one LSTM cell step of layer `l` for n hypotheses with pool slots; KL_ERR_SHAPE = not applicable (the caller takes the
-// launch-per-layer kernels of lstm_step.hip)
+// launch-per-layer kernels of lstm_step.hip).  p.UT_hi / p.KT_hi: the FRAGMENT-MAJOR arrays of the layer (planes interleaved).
 int kl_launch_inc_cell(const KlIncCellArgs& p, hipStream_t stream) {
   const int W = p.W;
   if (p.n < 1 || (W & 255) || !p.pool || !p.slot_in || !p.slot_out || !p.UT_hi) return KL_ERR_SHAPE;
   const bool lo = p.split == 3;
-  if (lo && (!p.UT_lo || (p.x_off >= 0 && !p.KT_lo))) return KL_ERR_ARG;
   if (p.x_off >= 0 && !p.KT_hi) return KL_ERR_ARG;
   const int K = p.x_off >= 0 ? 2 * W : W;
   int nmt = p.n > 128 ? 2 : 1;
   if ((size_t)16 * nmt * K * 4 > LDS_LIMIT) nmt = 1;
   size_t lds = (size_t)16 * nmt * K * 4;
-  if (lds < (size_t)4 * nmt * 4 * 16 * 17 * 4) lds = (size_t)4 * nmt * 4 * 16 * 17 * 4;      // (the partial tiles re-use the planes' room)
+  if (lds < (size_t)8 * nmt * 4 * 16 * 17 * 4) lds = (size_t)8 * nmt * 4 * 16 * 17 * 4;      // (the partial tiles re-use the planes' room)
   if (lds > LDS_LIMIT) return KL_ERR_SHAPE;
   IncCell a;
   a.n = p.n; a.W = W; a.pool = p.pool; a.slot_ld = p.slot_ld; a.slot_in = p.slot_in; a.slot_out = p.slot_out;
   a.h_off = p.h_off; a.c_off = p.c_off; a.x_off = p.x_off;
-  a.UT_hi = p.UT_hi; a.UT_lo = p.UT_lo; a.KT_hi = p.KT_hi; a.KT_lo = p.KT_lo;
+  a.UF = p.UT_hi; a.KF = p.KT_hi;
   a.T1 = p.T1; a.i1 = p.i1; a.T2 = p.T2; a.i2 = p.i2; a.bias = p.bias;
   dim3 grid(W / 16, (p.n + 16 * nmt - 1) / (16 * nmt));
 #define KL_IC_CASE(NMT_, LO_)                                                                                               \
   do {                                                                                                                      \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&inc_cell_kernel<NMT_, LO_>),                                    \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;     \
-    hipLaunchKernelGGL((inc_cell_kernel<NMT_, LO_>), grid, dim3(256), lds, stream, a);                                      \
+    hipLaunchKernelGGL((inc_cell_kernel<NMT_, LO_>), grid, dim3(512), lds, stream, a);                                      \
   } while (0)
   if (nmt == 2) { if (lo) KL_IC_CASE(2, true); else KL_IC_CASE(2, false); }
   else { if (lo) KL_IC_CASE(1, true); else KL_IC_CASE(1, false); }

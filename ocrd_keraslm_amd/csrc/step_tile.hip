@@ -1,21 +1,28 @@
 // Incremental step for many hypotheses (n >= 256; Rater.predict / rate_best batches, rating.py:578-639): ONE launch per
-// layer, a workgroup = TR hypotheses x 32 hidden units x 4 gates, the contraction in split precision over operands
-// that are each read ONCE per tile.
+// layer, a workgroup = 64 hypotheses x 32 hidden units x 4 gates, the contraction in split precision over operands
+// that are each read ONCE per tile; and the output layer (logits over the tied embedding + softmax) in one launch.
 //
 // What the [hi | lo | hi] . [w_hi | w_hi | w_lo] form of step_big.hip + gemm.hip cost (round 2-3: 2 x 23 us of a 60 us
-// step at 1024 hypotheses): 6 bytes per element on both sides (hi twice), all of it by LDS-DMA (1 KiB per ~32 cycles of
-// the CU's address unit: ~70 GB/s per CU whatever is in flight), behind a separate gather launch that splits the f32 state
-// rows, in front of an epilogue whose inputs were requested only after the last k-step.  Here:
+// step at 1024 hypotheses): 6 bytes per element on both sides (hi twice), all of it by LDS-DMA, behind a separate gather
+// launch that splits the f32 state rows, in front of an epilogue whose inputs were requested only after the last k-step
+// and whose gates cost ~250 instructions per cell.  Here:
 //  * the state rows are read as they are (f32, through the pool slots: slot_out for the layer below's new h, slot_in for
-//    this layer's previous h), split into bf16 hi + lo in registers and laid into the stage's two A planes -- no gather
+//    this layer's previous h), split into bf16 hi + lo in registers and laid into the stage's two planes -- no gather
 //    launch, no activation copy in HBM, 4 bytes per element;
-//  * the weights come from the [4W][W] hi / lo arrays kl_prepare keeps anyway (the tile's 128 columns are four row groups
-//    of 32, one per gate: no permuted copy), 4 bytes per element, as 16-byte register loads (half the address-unit time
-//    of LDS-DMA) two k-steps ahead;
+//  * the weights never touch LDS: wave w owns columns 16 w .. 16 w + 15 of the tile, and its fragments come straight from
+//    FRAGMENT-MAJOR copies of the [4W][W] hi / lo arrays (frag_major_kernel: block (16 rows, 32-deep k block, plane) = 1 KiB
+//    in the order the MFMA's lanes take it, so a wave instruction reads 1 KiB of contiguous memory), four k-steps ahead.
+//    Read from the [4W][W] arrays themselves, a fragment is 16 rows x 64 bytes with consecutive lanes in different rows:
+//    every lane a cache line of its own -- measured 27 GB/s per CU, slower than staging the weights through LDS;
 //  * three MFMAs per fragment pair: hi.hi + lo.hi + hi.lo;
-//  * the epilogue's inputs (c_prev, the table rows of layer 0, the bias) are requested before the main loop;
+//  * the epilogue's inputs (c_prev, the table rows of layer 0, the bias) are requested before the main loop, as 16-byte
+//    accesses (a dword access costs the CU's address unit as much), the gates from the hardware's exp2 and reciprocal;
 //  * tiles are dealt to the XCDs as rectangles of the tile grid (4 unit blocks x 8 row tiles at 1024 x 512), so that an
 //    XCD's L2 holds what its 32 tiles share (speed only: any placement is correct).
+// Measured (round 3, depth 2, width 512, split precision): 1024 hypotheses 60.7 -> 40-42 us per step (the two cell launches
+// 2 x 23 -> 12.2 + 19.8 us, gather 5.6 -> none, thin GEMM 8.9 + softmax 4.8 -> 9.6 us); 2048: 96 -> 70; depth 4 / width 1024
+// at 1024 hypotheses 453 -> 233 us.  The main loop runs at the L2's rate: 256 workgroups x (64 + 128) rows x K x 4 bytes =
+// 196 MB per layer-1 launch at ~18 TB/s (64 B/clk per L2 channel, 16 channels per XCD).
 // The arithmetic restates rating.py:578-639 (one LSTM step per layer with explicit states); rows = hypotheses.
 #include <string.h>
 
@@ -366,12 +373,21 @@ __global__ __launch_bounds__(512, 1) void out_softmax_kernel(const OutSoftmax a)
       for (int j = 0; j < 2; ++j) r.l[j] = *reinterpret_cast<const uint4*>(a.EF + eo + (j * nkb + ks) * NPL * 512 + 512);
     }
   };
-  ERegs e0, e1, e2, e3;
+  // (eight blocks in flight per wave = 256 KiB per CU: with only n / 16 workgroups on the chip nothing but a CU's own
+  // requests in flight sets its rate -- four blocks: 9.6 us per launch at width 512, 53 GB/s per CU)
+  ERegs e0, e1, e2, e3, e4, e5, e6, e7;
+  const int nks = W >> 5;
   if (has_cols) {
     load_e(e0, 0);
     load_e(e1, 1);
     load_e(e2, 2);
     load_e(e3, 3);
+    if (nks > 4) {
+      load_e(e4, 4);
+      load_e(e5, 5);
+      load_e(e6, 6);
+      load_e(e7, 7);
+    }
   }
 
   // ---- state rows: coalesced (a wave instruction = 1 KiB of one row), split, into LDS; four pieces per thread in flight
@@ -407,8 +423,8 @@ __global__ __launch_bounds__(512, 1) void out_softmax_kernel(const OutSoftmax a)
   }
   wg_barrier();
 
-  // ---- contraction (W / 32 blocks, a multiple of 4), no barrier: turns of four blocks, each set of fragments reloaded
-  // four blocks ahead right behind its use; the last turn peeled (its waits are counted over a fixed sequence of loads)
+  // ---- contraction, no barrier: turns of eight blocks, each set of fragments reloaded eight blocks ahead right behind its
+  // use; the last turn peeled (its waits are counted over a fixed sequence of loads)
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   if (has_cols) {
     auto contract = [&](int ks, const ERegs& e) __attribute__((always_inline)) {
@@ -430,18 +446,32 @@ __global__ __launch_bounds__(512, 1) void out_softmax_kernel(const OutSoftmax a)
     auto turn = [&](int ks, auto more) __attribute__((always_inline)) {
       constexpr bool MORE = decltype(more)::value;
       contract(ks, e0);
-      if (MORE) load_e(e0, ks + 4);
+      if (MORE) load_e(e0, ks + 8);
       contract(ks + 1, e1);
-      if (MORE) load_e(e1, ks + 5);
+      if (MORE) load_e(e1, ks + 9);
       contract(ks + 2, e2);
-      if (MORE) load_e(e2, ks + 6);
+      if (MORE) load_e(e2, ks + 10);
       contract(ks + 3, e3);
-      if (MORE) load_e(e3, ks + 7);
+      if (MORE) load_e(e3, ks + 11);
+      contract(ks + 4, e4);
+      if (MORE) load_e(e4, ks + 12);
+      contract(ks + 5, e5);
+      if (MORE) load_e(e5, ks + 13);
+      contract(ks + 6, e6);
+      if (MORE) load_e(e6, ks + 14);
+      contract(ks + 7, e7);
+      if (MORE) load_e(e7, ks + 15);
     };
-    const int nks = W >> 5;
-    int ks = 0;
-    for (; ks + 4 < nks; ks += 4) turn(ks, std::true_type{});
-    turn(ks, std::false_type{});
+    if (nks == 4) {      // width 128
+      contract(0, e0);
+      contract(1, e1);
+      contract(2, e2);
+      contract(3, e3);
+    } else {             // widths of 256, 512, ...: W / 32 a multiple of 8
+      int ks = 0;
+      for (; ks + 8 < nks; ks += 8) turn(ks, std::true_type{});
+      turn(ks, std::false_type{});
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -561,7 +591,7 @@ int kl_launch_inc_tile(const KlIncCellArgs& p, int variant, hipStream_t stream) 
 // caller takes the thin GEMM + the softmax kernel)
 int kl_launch_out_softmax(const float* pool, long slot_ld, const int* slot_out, int h_off, const bf16_t* EF, int split,
                           int n, int W, int V, float* probs, long ldp, hipStream_t stream) {
-  if (n < 1 || V < 1 || V > 256 || (W & 127) || !pool || !slot_out || !EF || !probs) return KL_ERR_SHAPE;
+  if (n < 1 || V < 1 || V > 256 || (W != 128 && (W & 255)) || !pool || !slot_out || !EF || !probs) return KL_ERR_SHAPE;
   OutSoftmax a;
   memset(&a, 0, sizeof(a));
   a.n = n; a.W = W; a.V = V; a.pool = pool; a.slot_ld = slot_ld; a.slot_out = slot_out; a.h_off = h_off;

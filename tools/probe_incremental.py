@@ -5,9 +5,10 @@ import numpy as np, torch
 sys.path.insert(0, '.')
 from ocrd_keraslm_amd.lib import hipabi
 from ocrd_keraslm_amd.lib.engine import HipLM
-L, W, V = 2, 512, 256
+L, W, V = int(os.environ.get('KL_PROBE_L', '2')), int(os.environ.get('KL_PROBE_W', '512')), 256
+NC = int(os.environ.get('KL_PROBE_C', '1'))
 S = int(os.environ.get("KL_PROBE_STEPS", "200"))
-lm = HipLM(L, W, V, 1)
+lm = HipLM(L, W, V, NC)
 lm.init_weights(seed=4, emb_std=0.5)
 rng = np.random.default_rng(3)
 for prec in [int(x) for x in os.environ.get("KL_PROBE_PREC", "3,1").split(",")]:
@@ -15,7 +16,7 @@ for prec in [int(x) for x in os.environ.get("KL_PROBE_PREC", "3,1").split(",")]:
     for n in [int(a) for a in sys.argv[1:]] or [128, 1024]:
         lm.ensure_pool(2 * n)
         ids = torch.from_numpy(rng.integers(1, V, size=(S, n)).astype(np.int32)).cuda()
-        cc = torch.from_numpy(rng.integers(0, 200, size=(n, 1)).astype(np.int32)).cuda()
+        cc = torch.from_numpy(rng.integers(0, 200, size=(n, NC)).astype(np.int32)).cuda()
         a = torch.arange(n, dtype=torch.int32).cuda(); b = a + n
         for s in range(20):
             lm.step_slots(ids[s], cc, a, b); a, b = b, a
