@@ -416,7 +416,7 @@ def main():
     if not args.no_incremental:
         lm.prepare(hipabi.KL_PREC_SPLIT)
         legs = {}
-        for N, S in ((1024, 512), (128, 512)):
+        for N, S in ((1024, 512), (128, 512), (32, 512)):
             legs[N] = incremental_leg(lm, device, DEPTH, WIDTH, N_CTX, N, S, seed=3 + rank)
         if world > 1:
             t = torch.tensor([legs[1024]["value"], legs[128]["value"]], dtype=torch.float64, device=device)
@@ -431,7 +431,10 @@ def main():
                                 "gpu_us_per_step": legs[128]["gpu_us_per_step"],
                                 "algorithmic_bytes_per_step": legs[128]["algorithmic_bytes_per_step"],
                                 "hbm_frac": legs[128]["hbm_frac"], "mfma_frac": legs[128]["mfma_frac"],
-                                "note": "the reference's batch cap (rating.py:49, 809)"}}
+                                "note": "the reference's batch cap (rating.py:49, 809)"},
+                       "n32": {"value": legs[32]["value"], "hypotheses": 32, "us_per_step": legs[32]["us_per_step"],
+                               "gpu_us_per_step": legs[32]["gpu_us_per_step"],
+                               "note": "a beam of 10 with 3 alternatives per edge (rate_best's default width, rating.py:712); this rank's GPU"}}
 
     # ---- rating windows (rate / rate2 / test): the stateful windowed forward in split precision with probabilities out,
     # at the reference's batching (1 stream x 256 chars, rating.py:490) and at 64 streams; rank 0 reports its own GPU

@@ -104,19 +104,32 @@ __global__ __launch_bounds__(512) void inc_cell_kernel(const IncCell a) {
   // the chain rows -> LDS -> barrier -> MFMA: whatever is issued ahead of them delays them); the rest of the first weight group;
   // the epilogue's inputs (table rows, bias, c_prev: needed last).
   ISTAMP(0);
+  // (Every workgroup of a row tile -- W / 16 of them, eight waves each -- asks for the same few cache lines of the index
+  // arrays at the same moment, and an L2 channel answers the requests for one line one after the other: the stamps showed
+  // 2 500 - 6 000 clocks between the request of the indices and their arrival.  So a wave asks only for what it needs: the
+  // slots of the rows it stages by SCALAR loads, the epilogue's indices in waves 0 .. 3 alone.)
   const int ej = tid & 15, er = (tid >> 4) & 15;   // epilogue cell of threads 0 .. 255: (row er of each row tile, unit u0 + ej)
   int e_in[NMT], e_out[NMT], e_i1[NMT], e_i2[NMT];
 #pragma unroll
-  for (int m = 0; m < NMT; ++m) {
-    const int row = min(r0 + m * 16 + er, a.n - 1);
-    e_in[m] = a.slot_in[row];
-    e_out[m] = a.slot_out[row];
-    e_i1[m] = a.i1 ? a.i1[row] : row;
-    e_i2[m] = a.i2 ? a.i2[row] : row;
+  for (int m = 0; m < NMT; ++m) e_in[m] = e_out[m] = e_i1[m] = e_i2[m] = 0;
+  if (wave < 4) {
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) {
+      const int row = min(r0 + m * 16 + er, a.n - 1);
+      e_in[m] = a.slot_in[row];
+      e_out[m] = a.slot_out[row];
+      e_i1[m] = a.i1 ? a.i1[row] : row;
+      e_i2[m] = a.i2 ? a.i2[row] : row;
+    }
   }
-  // (the rows' slots sit in lanes 0 .. ROWS - 1 of every wave and are broadcast from there)
-  const int my_row = min(r0 + (lane < ROWS ? lane : 0), a.n - 1);
-  const int sl_in = a.slot_in[my_row], sl_out = a.slot_out[my_row];
+  // the slots of this wave's RPW staging rows (uniform addresses: scalar loads)
+  int sl_in[RPW], sl_out[RPW];
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = min(r0 + wave * RPW + rr, a.n - 1);
+    sl_in[rr] = a.slot_in[row];
+    sl_out[rr] = a.slot_out[row];
+  }
 
   const int nks = K >> 5, nks_x = Kx >> 5;         // k-steps of 32; the first nks_x belong to x . K
   const int col = lane & 15, kg = lane >> 4;
@@ -155,18 +168,23 @@ __global__ __launch_bounds__(512) void inc_cell_kernel(const IncCell a) {
   const bool cpr_pow2 = (cpr & (cpr - 1)) == 0;
   const int cshift = __builtin_ctz(cpr);
   float4 av[AP];
-  auto piece = [&](int p, int& row, int& c) __attribute__((always_inline)) {
-    const int rr = cpr_pow2 ? p >> cshift : p / cpr;
+  auto piece = [&](int p, int& rr, int& c) __attribute__((always_inline)) {
+    rr = cpr_pow2 ? p >> cshift : p / cpr;
     c = p - rr * cpr;
-    row = wave * RPW + rr;
+  };
+  auto pick = [&](const int (&v)[RPW], int rr) __attribute__((always_inline)) {      // v[rr] for a uniform rr without indexing registers
+    int x = v[0];
+#pragma unroll
+    for (int q = 1; q < RPW; ++q) x = rr == q ? v[q] : x;
+    return x;
   };
   auto rows_load = [&](int p0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       if (p0 + i < npc) {
-        int row, c;
-        piece(p0 + i, row, c);
-        const int so = __builtin_amdgcn_readlane(sl_out, row), si = __builtin_amdgcn_readlane(sl_in, row);
+        int rr, c;
+        piece(p0 + i, rr, c);
+        const int so = pick(sl_out, rr), si = pick(sl_in, rr);
         const int k0 = c * 256;                    // (W is a multiple of 256: a piece lies in x or in h)
         const float* src = k0 < Kx ? a.pool + (long)so * a.slot_ld + a.x_off + k0 : a.pool + (long)si * a.slot_ld + a.h_off + (k0 - Kx);
         av[i] = *reinterpret_cast<const float4*>(src + lane * 4);
@@ -177,11 +195,11 @@ __global__ __launch_bounds__(512) void inc_cell_kernel(const IncCell a) {
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       if (p0 + i < npc) {
-        int row, c;
-        piece(p0 + i, row, c);
+        int rr, c;
+        piece(p0 + i, rr, c);
         uint2 hi, lo;
         split4<LO>(av[i], hi, lo);
-        const unsigned off = a_off(row, c * 256 + lane * 4, K);
+        const unsigned off = a_off(wave * RPW + rr, c * 256 + lane * 4, K);
         *reinterpret_cast<uint2*>(plane_hi + off) = hi;
         if (LO) *reinterpret_cast<uint2*>(plane_lo + off) = lo;
       }

@@ -119,20 +119,19 @@ __global__ __launch_bounds__(512, 1) void inc_tile_kernel(const IncTile a) {
   const int Kx = a.x_off >= 0 ? W : 0;                // [x | h] or h alone
   const int nkt = (Kx + W) / BK, nkx = Kx / BK;
 
-  // ---- every index this thread will need, in one round trip: the slots of its A rows (piece j: row j * 32 + tid / 16, floats
-  // 4 * (tid % 16) .. + 3 of the k-step) and of its epilogue cells (row tid / 8, units u0 + 4 * (tid % 8) .. + 3: 16-byte
-  // loads and stores -- a dword access costs the CU's address unit as much as a 16-byte one, and there are 13 loads per
-  // thread this way, not 44)
-  int a_si[APC], a_so[APC];
-#pragma unroll
-  for (int j = 0; j < APC; ++j) {
-    const int row = min(m0 + j * 32 + (tid >> 4), a.n - 1);
-    a_si[j] = a.slot_in[row];
-    a_so[j] = a.slot_out[row];
+  // ---- the indices of the tile's 64 rows (pool slots, table rows): requested by ONE wave and handed to the others through
+  // LDS.  (Every workgroup of a row tile -- W / 32 of them, eight waves each -- would ask for the same few cache lines at the
+  // same moment, and an L2 channel answers the requests for one line one after the other: step_small.hip's stamps showed
+  // 2 500 - 6 000 clocks from request to arrival that way.)
+  __shared__ int idx_lds[4][TR];
+  int i_si = 0, i_so = 0, i_1 = 0, i_2 = 0;
+  if (wave == 0) {
+    const int row = min(m0 + lane, a.n - 1);
+    i_si = a.slot_in[row];
+    i_so = a.slot_out[row];
+    i_1 = a.i1 ? a.i1[row] : row;
+    i_2 = a.i2 ? a.i2[row] : row;
   }
-  const int erow = min(m0 + (tid >> 3), a.n - 1);
-  const int e_si = a.slot_in[erow], e_out = a.slot_out[erow];
-  const int e_i1 = a.i1 ? a.i1[erow] : erow, e_i2 = a.i2 ? a.i2[erow] : erow;
 
   // this wave's 16 weight rows are row tile (gate * W + u0 + 16 * (wave % 2)) / 16 of the fragment-major arrays: block
   // (row tile, 32-deep block kb, plane) is 1 KiB in lane order -- a wave instruction reads 1 KiB of contiguous memory.
@@ -189,12 +188,24 @@ __global__ __launch_bounds__(512, 1) void inc_tile_kernel(const IncTile a) {
     load_b(b2, 2);
     load_b(b3, 3);
   }
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(run_main ? 4 * 2 * NPL : 0) : "memory");
+  if (wave == 0) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(run_main ? 4 * 2 * NPL : 0) : "memory");
+    idx_lds[0][lane] = i_si;
+    idx_lds[1][lane] = i_so;
+    idx_lds[2][lane] = i_1;
+    idx_lds[3][lane] = i_2;
+  }
+  wg_barrier();
+  // A piece j: row j * 32 + tid / 16, floats 4 * (tid % 16) .. + 3 of the k-step; epilogue cells: row tid / 8, units u0 + 4 * (tid % 8) .. + 3
+  // (16-byte loads and stores -- a dword access costs the CU's address unit as much as a 16-byte one, and there are 13 loads
+  // per thread this way, not 44)
 #pragma unroll
   for (int j = 0; j < APC; ++j) {
-    ax[j] = a.pool + (long)a_so[j] * a.slot_ld + (a.x_off >= 0 ? a.x_off : 0) + (tid & 15) * 4;
-    ah[j] = a.pool + (long)a_si[j] * a.slot_ld + a.h_off + (tid & 15) * 4 - Kx;
+    const int lr = j * 32 + (tid >> 4);
+    ax[j] = a.pool + (long)idx_lds[1][lr] * a.slot_ld + (a.x_off >= 0 ? a.x_off : 0) + (tid & 15) * 4;
+    ah[j] = a.pool + (long)idx_lds[0][lr] * a.slot_ld + a.h_off + (tid & 15) * 4 - Kx;
   }
+  const int e_si = idx_lds[0][tid >> 3], e_out = idx_lds[1][tid >> 3], e_i1 = idx_lds[2][tid >> 3], e_i2 = idx_lds[3][tid >> 3];
   if (run_main) {
     load_a(a0, 0);
     load_a(a1, 1);
