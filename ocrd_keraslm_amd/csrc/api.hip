@@ -1460,8 +1460,7 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
     a.n = n; a.W = W; a.split = split;
     a.pool = pool; a.slot_ld = slot_ld; a.slot_in = slot_in; a.slot_out = slot_out;
     a.h_off = 2 * l * W; a.c_off = (2 * l + 1) * W; a.x_off = l > 0 ? 2 * (l - 1) * W : -1;
-    a.UT_hi = d.UT_hi[l]; a.UT_lo = split == 3 ? d.UT_lo[l] : nullptr;
-    a.KT_hi = l > 0 ? d.KT_hi[l] : nullptr; a.KT_lo = (l > 0 && split == 3) ? d.KT_lo[l] : nullptr;
+    a.UF = d.UF[l]; a.KF = d.KF[l];
     if (l == 0) {
       if (prow) { a.T1 = prow; }
       else { a.T1 = d.EK; a.i1 = idx; a.T2 = d.CtxK[0]; a.i2 = ctx; a.bias = P + h->off_b[0]; }
@@ -1476,9 +1475,7 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
     if (!h->inc_ready) KL_TRY(prepare_incremental(h, s));
     int e = 0;
     for (int l = 0; l < L && e == 0; ++l) {
-      KlIncCellArgs ta = cell_args(l);
-      ta.UT_hi = d.UF[l]; ta.KT_hi = d.KF[l]; ta.UT_lo = ta.KT_lo = nullptr;      // (fragment-major, planes interleaved)
-      e = kl_launch_inc_tile(ta, h->tile_var, s);
+      e = kl_launch_inc_tile(cell_args(l), h->tile_var, s);
       if (e == KL_ERR_SHAPE && l > 0) return e;      // (layer 0 decides for all: the shapes are the same)
     }
     if (e == 0) return output_layer();
@@ -1557,9 +1554,7 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
     int e = d.EF ? 0 : KL_ERR_SHAPE;
     if (e == 0 && !h->inc_ready) KL_TRY(prepare_incremental(h, s));
     for (int l = 0; l < L && e == 0; ++l) {
-      KlIncCellArgs ta = cell_args(l);
-      ta.UT_hi = d.UF[l]; ta.KT_hi = d.KF[l]; ta.UT_lo = ta.KT_lo = nullptr;      // (fragment-major, planes interleaved)
-      e = kl_launch_inc_cell(ta, s);
+      e = kl_launch_inc_cell(cell_args(l), s);
       if (e == KL_ERR_SHAPE && l > 0) return e;      // (layer 0 decides for all: the shapes are the same)
     }
     if (e == 0) return output_layer();

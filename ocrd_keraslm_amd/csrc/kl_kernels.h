@@ -267,13 +267,14 @@ struct KlIncCellArgs {
   float* pool; long slot_ld;           // [slots][2L][W] f32
   const int* slot_in; const int* slot_out;
   int h_off, c_off, x_off;             // float offsets inside a slot: this layer's h and c, the layer below's (new) h (-1: layer 0)
-  const bf16_t* UT_hi; const bf16_t* UT_lo; const bf16_t* KT_hi; const bf16_t* KT_lo;   // [4W][W]
+  const bf16_t* UF; const bf16_t* KF;  // U^T and K^T of the layer FRAGMENT-MAJOR (kl_launch_frag_major of the [4W][W] hi / lo arrays;
+                                       // hi and lo planes interleaved per block when split == 3); KF null for layer 0
   const float* T1; const int* i1; const float* T2; const int* i2; const float* bias;    // z init: T1[i1[r]] + T2[i2[r]] + bias (null: none)
 };
 int kl_launch_inc_cell(const KlIncCellArgs& a, hipStream_t stream);      // KL_ERR_SHAPE: not applicable
 
 // ---- step_tile.hip: the same for n >= KL_BIG_STEP_N, TR x 128 tiles with the operands read once (variant: timing builds, 0)
-int kl_launch_inc_tile(const KlIncCellArgs& a, int variant, hipStream_t stream);      // KL_ERR_SHAPE: not applicable; a.UT_hi / a.KT_hi = FRAGMENT-MAJOR arrays
+int kl_launch_inc_tile(const KlIncCellArgs& a, int variant, hipStream_t stream);      // KL_ERR_SHAPE: not applicable
 // output layer in one launch: probs[n][V] = softmax(h_top . E^T), h_top rows through slot_out (V <= 256, W % 128 == 0)
 int kl_launch_out_softmax(const float* pool, long slot_ld, const int* slot_out, int h_off, const bf16_t* EF, int split,
                           int n, int W, int V, float* probs, long ldp, hipStream_t stream);      // KL_ERR_SHAPE: not applicable

@@ -337,12 +337,12 @@ extern "C" int kl_test_read_inc_stamps(unsigned long long* out) {
 #endif
 
 // one LSTM cell step of layer `l` for n hypotheses with pool slots; KL_ERR_SHAPE = not applicable (the caller takes the
-// launch-per-layer kernels of lstm_step.hip).  p.UT_hi / p.KT_hi: the FRAGMENT-MAJOR arrays of the layer (planes interleaved).
+// launch-per-layer kernels of lstm_step.hip).
 int kl_launch_inc_cell(const KlIncCellArgs& p, hipStream_t stream) {
   const int W = p.W;
-  if (p.n < 1 || (W & 255) || !p.pool || !p.slot_in || !p.slot_out || !p.UT_hi) return KL_ERR_SHAPE;
+  if (p.n < 1 || (W & 255) || !p.pool || !p.slot_in || !p.slot_out || !p.UF) return KL_ERR_SHAPE;
   const bool lo = p.split == 3;
-  if (p.x_off >= 0 && !p.KT_hi) return KL_ERR_ARG;
+  if (p.x_off >= 0 && !p.KF) return KL_ERR_ARG;
   const int K = p.x_off >= 0 ? 2 * W : W;
   int nmt = p.n > 128 ? 2 : 1;
   if ((size_t)16 * nmt * K * 4 > LDS_LIMIT) nmt = 1;
@@ -352,7 +352,7 @@ int kl_launch_inc_cell(const KlIncCellArgs& p, hipStream_t stream) {
   IncCell a;
   a.n = p.n; a.W = W; a.pool = p.pool; a.slot_ld = p.slot_ld; a.slot_in = p.slot_in; a.slot_out = p.slot_out;
   a.h_off = p.h_off; a.c_off = p.c_off; a.x_off = p.x_off;
-  a.UF = p.UT_hi; a.KF = p.KT_hi;
+  a.UF = p.UF; a.KF = p.KF;
   a.T1 = p.T1; a.i1 = p.i1; a.T2 = p.T2; a.i2 = p.i2; a.bias = p.bias;
   dim3 grid(W / 16, (p.n + 16 * nmt - 1) / (16 * nmt));
 #define KL_IC_CASE(NMT_, LO_)                                                                                               \

@@ -555,19 +555,18 @@ int kl_launch_frag_major(const bf16_t* hi, const bf16_t* lo, int rows, int K, lo
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 
-// (p.UT_hi / p.KT_hi: the FRAGMENT-MAJOR arrays of the layer, hi and lo planes interleaved per block when p.split == 3)
 int kl_launch_inc_tile(const KlIncCellArgs& p, int variant, hipStream_t stream) {
   const int W = p.W;
-  if (p.n < 1 || (W & 255) || !p.pool || !p.slot_in || !p.slot_out || !p.UT_hi) return KL_ERR_SHAPE;
+  if (p.n < 1 || (W & 255) || !p.pool || !p.slot_in || !p.slot_out || !p.UF) return KL_ERR_SHAPE;
   if ((long)8 * W * W >= (1L << 31)) return KL_ERR_SHAPE;
   const bool lo = p.split == 3;
-  if (p.x_off >= 0 && !p.KT_hi) return KL_ERR_ARG;
+  if (p.x_off >= 0 && !p.KF) return KL_ERR_ARG;
   constexpr int TR = 64;
   IncTile a;
   memset(&a, 0, sizeof(a));
   a.n = p.n; a.W = W; a.pool = p.pool; a.slot_ld = p.slot_ld; a.slot_in = p.slot_in; a.slot_out = p.slot_out;
   a.h_off = p.h_off; a.c_off = p.c_off; a.x_off = p.x_off;
-  a.UF = p.UT_hi; a.KF = p.KT_hi;
+  a.UF = p.UF; a.KF = p.KF;
   a.T1 = p.T1; a.i1 = p.i1; a.T2 = p.T2; a.i2 = p.i2; a.bias = p.bias;
   a.nx = W / 32;
   a.ny = (p.n + TR - 1) / TR;
