@@ -425,6 +425,18 @@ class HipLM:
                                             stream), "kl_step_batch")
         return probs
 
+    def step_slots_heads(self, idx, ctx, slot_in, slot_out, k):
+        """step_slots plus the first k state vectors of the new states, both on the HOST after ONE synchronising copy:
+        (probs [n][V], heads [n][k][W]) as numpy arrays.  A beam search with history clustering (rating.py:887-916) needs
+        both after every character; fetched one after the other they cost two round trips to an otherwise idle GPU."""
+        torch = self.torch
+        probs = self.step_slots(idx, ctx, slot_in, slot_out)
+        so = self._i32(slot_out).reshape(-1)
+        n = probs.shape[0]
+        heads = self.pool.index_select(0, so.long())[:, :k, :self.width].reshape(n, -1)
+        both = torch.cat([probs, heads], dim=1).cpu().numpy()
+        return both[:, :self.voc_size], both[:, self.voc_size:].reshape(n, k, self.width)
+
     def to_device_i32(self, a):
         """one host-to-device transfer of an int32 array (rows stay contiguous views)"""
         return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.device, non_blocking=True)

@@ -836,14 +836,19 @@ class Rater(object):
         packed[2] = np.fromiter((r.slot for r in new), dtype=np.int32, count=n)
         packed[3:] = ctx[:, None]
         lm = self.model
+        hv = None
         if hasattr(lm, "to_device_i32"):
             dev = lm.to_device_i32(packed)
             ctx_d = dev[3] if len(ctx) == 1 else dev[3:].t().contiguous()
-            probs = _np(lm.step_slots(dev[0], ctx_d, dev[1], dev[2]))
+            if heads and hasattr(lm, "step_slots_heads"):
+                probs, hv = lm.step_slots_heads(dev[0], ctx_d, dev[1], dev[2], self.depth)      # (one copy to the host for both)
+            else:
+                probs = _np(lm.step_slots(dev[0], ctx_d, dev[1], dev[2]))
         else:
             probs = _np(lm.step_slots(packed[0], packed[3:].T.copy(), packed[1], packed[2]))
         if heads:
-            hv = _np(lm.pool_heads(packed[2], self.depth))
+            if hv is None:
+                hv = _np(lm.pool_heads(packed[2], self.depth))
             for r, v in zip(new, hv):
                 r.head = v
         return probs, new
