@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void lstm_scan_fwd_kernel(const KlScanFwd a
   static_assert(KSTEPS % KW == 0, "K split");
   constexpr int W = KSTEPS * 32;
   constexpr int NUG = W / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool kactive = wave < KW;
   const int kw = kactive ? wave : 0;       // (idle waves read wave 0's slice and discard the product)
   int id = blockIdx.x;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_kernel(const KlSca
   static_assert(KSTEPS % KW == 0, "K split");
   constexpr int W = KSTEPS * 32;
   constexpr int NUG = W / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int id = blockIdx.x;
   const int n_rg = a.n_rg, n_rb = a.n_rb, B = a.B, T = a.T;
   const int l = id / (NUG * n_rg);
@@ -403,10 +403,10 @@ __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_kernel(const KlSca
       float z[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) z[g] = zin[g] + zt[0][g][er][eu] + zt[1][g][er][eu] + zt[2][g][er][eu] + zt[3][g][er][eu];
-      const float gi = sigmoidf_(z[0]), gf = sigmoidf_(z[1]), gg = tanhf_(z[2]), go = sigmoidf_(z[3]);
+      const float gi = fast_sigmoid(z[0]), gf = fast_sigmoid(z[1]), gg = fast_tanh(z[2]), go = fast_sigmoid(z[3]);
       const float c = gf * c_reg[i] + gi * gg;
       c_reg[i] = c;
-      const float h = go * tanhf_(c);
+      const float h = go * fast_tanh(c);
       const bool row_ok = (r0 + er) < B;
       const unsigned hh = f2bf(h);
       const unsigned hl = f2bf(h - bf2f((bf16_t)hh));
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_sent_kernel(const 
   static_assert(KSTEPS % KW == 0, "K split");
   constexpr int W = KSTEPS * 32;
   constexpr int NUG = W / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int id = blockIdx.x;
   const int n_rg = a.n_rg, n_rb = a.n_rb, B = a.B, T = a.T;
   const int l = id / (NUG * n_rg);
@@ -593,10 +593,10 @@ __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_sent_kernel(const 
       for (int g = 0; g < 4; ++g)
         z[g] = zin[g] + zt[par][0][g][er][eu] + zt[par][1][g][er][eu] + zt[par][2][g][er][eu] + zt[par][3][g][er][eu];
       par ^= 1;
-      const float gi = sigmoidf_(z[0]), gf = sigmoidf_(z[1]), gg = tanhf_(z[2]), go = sigmoidf_(z[3]);
+      const float gi = fast_sigmoid(z[0]), gf = fast_sigmoid(z[1]), gg = fast_tanh(z[2]), go = fast_sigmoid(z[3]);
       const float c = gf * c_reg[i] + gi * gg;
       c_reg[i] = c;
-      float h = go * tanhf_(c);
+      float h = go * fast_tanh(c);
       // (a non-finite or out-of-range h -- broken weights -- must not look like a sentinel to the consumers: they would
       //  spin until the time-out; the f32 output keeps the value as computed)
       const float hx = (h > -1.f && h < 1.f) ? h : (h >= 1.f ? 1.f : (h <= -1.f ? -1.f : 0.f));
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_sent8_kernel(const
   static_assert(KSTEPS % KW == 0, "K split");
   constexpr int W = KSTEPS * 32;
   constexpr int NUG = W / 8;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int id = blockIdx.x;
   const int n_rg = a.n_rg, n_rb = a.n_rb, B = a.B, T = a.T;
   const int lrel = id / (NUG * n_rg);
@@ -779,10 +779,10 @@ __global__ __launch_bounds__(256, 1) void lstm_scan_fwd_split_sent8_kernel(const
         z[g] = zin[g] + zt[par][0][ct][er][cc] + zt[par][1][ct][er][cc] + zt[par][2][ct][er][cc] + zt[par][3][ct][er][cc];
       }
       par ^= 1;
-      const float gi = sigmoidf_(z[0]), gf = sigmoidf_(z[1]), gg = tanhf_(z[2]), go = sigmoidf_(z[3]);
+      const float gi = fast_sigmoid(z[0]), gf = fast_sigmoid(z[1]), gg = fast_tanh(z[2]), go = fast_sigmoid(z[3]);
       const float c = gf * c_reg[i] + gi * gg;
       c_reg[i] = c;
-      float h = go * tanhf_(c);
+      float h = go * fast_tanh(c);
       // (a non-finite or out-of-range h -- broken weights -- must not look like a sentinel to the consumers: they would
       //  spin until the time-out; the f32 output keeps the value as computed)
       const float hx = (h > -1.f && h < 1.f) ? h : (h >= 1.f ? 1.f : (h <= -1.f ? -1.f : 0.f));
@@ -816,7 +816,7 @@ template <int KSTEPS, int MAXRB, bool UP = true>
 __global__ __launch_bounds__(256, 2) void lstm_scan_bwd_kernel(const KlScanBwd a) {
   constexpr int W = KSTEPS * 32;
   constexpr int NUG = W / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int id = blockIdx.x;
   const int n_rg = a.n_rg, n_rb = a.n_rb, B = a.B, T = a.T;
   const int l = id / (NUG * n_rg);
