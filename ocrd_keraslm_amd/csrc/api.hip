@@ -49,7 +49,7 @@ struct Derived {
   std::vector<bf16_t*> UT_hi, UT_lo, KT_hi, KT_lo, Un, Kn;   // per layer (KT/Kn of layer 0 = rows [0,W) of K0)
   bf16_t *E_hi = nullptr, *E_lo = nullptr, *ET = nullptr;
   std::vector<bf16_t*> WTcat;    // [4W][3*K_l] = [hi | hi | lo] blocks, K_0 = W (U), K_l = 2W (K then U): big-n step path
-  std::vector<bf16_t*> UF, KF;   // per layer: U^T / K^T fragment-major (hi and lo planes per 16 x 32 block), step_tile.hip (W % 128 == 0)
+  std::vector<bf16_t*> UF, KF;   // per layer: U^T / K^T fragment-major (hi and lo planes per 16 x 32 block), step_tile.hip / step_small.hip (W % 32 == 0)
   bf16_t* EF = nullptr;          // the embedding likewise
   std::vector<bf16_t*> WTperm;   // WTcat with rows in (unit block of 32, gate, unit) order: fused cell epilogue (W % 32 == 0)
   bf16_t* Ecat = nullptr;        // [Vp][3W]
@@ -250,7 +250,7 @@ size_t carve_derived(const kl_handle* h, void* base, Derived* d) {
   o.Ecat = cv.take<bf16_t>(Vp * 3 * W);
   o.UF.assign(c.depth, nullptr);
   o.KF.assign(c.depth, nullptr);
-  if ((W & 127) == 0) {
+  if ((W & 31) == 0) {
     for (int l = 0; l < c.depth; ++l) {
       o.UF[l] = cv.take<bf16_t>(4 * W * W * 2);
       if (l > 0) o.KF[l] = cv.take<bf16_t>(4 * W * W * 2);
@@ -1481,6 +1481,19 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
     if (e == 0) return output_layer();
     if (e != KL_ERR_SHAPE) return e;
   }
+  // 16 hypotheses and more (the reference's callers feed at most 128 / 256 rows; also whatever the tile kernel does not take:
+  // widths 64 and 128): coalesced state rows through LDS, 16-unit workgroups (step_small.hip); KL_ERR_SHAPE, or fewer rows:
+  // the gather + GEMM path / the launch-per-layer kernels below
+  if (h->inc_small && n >= h->inc_small_min && (n < KL_BIG_STEP_N || V < 1024)) {
+    int e = d.EF ? 0 : KL_ERR_SHAPE;
+    if (e == 0 && !h->inc_ready) KL_TRY(prepare_incremental(h, s));
+    for (int l = 0; l < L && e == 0; ++l) {
+      e = kl_launch_inc_cell(cell_args(l), s);
+      if (e == KL_ERR_SHAPE && l > 0) return e;      // (layer 0 decides for all: the shapes are the same)
+    }
+    if (e == 0) return output_layer();
+    if (e != KL_ERR_SHAPE) return e;
+  }
   if (n >= KL_BIG_STEP_N && ws && ws_bytes >= kl_step_workspace_bytes(h, n)) {
     if (!h->inc_ready) KL_TRY(prepare_incremental(h, s));
     // big-tile path: gather+split -> one bf16 GEMM over the 3x contraction -> gates
@@ -1547,18 +1560,6 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
     }
     KL_TRY(kl_launch_softmax_ce(probs, V, n, V, nullptr, n, 1, 1.f, nullptr, 0, nullptr, nullptr, 0, s));
     return 0;
-  }
-  // 96..255 hypotheses (the reference's callers feed at most 128 / 256 rows): coalesced state rows through LDS, 16-unit
-  // workgroups (step_small.hip); KL_ERR_SHAPE, or fewer rows: the launch-per-layer kernels below
-  if (h->inc_small && n >= h->inc_small_min) {
-    int e = d.EF ? 0 : KL_ERR_SHAPE;
-    if (e == 0 && !h->inc_ready) KL_TRY(prepare_incremental(h, s));
-    for (int l = 0; l < L && e == 0; ++l) {
-      e = kl_launch_inc_cell(cell_args(l), s);
-      if (e == KL_ERR_SHAPE && l > 0) return e;      // (layer 0 decides for all: the shapes are the same)
-    }
-    if (e == 0) return output_layer();
-    if (e != KL_ERR_SHAPE) return e;
   }
   for (int l = 0; l < L; ++l) {
     KlFwdStep S;

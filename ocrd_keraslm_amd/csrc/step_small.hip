@@ -12,7 +12,9 @@
 //   128 hypotheses: 43.6 (round 2: four-unit thin workgroups) -> 35.8 (first cut of this kernel: 4 waves, fragments from the
 //   [4W][W] arrays) -> 29.0 (fragment-major weights) -> 24.2 (8 waves, scalar base addresses, exp2 / rcp gates; the kernel
 //   itself 10.9 -> 8.3 us per layer); 16 / 32 / 64 / 80 hypotheses 22.3 / 22.6 / 22.9 / 23.2 against 23.7 / 27.6 / 28.6 / 39.8
-//   with the thin kernels, which now only serve fewer than 16 rows and widths that are not multiples of 256.
+//   with the thin kernels, which now only serve fewer than 16 rows and widths above 1024 that are not multiples of 256.
+//   Widths 64 and 128 (the reference's README example and its published model; GEN instantiation): 27 -> 21 us per step at
+//   32 / 128 hypotheses, 1024 hypotheses 37.4 -> 19.6 us at width 128 (two row tiles per workgroup, any number of rows).
 // What the stamps say about the rest (tools/probe_inc_stamps.py): of a launch's ~11 000 (layer 0) / ~18 000 clocks, 2 500-6 000
 // pass between the request of the slot indices and their arrival, ~1 500 more until the rows are in LDS -- the chain
 // indices -> rows -> LDS -> MFMA -> exchange -> cell, every link a memory round trip, is the launch.
@@ -40,10 +42,11 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
 }
 
 // LDS image of the activation rows: plane p (0 = hi, 1 = lo), row r, K elements; 16-byte chunk c of row r sits at chunk
-// position c ^ (r & 15) of its 128-byte-aligned group of 16 chunks... (K is a multiple of 128 elements = 16 chunks)
+// position c ^ (r & 15) of its 128-byte-aligned group of 16 chunks (K a multiple of 128 elements = 16 chunks, or K = 64)
 __device__ __forceinline__ unsigned a_off(int row, int k, int K) {      // byte offset inside a plane of element k of row `row` (k % 4 == 0)
   const int chunk = k >> 3;
-  const int pos = (chunk & ~15) | ((chunk ^ row) & 15);
+  const int m = K >= 128 ? 15 : 7;                 // (K = 64: eight chunks per row, rows r and r + 8 share positions)
+  const int pos = (chunk & ~m) | ((chunk ^ row) & m);
   return (unsigned)((row * K + pos * 8 + (k & 7)) * 2);
 }
 
@@ -87,7 +90,9 @@ __device__ __forceinline__ float gate_tanh(float x) {
 // known to be uniform.  Hence: eight waves (two per SIMD, half the k-steps and half the staging each), the wave index
 // through readfirstlane so that every base address is computed on the scalar unit (loads take the SGPR-base form), no
 // division in the staging (a wave stages whole rows), hardware exp2 / rcp gates.
-template <int NMT, bool LO>
+// GEN: widths 64 and 128 (the reference's README example and its published model), K = 64, 128 or 256 -- a wave instruction of the
+// staging covers several rows, or the x and the h part of one; else W is a multiple of 256 and a wave stages whole rows.
+template <int NMT, bool LO, bool GEN>
 __global__ __launch_bounds__(512) void inc_cell_kernel(const IncCell a) {
   constexpr int ROWS = 16 * NMT, NW = 8, RPW = ROWS / NW, NPL = LO ? 2 : 1;
   const int W = a.W;
@@ -122,13 +127,19 @@ __global__ __launch_bounds__(512) void inc_cell_kernel(const IncCell a) {
       e_i2[m] = a.i2 ? a.i2[row] : row;
     }
   }
-  // the slots of this wave's RPW staging rows (uniform addresses: scalar loads)
+  // the slots of this wave's RPW staging rows (uniform addresses: scalar loads); GEN: lane r < ROWS holds the slots of row r
   int sl_in[RPW], sl_out[RPW];
+  int sl_all_in = 0, sl_all_out = 0;
+  if (GEN) {
+    const int row = min(r0 + (lane < ROWS ? lane : 0), a.n - 1);
+    sl_all_in = a.slot_in[row];
+    sl_all_out = a.slot_out[row];
+  }
 #pragma unroll
   for (int rr = 0; rr < RPW; ++rr) {
     const int row = min(r0 + wave * RPW + rr, a.n - 1);
-    sl_in[rr] = a.slot_in[row];
-    sl_out[rr] = a.slot_out[row];
+    sl_in[rr] = GEN ? 0 : a.slot_in[row];
+    sl_out[rr] = GEN ? 0 : a.slot_out[row];
   }
 
   const int nks = K >> 5, nks_x = Kx >> 5;         // k-steps of 32; the first nks_x belong to x . K
@@ -163,10 +174,12 @@ __global__ __launch_bounds__(512) void inc_cell_kernel(const IncCell a) {
   // ---- activation rows: wave w stages rows RPW w .. RPW w + RPW - 1, whole rows (a wave instruction = 256 consecutive floats
   // of one row: K / 256 pieces per lane and row), split, into LDS; AP pieces per thread and round
   constexpr int AP = 8;
-  const int cpr = K >> 8;
-  const int npc = RPW * cpr;
+  const int cpr = GEN ? 1 : K >> 8;
   const bool cpr_pow2 = (cpr & (cpr - 1)) == 0;
   const int cshift = __builtin_ctz(cpr);
+  // GEN: the workgroup's ROWS x K floats as one run of 256-float pieces, piece p to wave p % 8; lane: row = e / K, k = e % K
+  const int kshift = __builtin_ctz(K);
+  const int npc = GEN ? ((ROWS * K >> 8) - wave + NW - 1) / NW : RPW * cpr;
   float4 av[AP];
   auto piece = [&](int p, int& rr, int& c) __attribute__((always_inline)) {
     rr = cpr_pow2 ? p >> cshift : p / cpr;
@@ -182,12 +195,20 @@ __global__ __launch_bounds__(512) void inc_cell_kernel(const IncCell a) {
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       if (p0 + i < npc) {
-        int rr, c;
-        piece(p0 + i, rr, c);
-        const int so = pick(sl_out, rr), si = pick(sl_in, rr);
-        const int k0 = c * 256;                    // (W is a multiple of 256: a piece lies in x or in h)
-        const float* src = k0 < Kx ? a.pool + (long)so * a.slot_ld + a.x_off + k0 : a.pool + (long)si * a.slot_ld + a.h_off + (k0 - Kx);
-        av[i] = *reinterpret_cast<const float4*>(src + lane * 4);
+        if (GEN) {
+          const int e = (wave + NW * (p0 + i)) * 256 + lane * 4;
+          const int row = e >> kshift, k = e & (K - 1);
+          const int so = __shfl(sl_all_out, row), si = __shfl(sl_all_in, row);
+          const float* src = k < Kx ? a.pool + (long)so * a.slot_ld + a.x_off + k : a.pool + (long)si * a.slot_ld + a.h_off + (k - Kx);
+          av[i] = *reinterpret_cast<const float4*>(src);
+        } else {
+          int rr, c;
+          piece(p0 + i, rr, c);
+          const int so = pick(sl_out, rr), si = pick(sl_in, rr);
+          const int k0 = c * 256;                    // (W is a multiple of 256: a piece lies in x or in h)
+          const float* src = k0 < Kx ? a.pool + (long)so * a.slot_ld + a.x_off + k0 : a.pool + (long)si * a.slot_ld + a.h_off + (k0 - Kx);
+          av[i] = *reinterpret_cast<const float4*>(src + lane * 4);
+        }
       }
     }
   };
@@ -195,11 +216,17 @@ __global__ __launch_bounds__(512) void inc_cell_kernel(const IncCell a) {
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       if (p0 + i < npc) {
-        int rr, c;
-        piece(p0 + i, rr, c);
         uint2 hi, lo;
         split4<LO>(av[i], hi, lo);
-        const unsigned off = a_off(wave * RPW + rr, c * 256 + lane * 4, K);
+        unsigned off;
+        if (GEN) {
+          const int e = (wave + NW * (p0 + i)) * 256 + lane * 4;
+          off = a_off(e >> kshift, e & (K - 1), K);
+        } else {
+          int rr, c;
+          piece(p0 + i, rr, c);
+          off = a_off(wave * RPW + rr, c * 256 + lane * 4, K);
+        }
         *reinterpret_cast<uint2*>(plane_hi + off) = hi;
         if (LO) *reinterpret_cast<uint2*>(plane_lo + off) = lo;
       }
@@ -340,10 +367,11 @@ extern "C" int kl_test_read_inc_stamps(unsigned long long* out) {
 // launch-per-layer kernels of lstm_step.hip).
 int kl_launch_inc_cell(const KlIncCellArgs& p, hipStream_t stream) {
   const int W = p.W;
-  if (p.n < 1 || (W & 255) || !p.pool || !p.slot_in || !p.slot_out || !p.UF) return KL_ERR_SHAPE;
+  if (p.n < 1 || ((W & 255) && W != 64 && W != 128) || !p.pool || !p.slot_in || !p.slot_out || !p.UF) return KL_ERR_SHAPE;
   const bool lo = p.split == 3;
   if (p.x_off >= 0 && !p.KF) return KL_ERR_ARG;
   const int K = p.x_off >= 0 ? 2 * W : W;
+  const bool gen = (W & 255) != 0;                 // widths 64 and 128: K = 64, 128 or 256, a staging piece spans rows or x and h
   int nmt = p.n > 128 ? 2 : 1;
   if ((size_t)16 * nmt * K * 4 > LDS_LIMIT) nmt = 1;
   size_t lds = (size_t)16 * nmt * K * 4;
@@ -355,14 +383,16 @@ int kl_launch_inc_cell(const KlIncCellArgs& p, hipStream_t stream) {
   a.UF = p.UF; a.KF = p.KF;
   a.T1 = p.T1; a.i1 = p.i1; a.T2 = p.T2; a.i2 = p.i2; a.bias = p.bias;
   dim3 grid(W / 16, (p.n + 16 * nmt - 1) / (16 * nmt));
-#define KL_IC_CASE(NMT_, LO_)                                                                                               \
+#define KL_IC_CASE(NMT_, LO_, GEN_)                                                                                         \
   do {                                                                                                                      \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&inc_cell_kernel<NMT_, LO_>),                                    \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&inc_cell_kernel<NMT_, LO_, GEN_>),                              \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;     \
-    hipLaunchKernelGGL((inc_cell_kernel<NMT_, LO_>), grid, dim3(512), lds, stream, a);                                      \
+    hipLaunchKernelGGL((inc_cell_kernel<NMT_, LO_, GEN_>), grid, dim3(512), lds, stream, a);                                \
   } while (0)
-  if (nmt == 2) { if (lo) KL_IC_CASE(2, true); else KL_IC_CASE(2, false); }
-  else { if (lo) KL_IC_CASE(1, true); else KL_IC_CASE(1, false); }
+#define KL_IC_CASE2(NMT_, LO_) do { if (gen) KL_IC_CASE(NMT_, LO_, true); else KL_IC_CASE(NMT_, LO_, false); } while (0)
+  if (nmt == 2) { if (lo) KL_IC_CASE2(2, true); else KL_IC_CASE2(2, false); }
+  else { if (lo) KL_IC_CASE2(1, true); else KL_IC_CASE2(1, false); }
+#undef KL_IC_CASE2
 #undef KL_IC_CASE
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }

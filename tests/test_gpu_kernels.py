@@ -144,9 +144,11 @@ def make_model(depth, width, voc, n_ctx=1, seed=4, emb_std=0.5):
 
 @pytest.mark.parametrize("depth,width,voc,n,n_ctx", [(2, 64, 50, 5, 1), (2, 512, 256, 70, 1), (1, 128, 40, 33, 1),
                                                      (3, 96, 30, 17, 2),
-                                                     # 96 <= n < 256: 16-unit workgroups, state rows through LDS (step_small.hip), one / two row tiles,
+                                                     # 16 <= n < 256: 16-unit workgroups, state rows through LDS (step_small.hip), one / two row tiles,
                                                      # K = W and 2W, two weight groups per wave at width 1024, several context variables
                                                      (2, 512, 256, 128, 1), (2, 512, 256, 200, 1), (3, 256, 40, 100, 2), (4, 1024, 64, 130, 2),
+                                                     # ... widths 64 and 128 (K = 64 / 128: a staging instruction covers several rows), few and many rows
+                                                     (2, 64, 50, 40, 1), (2, 64, 50, 300, 0), (2, 128, 60, 128, 1), (3, 128, 60, 520, 2),
                                                      (1, 512, 64, 97, 0),
                                                      # n >= 256: big-tile path (step_big.hip)
                                                      (2, 512, 256, 300, 1), (3, 96, 30, 260, 2), (1, 128, 40, 257, 1),
