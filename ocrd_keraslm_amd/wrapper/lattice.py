@@ -88,16 +88,15 @@ def filter_choices(textequivs):
 
 
 def repair_tokenisation(tokenisation, concatenation, next_token, logger=None):
-    """True if the parent's own text (`tokenisation`) continues the text concatenated so far
-    directly with `next_token`, i.e. without the white space the hierarchy implies (rate.py:646-660)."""
-    overlap = 0
-    for overlap in range(min(len(tokenisation), len(concatenation)), -1, -1):
-        if concatenation[-overlap:] == tokenisation[:overlap]:
-            break
-    if overlap > 0 and tokenisation[overlap:].startswith(next_token):
+    """Does the parent's own text (`tokenisation`) continue the text concatenated so far directly with
+    `next_token`, i.e. without the white space the hierarchy implies (rate.py:646-660)?  The two texts are
+    aligned on the longest prefix of `tokenisation` that `concatenation` ends with."""
+    longest = min(len(tokenisation), len(concatenation))
+    overlap = next((k for k in range(longest, 0, -1) if concatenation.endswith(tokenisation[:k])), 0)
+    joined = overlap > 0 and tokenisation.startswith(next_token, overlap)
+    if joined:
         (logger or _LOG).warning('Repairing tokenisation between "%s" and "%s"', concatenation[-overlap:], next_token)
-        return True
-    return False
+    return joined
 
 
 def lattice_edges(graph, start_node):
@@ -207,19 +206,18 @@ def page_get_linear_graph_at(level, pcgts, problems=None, textequiv_factory=None
 
 def page_update_from_path(level, path, entropy, logger=None):
     """Write a decoded path back: every real element keeps only its chosen TextEquiv with the combined
-    score as confidence; logs average probability and perplexities (rate.py:425-440)."""
-    strlen = 0
-    for element, textequiv, score in path:
-        if element:
-            element.set_TextEquiv([textequiv])
-            strlen += len(textequiv.Unicode)
-            textequiv.set_conf(score)
-        else:
-            strlen += 1     # white-space pseudo element
-    if not strlen:
+    score as confidence; logs average probability and perplexities (rate.py:425-440).  `path` is a list of
+    (element or None for white space, TextEquiv, score)."""
+    chosen = [step for step in path if step[0]]
+    for element, textequiv, score in chosen:
+        element.set_TextEquiv([textequiv])
+        textequiv.set_conf(score)
+    n_chars = sum(len(textequiv.Unicode) for _element, textequiv, _score in chosen) + (len(path) - len(chosen))
+    if not n_chars:
         return None
-    ent = entropy / strlen
-    stats = (pow(2.0, -ent), pow(2.0, ent), pow(2.0, ent * strlen / len(path)))
+    bits_per_char = entropy / n_chars
+    bits_per_step = entropy / len(path)      # per TextEquiv at `level`, white space included (a character need not be a glyph)
+    stats = (2.0 ** -bits_per_char, 2.0 ** bits_per_char, 2.0 ** bits_per_step)
     (logger or _LOG).info("avg: %.3f, char ppl: %.3f, %s ppl: %.3f", stats[0], stats[1], level, stats[2])
     return stats
 

@@ -136,74 +136,124 @@ class KerasRate(Processor):
         return PendingPage(traceback=traceback, pcgts=pcgts, file_id=file_id, page_id=page_id)
 
     def process_workspace_stateful(self, workspace: Workspace) -> None:
-        """sequential page loop honouring OCRD_EXISTING_OUTPUT / OCRD_MISSING_OUTPUT (rate.py:133-246)"""
+        """Decode the pages of a workspace in document order with one beam search (rate.py:133-246): a page's final path
+        is fixed -- and its file written -- while the NEXT page is searched, the last one when the inputs are exhausted.
+        Three separate concerns, each in its own unit: which inputs can be decoded at all (`_decodable_inputs`), what a
+        failure on a page means under OCRD_MISSING_OUTPUT / OCRD_MAX_MISSING_OUTPUTS (`_PageTally`), and the search itself."""
         log = self._base_logger
         with pushd_popd(workspace.directory):
             self.workspace = workspace
             self.verify()
-            reason = {'SKIP': "skipped", 'COPY': "fallback-copied"}.get(config.OCRD_MISSING_OUTPUT, "aborted")
-            succeeded, failed, causes = 0, 0, defaultdict(int)
-            input_files = list(self.input_files)
-            prev = None
-            for input_file in input_files:
-                page_id = input_file.pageId
-                log.info("preparing page %s", page_id)
-                if self.download:
-                    try:
-                        input_file = self.workspace.download_file(input_file)
-                    except Exception as err:     # ValueError, FileNotFoundError, HTTP errors
-                        log.error(repr(err))
-                        log.warning("failed downloading file %s for page %s", input_file, page_id)
-                if input_file.local_filename is None:
-                    log.debug("ignoring missing file for page %s", page_id)
-                    continue
-                log.info("processing page %s", page_id)
+            inputs = list(self.input_files)
+            tally = _PageTally(len(inputs), log)
+            pending = None
+            for job in self._decodable_inputs(inputs, log):
                 try:
-                    pcgts = page_from_file(input_file)
-                    assert isinstance(pcgts, OcrdPage)
-                except ValueError as err:
-                    log.error("non-PAGE input for page %s: %s", page_id, err)
-                    continue
-                output_file_id = make_file_id(input_file, self.output_file_grp)
-                if input_file.fileGrp == self.output_file_grp:
-                    output_file_id = input_file.ID
-                existing = next(self.workspace.mets.find_files(ID=output_file_id), None)
-                if existing and config.OCRD_EXISTING_OUTPUT != 'OVERWRITE':
-                    log.error("A file with ID==%s already exists %s and neither force nor ignore are set",
-                              output_file_id, existing)
-                    continue
-                try:
-                    prev = self.process_page_pcgts_stateful(pcgts, prev, output_file_id, page_id)
-                    succeeded += 1
+                    pending = self.process_page_pcgts_stateful(job.pcgts, pending, job.output_id, job.page_id)
                 except FileExistsError as err:
+                    # an output that exists is the caller's decision, not a failure of the page
                     if config.OCRD_EXISTING_OUTPUT == 'ABORT':
-                        raise err
+                        raise
                     if config.OCRD_EXISTING_OUTPUT == 'OVERWRITE':
                         raise Exception("got %s despite OCRD_EXISTING_OUTPUT==OVERWRITE" % err)
                 except KeyboardInterrupt:
                     raise
                 except Exception as err:
-                    what = str(err) or err.__class__.__name__
-                    if config.OCRD_MISSING_OUTPUT == 'ABORT':
-                        log.error("Failure on page %s: %s", page_id, what)
-                        raise err
-                    log.exception("Failure on page %s: %s", page_id, what)
-                    if config.OCRD_MISSING_OUTPUT == 'COPY':
-                        self._copy_page_file(input_file)
-                    elif config.OCRD_MISSING_OUTPUT != 'SKIP':
-                        raise ValueError("unknown configuration value %s for OCRD_MISSING_OUTPUT" % config.OCRD_MISSING_OUTPUT)
-                    causes[err.__class__.__name__] += 1
-                    failed += 1
-                    if 0 < config.OCRD_MAX_MISSING_OUTPUTS < failed / len(input_files):
-                        raise Exception("too many failures with %s output (%d of %d, %s)" %
-                                        (reason, failed, failed + succeeded, str(dict(causes))))
-            if prev:
-                # end of the document: lock into the best path of the last page
-                path, entropy, _ = self.rater.next_path(prev.traceback[0], ([], prev.traceback[1]))
-                self._finish(prev, path, entropy)
-            total = succeeded + failed
-            if failed:
-                if 0 < config.OCRD_MAX_MISSING_OUTPUTS < failed / total:
-                    raise Exception("too many failures with %s output (%d of %d, %s)" % (reason, failed, total, str(dict(causes))))
-                log.warning("%s %d of %d pages due to %s", reason, failed, total, str(dict(causes)))
-            log.debug("succeeded %d, missed %d of %d pages due to %s", succeeded, failed, total, str(dict(causes)))
+                    if tally.failure(job.page_id, err) == 'COPY':
+                        self._copy_page_file(job.input_file)
+                    tally.check_limit(len(inputs))
+                else:
+                    tally.success()
+            if pending:
+                # end of the document: nothing follows that could still change the last page's path
+                beam, last_node = pending.traceback
+                path, entropy, _ = self.rater.next_path(beam, ([], last_node))
+                self._finish(pending, path, entropy)
+            tally.report()
+
+    def _decodable_inputs(self, inputs, log):
+        """the inputs a page search can start from, in order: present locally (downloaded if allowed), PAGE-XML, and with
+        an output ID that is free or may be overwritten; everything else is logged and passed over (rate.py:150-183)"""
+        for input_file in inputs:
+            page_id = input_file.pageId
+            log.info("preparing page %s", page_id)
+            if self.download:
+                try:
+                    input_file = self.workspace.download_file(input_file)
+                except Exception as err:     # ValueError, FileNotFoundError, HTTP errors
+                    log.error(repr(err))
+                    log.warning("failed downloading file %s for page %s", input_file, page_id)
+            if input_file.local_filename is None:
+                log.debug("ignoring missing file for page %s", page_id)
+                continue
+            log.info("processing page %s", page_id)
+            try:
+                pcgts = page_from_file(input_file)
+                assert isinstance(pcgts, OcrdPage)
+            except ValueError as err:
+                log.error("non-PAGE input for page %s: %s", page_id, err)
+                continue
+            same_group = input_file.fileGrp == self.output_file_grp
+            output_id = input_file.ID if same_group else make_file_id(input_file, self.output_file_grp)
+            taken = next(self.workspace.mets.find_files(ID=output_id), None)
+            if taken and config.OCRD_EXISTING_OUTPUT != 'OVERWRITE':
+                log.error("A file with ID==%s already exists %s and neither force nor ignore are set", output_id, taken)
+                continue
+            yield _PageJob(input_file, pcgts, output_id, page_id)
+
+
+@dataclass
+class _PageJob:
+    input_file: Any
+    pcgts: OcrdPage
+    output_id: str
+    page_id: str
+
+
+class _PageTally:
+    """what happened to the pages, and what OCRD_MISSING_OUTPUT / OCRD_MAX_MISSING_OUTPUTS make of the failures
+    (the accounting of ocrd.Processor.process_workspace_handle_tasks, which the sequential loop cannot use)"""
+
+    WORDING = {'SKIP': "skipped", 'COPY': "fallback-copied"}
+
+    def __init__(self, n_inputs, log):
+        self.n_inputs, self.log = n_inputs, log
+        self.good, self.bad, self.causes = 0, 0, defaultdict(int)
+
+    def success(self):
+        self.good += 1
+
+    def failure(self, page_id, err):
+        """log and count a failed page; returns the policy that applies ('SKIP' or 'COPY'); re-raises under 'ABORT'"""
+        policy = config.OCRD_MISSING_OUTPUT
+        what = str(err) or err.__class__.__name__
+        if policy == 'ABORT':
+            self.log.error("Failure on page %s: %s", page_id, what)
+            raise err
+        self.log.exception("Failure on page %s: %s", page_id, what)
+        if policy not in self.WORDING:
+            raise ValueError("unknown configuration value %s for OCRD_MISSING_OUTPUT" % policy)
+        self.causes[err.__class__.__name__] += 1
+        self.bad += 1
+        return policy
+
+    def _too_many(self, of):
+        return 0 < config.OCRD_MAX_MISSING_OUTPUTS < self.bad / of
+
+    def _complaint(self):
+        return "too many failures with %s output (%d of %d, %s)" % (
+            self.WORDING.get(config.OCRD_MISSING_OUTPUT, "aborted"), self.bad, self.bad + self.good, str(dict(self.causes)))
+
+    def check_limit(self, of):
+        """stop early once the share of failed pages among all inputs is beyond repair"""
+        if self._too_many(of):
+            raise Exception(self._complaint())
+
+    def report(self):
+        total = self.good + self.bad
+        causes = str(dict(self.causes))
+        if self.bad:
+            if self._too_many(total):
+                raise Exception(self._complaint())
+            self.log.warning("%s %d of %d pages due to %s", self.WORDING.get(config.OCRD_MISSING_OUTPUT, "aborted"), self.bad, total, causes)
+        self.log.debug("succeeded %d, missed %d of %d pages due to %s", self.good, self.bad, total, causes)
