@@ -385,8 +385,12 @@ int kl_launch_inc_cell(const KlIncCellArgs& p, hipStream_t stream) {
   dim3 grid(W / 16, (p.n + 16 * nmt - 1) / (16 * nmt));
 #define KL_IC_CASE(NMT_, LO_, GEN_)                                                                                         \
   do {                                                                                                                      \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&inc_cell_kernel<NMT_, LO_, GEN_>),                              \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;     \
+    static size_t granted = 0;      /* (per instantiation: the attribute is set when a launch needs more than any before) */ \
+    if (lds > granted) {                                                                                                    \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&inc_cell_kernel<NMT_, LO_, GEN_>),                            \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;   \
+      granted = lds;                                                                                                        \
+    }                                                                                                                       \
     hipLaunchKernelGGL((inc_cell_kernel<NMT_, LO_, GEN_>), grid, dim3(512), lds, stream, a);                                \
   } while (0)
 #define KL_IC_CASE2(NMT_, LO_) do { if (gen) KL_IC_CASE(NMT_, LO_, true); else KL_IC_CASE(NMT_, LO_, false); } while (0)
