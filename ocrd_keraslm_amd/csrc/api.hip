@@ -135,6 +135,7 @@ struct kl_handle {
   bool fused_step = true;       // incremental step, n >= 256: cell fused into the GEMM epilogue (KL_FUSED_STEP=0: separate kernels)
   bool inc_tile = true;         // incremental step, n >= 256: step_tile.hip's one launch per layer (KL_INC_TILE=0: gather + [hi|lo|hi] GEMM)
   int tile_var = 0;             // KL_TILE_VAR: timing variants of inc_tile_kernel (never in production)
+  int tile_rows = -1;           // KL_TILE_ROWS=64|128: rows per tile of inc_tile_kernel (default: by size)
   bool out_fused = true;        // incremental step: logits + softmax in one launch (KL_OUT_FUSED=0: thin GEMM + softmax kernel)
   int out_fused_min = 512;      // ... from this many hypotheses on (KL_OUT_FUSED_MIN; width 512: 128 rows 25.7 us per step against 24.2, 256 rows 35.8 / 35.1, 1024 rows 41.3 / 43.5)
   int inc_small_min = KL_SMALL_STEP_N;      // step_small.hip's kernel from this many hypotheses on (KL_INC_SMALL_MIN)
@@ -945,6 +946,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   h->inc_tile = !(env6k && env6k[0] == '0');
   const char* env6l = getenv("KL_TILE_VAR");
   h->tile_var = env6l ? atoi(env6l) : 0;
+  const char* env6r = getenv("KL_TILE_ROWS");
+  if (env6r) h->tile_rows = atoi(env6r);
   const char* env6m = getenv("KL_OUT_FUSED");
   h->out_fused = !(env6m && env6m[0] == '0');
   const char* env6n = getenv("KL_OUT_FUSED_MIN");
@@ -1475,7 +1478,7 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
     if (!h->inc_ready) KL_TRY(prepare_incremental(h, s));
     int e = 0;
     for (int l = 0; l < L && e == 0; ++l) {
-      e = kl_launch_inc_tile(cell_args(l), h->tile_var, s);
+      e = kl_launch_inc_tile(cell_args(l), h->tile_var, s, h->tile_rows);
       if (e == KL_ERR_SHAPE && l > 0) return e;      // (layer 0 decides for all: the shapes are the same)
     }
     if (e == 0) return output_layer();

@@ -274,7 +274,7 @@ struct KlIncCellArgs {
 int kl_launch_inc_cell(const KlIncCellArgs& a, hipStream_t stream);      // KL_ERR_SHAPE: not applicable
 
 // ---- step_tile.hip: the same for n >= KL_BIG_STEP_N, TR x 128 tiles with the operands read once (variant: timing builds, 0)
-int kl_launch_inc_tile(const KlIncCellArgs& a, int variant, hipStream_t stream);      // KL_ERR_SHAPE: not applicable
+int kl_launch_inc_tile(const KlIncCellArgs& a, int variant, hipStream_t stream, int rows = -1);      // KL_ERR_SHAPE: not applicable; rows: 64 / 128 per tile, -1 = by size
 // output layer in one launch: probs[n][V] = softmax(h_top . E^T), h_top rows through slot_out (V <= 256, W % 128 == 0)
 int kl_launch_out_softmax(const float* pool, long slot_ld, const int* slot_out, int h_off, const bf16_t* EF, int split,
                           int n, int W, int V, float* probs, long ldp, hipStream_t stream);      // KL_ERR_SHAPE: not applicable

@@ -94,7 +94,10 @@ __global__ __launch_bounds__(512, 1) void inc_tile_kernel(const IncTile a) {
   constexpr int NPL = LO ? 2 : 1;
   constexpr int A_PLANE = TR * 128;
   constexpr int STAGE = NPL * A_PLANE;
-  static_assert(TR == 64, "the epilogue's thread = (row, four units) map takes 64 rows");
+  constexpr int EP = TR / 64;                         // epilogue passes: thread = (row p * 64 + tid / 8, four units)
+  constexpr bool EARLY = TR == 64;                    // the epilogue's inputs requested before the main loop (TR = 128: behind it --
+                                                      // 8 row fragments and their accumulators leave no registers to park them in)
+  static_assert(TR == 64 || TR == 128, "tile rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,8 +128,8 @@ __global__ __launch_bounds__(512, 1) void inc_tile_kernel(const IncTile a) {
   // 2 500 - 6 000 clocks from request to arrival that way.)
   __shared__ int idx_lds[4][TR];
   int i_si = 0, i_so = 0, i_1 = 0, i_2 = 0;
-  if (wave == 0) {
-    const int row = min(m0 + lane, a.n - 1);
+  if (wave < TR / 64) {
+    const int row = min(m0 + wave * 64 + lane, a.n - 1);
     i_si = a.slot_in[row];
     i_so = a.slot_out[row];
     i_1 = a.i1 ? a.i1[row] : row;
@@ -188,12 +191,12 @@ __global__ __launch_bounds__(512, 1) void inc_tile_kernel(const IncTile a) {
     load_b(b2, 2);
     load_b(b3, 3);
   }
-  if (wave == 0) {
+  if (wave < TR / 64) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(run_main ? 4 * 2 * NPL : 0) : "memory");
-    idx_lds[0][lane] = i_si;
-    idx_lds[1][lane] = i_so;
-    idx_lds[2][lane] = i_1;
-    idx_lds[3][lane] = i_2;
+    idx_lds[0][wave * 64 + lane] = i_si;
+    idx_lds[1][wave * 64 + lane] = i_so;
+    idx_lds[2][wave * 64 + lane] = i_1;
+    idx_lds[3][wave * 64 + lane] = i_2;
   }
   wg_barrier();
   // A piece j: row j * 32 + tid / 16, floats 4 * (tid % 16) .. + 3 of the k-step; epilogue cells: row tid / 8, units u0 + 4 * (tid % 8) .. + 3
@@ -205,31 +208,39 @@ __global__ __launch_bounds__(512, 1) void inc_tile_kernel(const IncTile a) {
     ax[j] = a.pool + (long)idx_lds[1][lr] * a.slot_ld + (a.x_off >= 0 ? a.x_off : 0) + (tid & 15) * 4;
     ah[j] = a.pool + (long)idx_lds[0][lr] * a.slot_ld + a.h_off + (tid & 15) * 4 - Kx;
   }
-  const int e_si = idx_lds[0][tid >> 3], e_out = idx_lds[1][tid >> 3], e_i1 = idx_lds[2][tid >> 3], e_i2 = idx_lds[3][tid >> 3];
   if (run_main) {
     load_a(a0, 0);
     load_a(a1, 1);
   }
 
-  // ---- epilogue inputs: requested now, used after the loop (whole groups under uniform branches: no wait in between)
+  // ---- epilogue inputs (whole groups under uniform branches: no wait in between); EARLY: requested now, used after the loop
   const int eu = u0 + 4 * (tid & 7);
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  const f32x4 ecp = *reinterpret_cast<const f32x4*>(a.pool + (long)e_si * a.slot_ld + a.c_off + eu);
-  f32x4 et1[4], et2[4], eb[4];
+  f32x4 ecp[EP], et1[EP][4], et2[EP][4], eb[4];
+  auto epi_load = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int g = 0; g < 4; ++g) eb[g] = et1[g] = et2[g] = zero4;
-  if (a.bias) {
+    for (int g = 0; g < 4; ++g) eb[g] = zero4;
+    if (a.bias) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) eb[g] = *reinterpret_cast<const f32x4*>(a.bias + g * W + eu);
-  }
-  if (a.T1) {
+      for (int g = 0; g < 4; ++g) eb[g] = *reinterpret_cast<const f32x4*>(a.bias + g * W + eu);
+    }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) et1[g] = *reinterpret_cast<const f32x4*>(a.T1 + (long)e_i1 * 4 * W + g * W + eu);
-  }
-  if (a.T2) {
+    for (int p = 0; p < EP; ++p) {
+      const int lr = p * 64 + (tid >> 3);
+      ecp[p] = *reinterpret_cast<const f32x4*>(a.pool + (long)idx_lds[0][lr] * a.slot_ld + a.c_off + eu);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) et2[g] = *reinterpret_cast<const f32x4*>(a.T2 + (long)e_i2 * 4 * W + g * W + eu);
-  }
+      for (int g = 0; g < 4; ++g) et1[p][g] = et2[p][g] = zero4;
+      if (a.T1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) et1[p][g] = *reinterpret_cast<const f32x4*>(a.T1 + (long)idx_lds[2][lr] * 4 * W + g * W + eu);
+      }
+      if (a.T2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) et2[p][g] = *reinterpret_cast<const f32x4*>(a.T2 + (long)idx_lds[3][lr] * 4 * W + g * W + eu);
+      }
+    }
+  };
+  if (EARLY) epi_load();
 
   f32x4 acc[RF];
 #pragma unroll
@@ -237,23 +248,28 @@ __global__ __launch_bounds__(512, 1) void inc_tile_kernel(const IncTile a) {
 
   auto contract = [&](int stage, const BRegs& b) __attribute__((always_inline)) {
     const unsigned char* const a_hi = smem + stage * STAGE;
+    constexpr int RH = RF > 4 ? 4 : RF;               // row fragments in registers at a time
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      frag16 fah[RF], fal[RF], fbh, fbl;
+      frag16 fbh, fbl;
       fbh.u = b.h[s];
       if (LO) fbl.u = b.l[s];
 #pragma unroll
-      for (int i = 0; i < RF; ++i) {
-        const int off = pl_off(i * 16 + fr, s * 4 + fq);
-        fah[i].u = *reinterpret_cast<const uint4*>(a_hi + off);
-        if (LO) fal[i].u = *reinterpret_cast<const uint4*>(a_hi + A_PLANE + off);
-      }
+      for (int i0 = 0; i0 < RF; i0 += RH) {
+        frag16 fah[RH], fal[RH];
 #pragma unroll
-      for (int i = 0; i < RF; ++i) {
-        acc[i] = mfma16(fah[i].v, fbh.v, acc[i]);
-        if (LO) {
-          acc[i] = mfma16(fal[i].v, fbh.v, acc[i]);
-          acc[i] = mfma16(fah[i].v, fbl.v, acc[i]);
+        for (int i = 0; i < RH; ++i) {
+          const int off = pl_off((i0 + i) * 16 + fr, s * 4 + fq);
+          fah[i].u = *reinterpret_cast<const uint4*>(a_hi + off);
+          if (LO) fal[i].u = *reinterpret_cast<const uint4*>(a_hi + A_PLANE + off);
+        }
+#pragma unroll
+        for (int i = 0; i < RH; ++i) {
+          acc[i0 + i] = mfma16(fah[i].v, fbh.v, acc[i0 + i]);
+          if (LO) {
+            acc[i0 + i] = mfma16(fal[i].v, fbh.v, acc[i0 + i]);
+            acc[i0 + i] = mfma16(fah[i].v, fbl.v, acc[i0 + i]);
+          }
         }
       }
     }
@@ -312,24 +328,27 @@ __global__ __launch_bounds__(512, 1) void inc_tile_kernel(const IncTile a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) ct[(i * 16 + fq * 4 + r) * LDP + wave * 16 + fr] = acc[i][r];
   wg_barrier();
-  if (m0 + (tid >> 3) < a.n) {
+  if (!EARLY) epi_load();
+#pragma unroll
+  for (int p = 0; p < EP; ++p) {
+    const int lr = p * 64 + (tid >> 3);
+    if (m0 + lr >= a.n) continue;
     f32x4 z[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      z[g] = *reinterpret_cast<const f32x4*>(ct + (tid >> 3) * LDP + g * 32 + 4 * (tid & 7)) + eb[g] + et1[g] + et2[g];
+      z[g] = *reinterpret_cast<const f32x4*>(ct + lr * LDP + g * 32 + 4 * (tid & 7)) + eb[g] + et1[p][g] + et2[p][g];
     f32x4 c, hv;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float gi = gate_sigmoid(z[0][k]), gf = gate_sigmoid(z[1][k]), gg = gate_tanh(z[2][k]), go = gate_sigmoid(z[3][k]);
-      c[k] = gf * ecp[k] + gi * gg;
+      c[k] = gf * ecp[p][k] + gi * gg;
       hv[k] = go * gate_tanh(c[k]);
     }
-    float* out = a.pool + (long)e_out * a.slot_ld;
+    float* out = a.pool + (long)idx_lds[1][lr] * a.slot_ld;
     *reinterpret_cast<f32x4*>(out + a.c_off + eu) = c;
     *reinterpret_cast<f32x4*>(out + a.h_off + eu) = hv;
   }
 }
-
 
 // ---------------------------------------------------------------- output layer: logits over the tied embedding + softmax
 // One launch instead of a thin GEMM and a softmax kernel: a workgroup = 16 hypotheses x all characters (V <= 256), so that a
@@ -555,13 +574,10 @@ int kl_launch_frag_major(const bf16_t* hi, const bf16_t* lo, int rows, int K, lo
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 
-int kl_launch_inc_tile(const KlIncCellArgs& p, int variant, hipStream_t stream) {
+template <int TR>
+static int launch_inc_tile(const KlIncCellArgs& p, int variant, hipStream_t stream) {
   const int W = p.W;
-  if (p.n < 1 || (W & 255) || !p.pool || !p.slot_in || !p.slot_out || !p.UF) return KL_ERR_SHAPE;
-  if ((long)8 * W * W >= (1L << 31)) return KL_ERR_SHAPE;
   const bool lo = p.split == 3;
-  if (p.x_off >= 0 && !p.KF) return KL_ERR_ARG;
-  constexpr int TR = 64;
   IncTile a;
   memset(&a, 0, sizeof(a));
   a.n = p.n; a.W = W; a.pool = p.pool; a.slot_ld = p.slot_ld; a.slot_in = p.slot_in; a.slot_out = p.slot_out;
@@ -599,6 +615,19 @@ int kl_launch_inc_tile(const KlIncCellArgs& p, int variant, hipStream_t stream) 
   else KL_IT_CASE(true, 0);
 #undef KL_IT_CASE
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+// one LSTM cell step of a layer for n hypotheses with pool slots; KL_ERR_SHAPE = not applicable (the caller takes
+// step_small.hip's kernel or step_big.hip's gather + GEMM path).  Tiles of 128 rows once 64-row tiles would be two or more
+// per CU (width 1024 from 512 hypotheses, width 512 from 2048): a unit block's weights are then read by half as many tiles
+// -- the launches run at the L2's rate, so the bytes are the time.  (rows = -1: by that rule; KL_TILE_ROWS forces 64 / 128.)
+int kl_launch_inc_tile(const KlIncCellArgs& p, int variant, hipStream_t stream, int rows) {
+  const int W = p.W;
+  if (p.n < 1 || (W & 255) || !p.pool || !p.slot_in || !p.slot_out || !p.UF) return KL_ERR_SHAPE;
+  if ((long)8 * W * W >= (1L << 31)) return KL_ERR_SHAPE;
+  if (p.x_off >= 0 && !p.KF) return KL_ERR_ARG;
+  if (rows != 64 && rows != 128) rows = (long)(W / 32) * ((p.n + 63) / 64) >= 512 ? 128 : 64;
+  return rows == 128 ? launch_inc_tile<128>(p, variant, stream) : launch_inc_tile<64>(p, variant, stream);
 }
 
 // probs[n][V] = softmax(h_top . E^T) for the top layer's new h rows (pool slots slot_out); KL_ERR_SHAPE = not applicable (the

@@ -156,6 +156,8 @@ def make_model(depth, width, voc, n_ctx=1, seed=4, emb_std=0.5):
                                                      # rows read through the pool slots (step_tile.hip): whole and ragged row tiles, tile grids that
                                                      # are / are not dealt to the XCDs as rectangles, 0 / 1 / 2 context variables
                                                      (2, 256, 40, 320, 1), (3, 768, 50, 512, 0), (2, 512, 256, 1024, 1), (2, 512, 64, 449, 2),
+                                                     # ... 128-row tiles (two or more 64-row tiles per CU), the last one ragged
+                                                     (2, 1024, 64, 1030, 1),
                                                      # cfg5 topology (small and big-n paths)
                                                      (4, 1024, 64, 20, 2), (4, 1024, 64, 272, 2),
                                                      # wide vocabulary (V >= 1024): output projection through the big GEMM too
