@@ -191,6 +191,39 @@ def test_step_batch_parity(depth, width, voc, n, n_ctx):
         assert np.abs(pool[:, k] - st[k]).max() < 1e-4
 
 
+@pytest.mark.parametrize("depth,width,voc,n,env", [
+    (2, 512, 256, 300, {"KL_INC_TILE": "0"}),        # inc_cell_kernel with two row tiles per workgroup instead of the tile kernel
+    (2, 512, 256, 300, {"KL_INC_TILE": "0", "KL_INC_SMALL": "0"}),      # gather + [hi|lo|hi] GEMM with the cell as epilogue
+    (2, 512, 256, 300, {"KL_TILE_ROWS": "128"}),     # 128-row tiles, the last one ragged
+    (2, 512, 256, 600, {"KL_OUT_FUSED": "0"}),       # thin GEMM + softmax kernel instead of out_softmax_kernel
+    (2, 512, 256, 100, {"KL_OUT_FUSED_MIN": "16"}),  # out_softmax_kernel below its default row count
+    (2, 512, 256, 100, {"KL_INC_SMALL": "0"}),       # launch-per-layer thin kernels
+    (2, 128, 60, 100, {"KL_INC_SMALL": "0"})])
+def test_step_batch_paths_agree(monkeypatch, depth, width, voc, n, env):
+    """The incremental step's kernels are chosen by row count and width; every alternative (KL_* switches of INTEGRATION.md)
+    computes the same split-precision arithmetic, so chained steps through the pool must agree with the default path to a
+    few f32 roundings -- the fall-backs stay exercised although the defaults no longer reach them at these shapes."""
+    from ocrd_keraslm_amd.lib import hipabi
+    rng = np.random.default_rng(5)
+    ctx = rng.integers(0, 200, (n, 1))
+    ids = rng.integers(1, voc, (12, n))
+    out = {}
+    for name, e in (("default", {}), ("alternative", env)):
+        with monkeypatch.context() as mp:
+            for k, v in e.items():
+                mp.setenv(k, v)
+            cfg, w, lm = make_model(depth, width, voc)      # (the switches are read when the handle is created)
+        lm.set_weights(w, hipabi.KL_PREC_SPLIT)
+        lm.ensure_pool(2 * n)
+        a, b = np.arange(n), np.arange(n, 2 * n)
+        for step in range(len(ids)):
+            probs = lm.step_slots(ids[step], ctx, a, b).cpu().numpy()
+            a, b = b, a
+        out[name] = (probs, lm.pool_read(a))
+    assert np.abs(out["default"][0] - out["alternative"][0]).max() < 5e-6
+    assert np.abs(out["default"][1] - out["alternative"][1]).max() < 2e-5
+
+
 def test_state_dist2_matches_numpy():
     """kl_state_dist2 (history clustering, rating.py:887-916): squared distances between state entries of pool slots"""
     from ocrd_keraslm_amd.lib import hipabi
