@@ -224,6 +224,31 @@ def test_step_batch_paths_agree(monkeypatch, depth, width, voc, n, env):
     assert np.abs(out["default"][1] - out["alternative"][1]).max() < 2e-5
 
 
+@pytest.mark.parametrize("depth,width,voc,n", [(2, 512, 256, 128), (2, 512, 256, 1024), (2, 128, 60, 70), (4, 1024, 64, 1100)])
+def test_step_batch_repeatable_bitwise(depth, width, voc, n):
+    """No atomics and no order-dependent reductions in the incremental step: the same chained steps from the same pool give
+    bitwise the same probabilities and states, run after run (a fragment or an index taken before it had landed would show
+    here as a difference between runs)."""
+    from ocrd_keraslm_amd.lib import hipabi
+    cfg, w, lm = make_model(depth, width, voc)
+    lm.set_weights(w, hipabi.KL_PREC_SPLIT)
+    lm.ensure_pool(2 * n)
+    rng = np.random.default_rng(6)
+    ctx = rng.integers(0, 200, (n, 1))
+    ids = rng.integers(1, voc, (10, n))
+    runs = []
+    for rep in range(3):
+        lm.pool.zero_()
+        a, b = np.arange(n), np.arange(n, 2 * n)
+        for step in range(len(ids)):
+            probs = lm.step_slots(ids[step], ctx, a, b).cpu().numpy()
+            a, b = b, a
+        runs.append((probs, lm.pool_read(a)))
+    for probs, pool in runs[1:]:
+        assert np.array_equal(probs, runs[0][0])
+        assert np.array_equal(pool, runs[0][1])
+
+
 def test_state_dist2_matches_numpy():
     """kl_state_dist2 (history clustering, rating.py:887-916): squared distances between state entries of pool slots"""
     from ocrd_keraslm_amd.lib import hipabi
