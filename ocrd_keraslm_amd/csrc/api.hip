@@ -117,7 +117,8 @@ struct kl_handle {
   bool scan_enabled = true;     // persistent scans (KL_SCAN=0 forces the launch-per-step path)
   bool seq_bwd = true;          // layer-sequential backward scans for many row blocks (KL_SEQ_BWD=0: always fused)
   bool wide_bwd = true;         // ... with 64-unit workgroups (KL_WIDE_BWD=0: thin workgroups)
-  bool inc_ready = false;       // the big-n incremental operands match the current weights
+  bool inc_ready = false;       // the incremental step's fragment-major operands match the current weights (prepare_incremental)
+  bool big_ready = false;       // ... and those of the gather + GEMM path (prepare_big_step)
   int last_only = 0;            // stateless windows: one target per row, at the last position (kl_set_window_mode)
   bool sentinel = true;         // wide scans hand off by data sentinels instead of counters (KL_SENTINEL=0: counters)
   bool gemm_an = true;          // weight gradients read the backward scan's dZ K-major, no transposed copy (KL_GEMM_AN=0: dZ^T)
@@ -396,14 +397,33 @@ int prepare_impl(kl_handle* h, int precision, hipStream_t s) {
     if (c.n_ctx > 0) KL_TRY(kl_launch_permute_gate_cols_f32(d.CtxK[0], nullptr, d.CtxKp, c.ctx_vocab, W, s));
   }
   h->precision = precision;
-  h->inc_ready = false;      // the big-n incremental operands are rebuilt on their first use (prepare_incremental)
+  h->inc_ready = false;      // the incremental step's own operands are rebuilt on their first use (prepare_incremental,
+  h->big_ready = false;      // prepare_big_step)
   return 0;
 }
 
-// Operands only the big-n incremental step reads: concatenated [hi | hi | lo] weights, their
-// gate-permuted copies and the concatenated embedding.  Built lazily: a training step re-derives the
-// window operands after every Adam update and never touches these.
+// Operands only the incremental step reads.  Built lazily: a training step re-derives the window operands after every
+// Adam update and never touches these.
+// (1) fragment-major copies of the [4W][W] / [Vp][W] hi / lo arrays kl_prepare keeps (step_small.hip, step_tile.hip)
 int prepare_incremental(kl_handle* h, hipStream_t s) {
+  const kl_config& c = h->cfg;
+  const int W = c.width, Vp = h->Vp;
+  Derived& d = h->d;
+  const bool split = h->precision == KL_PREC_SPLIT;
+  if (d.EF) {
+    for (int l = 0; l < c.depth; ++l) {
+      KL_TRY(kl_launch_frag_major(d.UT_hi[l], split ? d.UT_lo[l] : nullptr, 4 * W, W, W, d.UF[l], s));
+      if (l > 0) KL_TRY(kl_launch_frag_major(d.KT_hi[l], split ? d.KT_lo[l] : nullptr, 4 * W, W, W, d.KF[l], s));
+    }
+    KL_TRY(kl_launch_frag_major(d.E_hi, split ? d.E_lo : nullptr, Vp, W, W, d.EF, s));
+  }
+  h->inc_ready = true;
+  return 0;
+}
+
+// (2) the gather + GEMM path (widths beyond 1024 that are not multiples of 256; vocabularies from 1024 characters on):
+// concatenated [hi | hi | lo] weights, their gate-permuted copies and the concatenated embedding
+int prepare_big_step(kl_handle* h, hipStream_t s) {
   const kl_config& c = h->cfg;
   const int W = c.width, V = c.voc_size, Vp = h->Vp;
   const float* P = h->params;
@@ -425,17 +445,10 @@ int prepare_incremental(kl_handle* h, hipStream_t s) {
     if (split) KL_TRY(kl_launch_f32_to_bf16_t(U, 4 * W, W, 4 * W, base + Kl + uoff, nullptr, ld, 1, s));
     if (d.WTperm[l]) KL_TRY(kl_launch_permute_gate_rows(base, d.WTperm[l], W, ld, s));
   }
-  if (d.EF) {      // fragment-major copies of the [4W][W] / [Vp][W] hi / lo arrays kl_prepare keeps
-    for (int l = 0; l < c.depth; ++l) {
-      KL_TRY(kl_launch_frag_major(d.UT_hi[l], split ? d.UT_lo[l] : nullptr, 4 * W, W, W, d.UF[l], s));
-      if (l > 0) KL_TRY(kl_launch_frag_major(d.KT_hi[l], split ? d.KT_lo[l] : nullptr, 4 * W, W, W, d.KF[l], s));
-    }
-    KL_TRY(kl_launch_frag_major(d.E_hi, split ? d.E_lo : nullptr, Vp, W, W, d.EF, s));
-  }
   KL_TRY(kl_zero_async(d.Ecat, (size_t)Vp * 3 * W * sizeof(bf16_t), s));
   KL_TRY(kl_launch_f32_to_bf16_t(E, W, V, W, d.Ecat, split ? d.Ecat + 2 * W : nullptr, 3 * W, 0, s));
   if (split) KL_TRY(kl_launch_f32_to_bf16_t(E, W, V, W, d.Ecat + W, nullptr, 3 * W, 0, s));
-  h->inc_ready = true;
+  h->big_ready = true;
   return 0;
 }
 
@@ -1498,7 +1511,7 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
     if (e != KL_ERR_SHAPE) return e;
   }
   if (n >= KL_BIG_STEP_N && ws && ws_bytes >= kl_step_workspace_bytes(h, n)) {
-    if (!h->inc_ready) KL_TRY(prepare_incremental(h, s));
+    if (!h->big_ready) KL_TRY(prepare_big_step(h, s));
     // big-tile path: gather+split -> one bf16 GEMM over the 3x contraction -> gates
     Carver cv(ws);
     cv.take<float>((size_t)n * 4 * W);
