@@ -86,6 +86,9 @@ class HipLM:
         self._ws_key = None
         self.states = None          # [B][2L][W] implicit state of the stateful streams
         self.pool = None            # [slots][2L][W] explicit states of hypotheses
+        self.max_streams_per_launch = 0      # 0: what the kernels address (train_window splits larger batches into groups)
+        self._part_grads = None
+        self._part_loss = None
         self._step_ws = None
         self._step_ws_bytes = {}
         self.last_only = False
@@ -300,11 +303,30 @@ class HipLM:
                 self.reset_states(B)
             # (bf16 precision = validation windows: a training-size workspace lets the library take the training
             # forward, i.e. the persistent scans; it is the buffer train_window uses anyway)
-            ws = self._workspace(B, T, self.precision == hipabi.KL_PREC_BF16)
+            training_ws = self.precision == hipabi.KL_PREC_BF16
             probs = torch.empty((B, T, self.voc_size), dtype=torch.float32, device=self.device) if want_probs else None
-            hipabi.check(self.lib.kl_forward_window(self.handle, B, T, _ptr(idx_d), _ptr(ctx_d), _ptr(tgt_d),
-                                                    _ptr(self.states), _ptr(probs), _ptr(self.loss_acc), _ptr(ws),
-                                                    ws.numel(), self._stream()), "kl_forward_window")
+            parts = self._stream_groups(B, T) if training_ws else [(0, B)]
+            if len(parts) == 1:
+                ws = self._workspace(B, T, training_ws)
+                hipabi.check(self.lib.kl_forward_window(self.handle, B, T, _ptr(idx_d), _ptr(ctx_d), _ptr(tgt_d),
+                                                        _ptr(self.states), _ptr(probs), _ptr(self.loss_acc), _ptr(ws),
+                                                        ws.numel(), self._stream()), "kl_forward_window")
+            else:
+                # (more streams than one launch sequence addresses: groups of streams one after the other, as in train_window;
+                # the means over the batch are the size-weighted sums of the groups' means)
+                if self._part_loss is None:
+                    self._part_loss = torch.zeros_like(self.loss_acc)
+                ws = self._workspace(max(b1 - b0 for b0, b1 in parts), T, True)
+                for b0, b1 in parts:
+                    self._part_loss.zero_()
+                    hipabi.check(self.lib.kl_forward_window(self.handle, b1 - b0, T, _ptr(idx_d[b0:b1]),
+                                                            _ptr(ctx_d[b0:b1] if ctx_d is not None else None),
+                                                            _ptr(tgt_d[b0:b1] if tgt_d is not None else None),
+                                                            _ptr(self.states[b0:b1]), _ptr(probs[b0:b1] if probs is not None else None),
+                                                            _ptr(self._part_loss), _ptr(ws), ws.numel(), self._stream()),
+                                 "kl_forward_window")
+                    self.loss_acc[:2] += ((b1 - b0) / B) * self._part_loss[:2]
+                    self.loss_acc[3] = torch.maximum(self.loss_acc[3], self._part_loss[3])
             if want_probs and float(self.loss_acc[3].item()) != 0.0:
                 # (the caller reads the probabilities next, so this sync is not an extra one)
                 self.loss_acc[3] = 0.0        # one timed-out window must not fail every later call
@@ -358,11 +380,49 @@ class HipLM:
                     np.ascontiguousarray(masks, dtype=np.float32)).to(self.device)
                 if self.padded and masks_d.shape[-1] == self.width:      # (whatever the padded units get is multiplied by zero)
                     masks_d = torch.nn.functional.pad(masks_d, (0, self.pwidth - self.width), value=1.0).contiguous()
-            ws = self._workspace(B, T, True)
-            hipabi.check(self.lib.kl_train_window(self.handle, B, T, _ptr(idx_d), _ptr(ctx_d), _ptr(tgt_d),
-                                                  _ptr(self.states), _ptr(masks_d), _ptr(self.grads),
-                                                  _ptr(self.loss_acc), _ptr(ws), ws.numel(), self._stream()),
-                         "kl_train_window")
+            parts = self._stream_groups(B, T)
+            if len(parts) == 1:
+                ws = self._workspace(B, T, True)
+                hipabi.check(self.lib.kl_train_window(self.handle, B, T, _ptr(idx_d), _ptr(ctx_d), _ptr(tgt_d),
+                                                      _ptr(self.states), _ptr(masks_d), _ptr(self.grads),
+                                                      _ptr(self.loss_acc), _ptr(ws), ws.numel(), self._stream()),
+                             "kl_train_window")
+                return
+            # More streams than one launch sequence addresses (the scans index a layer's gate rows, T * B * 4W bf16, with 32-bit
+            # buffer offsets: 3072 streams at cfg2): the streams are independent, so the batch runs as groups of streams one
+            # after the other -- each on the persistent-scan path -- and the gradient of the mean over all B*T positions is
+            # the size-weighted sum of the groups' gradients (the regularisers' part is the same in every group: weights sum to 1).
+            if self._part_grads is None:
+                self._part_grads = torch.zeros_like(self.grads)
+            if self._part_loss is None:
+                self._part_loss = torch.zeros_like(self.loss_acc)
+            ws = self._workspace(max(b1 - b0 for b0, b1 in parts), T, True)
+            for i, (b0, b1) in enumerate(parts):
+                wgt = (b1 - b0) / B
+                self._part_loss.zero_()
+                m = masks_d[:, b0:b1].contiguous() if masks_d is not None else None
+                c = ctx_d[b0:b1] if ctx_d is not None else None
+                hipabi.check(self.lib.kl_train_window(self.handle, b1 - b0, T, _ptr(idx_d[b0:b1]), _ptr(c), _ptr(tgt_d[b0:b1]),
+                                                      _ptr(self.states[b0:b1]), _ptr(m), _ptr(self._part_grads),
+                                                      _ptr(self._part_loss), _ptr(ws), ws.numel(), self._stream()),
+                             "kl_train_window")
+                if i == 0:
+                    torch.mul(self._part_grads, wgt, out=self.grads)
+                    self.loss_acc[2] += self._part_loss[2]
+                else:
+                    self.grads.add_(self._part_grads, alpha=wgt)
+                self.loss_acc[:2] += wgt * self._part_loss[:2]
+                self.loss_acc[3] = torch.maximum(self.loss_acc[3], self._part_loss[3])
+
+    def _stream_groups(self, B, T):
+        """[(first, end)] stream ranges of one training batch: one range unless the batch is beyond what a launch sequence
+        addresses; then groups of `max_streams_per_launch` streams (a multiple of 1024 where the limit allows, so that every
+        full group runs on the second-generation scans) and the rest."""
+        limit = self.max_streams_per_launch or (0xfffffff0 // (T * 4 * self.pwidth * 2))
+        if B <= limit:
+            return [(0, B)]
+        step = limit // 1024 * 1024 if limit >= 1024 else max(16, limit // 16 * 16)
+        return [(b0, min(B, b0 + step)) for b0 in range(0, B, step)]
 
     def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7, clip=1.0, grad_scale=1.0):
         """Keras-2.3 Adam(clipvalue=1.0) (rating.py:178).  grad_scale: the gradients are read as grads * grad_scale

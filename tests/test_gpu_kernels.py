@@ -655,6 +655,42 @@ def test_train_consecutive_windows_reuse_buffers(depth, width, voc, B, T):
         st = [got_st[:, k].astype(np.float64) for k in range(2 * depth)]
 
 
+@pytest.mark.parametrize("depth,width,voc,B,T,limit,use_masks", [(2, 512, 64, 2048, 6, 1024, True), (2, 512, 64, 2560, 5, 1024, False),
+                                                                 (2, 128, 40, 200, 7, 64, True)])
+def test_train_window_stream_groups(depth, width, voc, B, T, limit, use_masks):
+    """A batch of more streams than one launch sequence addresses (32-bit offsets into a layer's gate rows: 3072 streams at
+    cfg2) runs as groups of streams one after the other (engine.train_window); the streams are independent, so loss,
+    gradients and carried states must equal those of the whole batch in one piece -- forced here at sizes where both forms
+    run (HipLM.max_streams_per_launch)."""
+    torch = _torch()
+    from ocrd_keraslm_amd.lib import hipabi
+    cfg, w, _ = make_model(depth, width, voc)
+    rng = np.random.default_rng(13)
+    idx = rng.integers(1, voc, (B, T)); tgt = rng.integers(1, voc, (B, T))
+    ctx = rng.integers(0, 200, (B, 1, 1)).repeat(T, axis=1)
+    masks = ((rng.random((depth, B, width)) >= 0.1) / 0.9).astype(np.float32) if use_masks else None
+    res = {}
+    for name, lim in (("whole", 0), ("groups", limit)):
+        lm = make_model(depth, width, voc)[2]
+        lm.set_weights(w, hipabi.KL_PREC_BF16)
+        lm.max_streams_per_launch = lim
+        lm.reset_states(B)
+        lm.loss_acc.zero_()
+        for _ in range(2):      # (two consecutive windows: the carried states of every group go back to its rows)
+            lm.train_window(idx, ctx, tgt, masks)
+        res[name] = (np.array(lm.read_loss()), lm.grads.cpu().numpy().copy(), lm.states.cpu().numpy().copy())
+        # ... and a validation window (bf16 forward on the training workspace) from those states
+        p = lm.forward_window(idx, ctx, tgt, want_probs=True).cpu().numpy()
+        res[name] += (p, np.array(lm.read_loss()))
+    assert len(lm._stream_groups(B, T)) > 1
+    l0, g0, s0, p0, v0 = res["whole"]; l1, g1, s1, p1, v1 = res["groups"]
+    assert np.abs(p0 - p1).max() < 2e-2 and abs(v0[0] - v1[0]) < 2e-3 * v0[0], (np.abs(p0 - p1).max(), v0, v1)
+    assert abs(l0[0] - l1[0]) < 1e-3 * l0[0] and abs(l0[2] - l1[2]) < 1e-5 * abs(l0[2]), (l0, l1)
+    assert abs(l0[1] - l1[1]) < 2e-3, (l0, l1)      # (accuracy: a few arg-max near-ties fall differently between the kernel generations)
+    assert np.abs(s0 - s1).max() < 2e-2
+    assert np.linalg.norm(g0 - g1) < 2e-2 * np.linalg.norm(g0), np.linalg.norm(g0 - g1) / np.linalg.norm(g0)
+
+
 @pytest.mark.parametrize("B,windows,env", [
     (512, 10, {}), (1024, 4, {}), (264, 6, {}),
     (2048, 2, {}),                                       # four row blocks per workgroup: prefetched tiles, late stores
