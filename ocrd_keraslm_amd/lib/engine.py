@@ -414,15 +414,30 @@ class HipLM:
                 self.loss_acc[:2] += wgt * self._part_loss[:2]
                 self.loss_acc[3] = torch.maximum(self.loss_acc[3], self._part_loss[3])
 
+    # stream counts the second-generation scans take at width 512 (32 row groups x 2..6 row blocks of 16, lstm_scan2.hip)
+    FAST_STREAMS = (3072, 2048, 1536, 1024)
+
     def _stream_groups(self, B, T):
-        """[(first, end)] stream ranges of one training batch: one range unless the batch is beyond what a launch sequence
-        addresses; then groups of `max_streams_per_launch` streams (a multiple of 1024 where the limit allows, so that every
-        full group runs on the second-generation scans) and the rest."""
+        """[(first, end)] stream ranges of one training batch.  One range, unless (a) the batch is beyond what a launch
+        sequence addresses (32-bit offsets into a layer's gate rows, T * B * 4W bf16) -- it would fall through to the
+        launch-per-step kernels --, or (b) at width 512 it is above 1024 streams and not one of the counts the second-
+        generation scans take: then the largest such counts are peeled off as long as 512 streams or more remain
+        (2560 -> 2048 + 512, 3584 -> 3072 + 512, 4096 -> 3072 + 1024) and only the rest runs on the first-generation scans."""
         limit = self.max_streams_per_launch or (0xfffffff0 // (T * 4 * self.pwidth * 2))
-        if B <= limit:
-            return [(0, B)]
-        step = limit // 1024 * 1024 if limit >= 1024 else max(16, limit // 16 * 16)
-        return [(b0, min(B, b0 + step)) for b0 in range(0, B, step)]
+        fast = [f for f in self.FAST_STREAMS if f <= limit] if (self.pwidth == 512 and T >= 3 and not self.max_streams_per_launch) else []
+        parts, b0 = [], 0
+        while B - b0 > 0:
+            rem = B - b0
+            take = rem
+            if fast and rem > fast[-1] and rem not in fast:
+                f = next((f for f in fast if f <= rem and (rem - f == 0 or rem - f >= 512)), None)
+                if f is not None:
+                    take = f
+            if take > limit:      # (no fast count applies: groups of the largest size the kernels address)
+                take = limit // 512 * 512 if limit >= 512 else max(16, limit // 16 * 16)
+            parts.append((b0, b0 + take))
+            b0 += take
+        return parts
 
     def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7, clip=1.0, grad_scale=1.0):
         """Keras-2.3 Adam(clipvalue=1.0) (rating.py:178).  grad_scale: the gradients are read as grads * grad_scale
