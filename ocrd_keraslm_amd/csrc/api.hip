@@ -59,7 +59,7 @@ struct Derived {
   std::vector<bf16_t*> KTp;      // [4W][W], l >= 1
   std::vector<float*> bp;        // [4W], l >= 1 (layer 0's bias is folded into EKp)
   float* EKp = nullptr;          // [V][4W] = EK + b_0
-  float* CtxKp = nullptr;        // [ctx_vocab][4W] of context variable 0
+  std::vector<float*> CtxKp;     // [ctx_vocab][W][4] per context variable (the scan's table mode reads that of variable 0)
   unsigned* scan_flags = nullptr;   // lstm_scan_bwd_wide2_kernel's flags + epoch (zeroed once per bind: the numbers only grow)
 };
 
@@ -268,7 +268,8 @@ size_t carve_derived(const kl_handle* h, void* base, Derived* d) {
     o.bp[l] = cv.take<float>(4 * W);
   }
   o.EKp = cv.take<float>(V * 4 * W);
-  o.CtxKp = c.n_ctx > 0 ? cv.take<float>((size_t)c.ctx_vocab * 4 * W) : nullptr;
+  o.CtxKp.assign(c.n_ctx, nullptr);
+  for (int n = 0; n < c.n_ctx; ++n) o.CtxKp[n] = cv.take<float>((size_t)c.ctx_vocab * 4 * W);
   o.scan_flags = cv.take<unsigned>(KL_SCAN_FLAGS + 64);      // hand-off flags of the backward scan [256 row blocks][64] + the epoch word
   return align_up(cv.off, 256);
 }
@@ -394,7 +395,7 @@ int prepare_impl(kl_handle* h, int precision, hipStream_t s) {
       KL_TRY(kl_launch_permute_gate_cols_f32(P + h->off_b[l], nullptr, d.bp[l], 1, W, s));
     }
     KL_TRY(kl_launch_permute_gate_cols_f32(d.EK, P + h->off_b[0], d.EKp, V, W, s));
-    if (c.n_ctx > 0) KL_TRY(kl_launch_permute_gate_cols_f32(d.CtxK[0], nullptr, d.CtxKp, c.ctx_vocab, W, s));
+    for (int n = 0; n < c.n_ctx; ++n) KL_TRY(kl_launch_permute_gate_cols_f32(d.CtxK[n], nullptr, d.CtxKp[n], c.ctx_vocab, W, s));
   }
   h->precision = precision;
   h->inc_ready = false;      // the incremental step's own operands are rebuilt on their first use (prepare_incremental,
@@ -457,7 +458,8 @@ int prepare_big_step(kl_handle* h, hipStream_t s) {
 int plan_scan2(const kl_handle* h, int B, int T, bool km_plan, bool need_bwd) {
   const kl_config& c = h->cfg;
   const int W = c.width;
-  if (!h->scan2 || !h->scan_enabled || !h->sentinel || !km_plan || c.n_ctx > 1 || T < 3) return 0;
+  if (!h->scan2 || !h->scan_enabled || !h->sentinel || !km_plan || T < 3) return 0;
+  if (c.n_ctx > 1 && !h->scan2_bf16) return 0;      // (several context variables: layer 0's gate inputs as bf16 P rows, kl_launch_p_gather_il)
   if (W != 512) return 0;      // (one tile row = one 1 KiB DMA piece)
   if (h->wide_fwd_min <= 0 || !kl_scan_fwd_wide_applicable(B, T, W) || ((B + 15) / 16) * (W / 64) < h->wide_fwd_min) return 0;
   if (need_bwd && (!h->wide_bwd || !h->seq_bwd || !h->sentinel_bwd || !h->sentinel_roll || !kl_scan_wide2_phases(B, T, W, 16, 6))) return 0;
@@ -517,10 +519,17 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
         KL_TRY(pe);
         a.P = w.P1;
         a.p_bf16 = v2 && h->scan2_bf16 ? 1 : 0;
+      } else if (v2 && c.n_ctx > 1) {
+        // several context variables: the scan's table mode adds ONE context row to the character row, so the gate inputs
+        // of layer 0 are gathered into P rows first (as the layers above get them from proj_ws_kernel)
+        KL_TRY(kl_launch_p_gather_il(d.EKp, d.CtxKp.data(), c.n_ctx, idx, ctx, B, T, W, c.voc_size, c.ctx_vocab,
+                                     reinterpret_cast<bf16_t*>(w.P1), s));
+        a.P = w.P1;
+        a.p_bf16 = 1;
       } else if (v2) {
         KL_TRY(kl_launch_ids_tm(idx, ctx, c.n_ctx, B, T, W, c.voc_size, c.ctx_vocab, w.ids_tm, s));
         a.EK = d.EKp;
-        a.CtxK[0] = d.CtxKp;
+        a.CtxK[0] = c.n_ctx > 0 ? d.CtxKp[0] : nullptr;
         a.n_ctx = c.n_ctx;
         a.ids_tm = w.ids_tm;
         a.V = c.voc_size; a.ctx_vocab = c.ctx_vocab;

@@ -169,6 +169,9 @@ int kl_scan_wide2_phases(int B, int T, int W, int rows, int max_np);
 int kl_launch_scan_fwd_wide2(KlScanFwdWide args, int rows, hipStream_t stream);
 int kl_launch_permute_gate_cols_f32(const float* in, const float* bias, float* out, long rows, int W, hipStream_t stream);
 int kl_launch_permute_gate_rows_bf16(const bf16_t* in, bf16_t* out, int W, int K, hipStream_t stream);
+// layer 0's gate inputs as gate-interleaved bf16 P rows (time-major) from the permuted tables: several context variables
+int kl_launch_p_gather_il(const float* EKp, const float* const* CtxKp, int n_ctx, const int* idx, const int* ctx, int B, int T, int W,
+                          int V, int ctx_vocab, bf16_t* out, hipStream_t stream);
 int kl_launch_ids_tm(const int* idx, const int* ctx, int n_ctx, int B, int T, int W, int V, int ctx_vocab, int* out,
                      hipStream_t stream);
 

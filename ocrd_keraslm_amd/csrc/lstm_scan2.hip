@@ -1815,7 +1815,47 @@ __global__ void ids_tm_kernel(const int* __restrict__ idx, const int* __restrict
   out[i * 2 + 1] = (int)((unsigned)c * row_bytes);
 }
 
+// Gate inputs of layer 0 as P rows for the second-generation forward scan when there are SEVERAL context variables (its
+// table mode adds one context row to the character row; rating.py:118-122 allows any number): P0[t * B + b][u][gate] =
+// EKp[idx] + sum over n of CtxKp_n[ctx_n], rows time-major, gate-interleaved, bf16 -- what proj_ws_kernel leaves for the
+// layers above.  16 bytes in per table and cell, 8 bytes out.
+struct KlCtxTabs { const float* t[8]; };
+__global__ void p_gather_il_kernel(const float* __restrict__ EKp, const KlCtxTabs tabs, int n_ctx, const int* __restrict__ idx,
+                                   const int* __restrict__ ctx, int B, int T, int W, int V, int ctx_vocab, bf16_t* __restrict__ out) {
+  const long total = (long)T * B * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / W;
+    const int u = (int)(i - row * W);
+    const int t = (int)(row / B), b = (int)(row - (long)t * B);
+    const long src = (long)b * T + t;
+    int id = idx[src];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    f32x4 v = *reinterpret_cast<const f32x4*>(EKp + ((long)id * W + u) * 4);
+    for (int n = 0; n < n_ctx; ++n) {
+      int c = ctx[src * n_ctx + n];
+      c = c < 0 ? 0 : (c >= ctx_vocab ? ctx_vocab - 1 : c);
+      v += *reinterpret_cast<const f32x4*>(tabs.t[n] + ((long)c * W + u) * 4);
+    }
+    uint2 o;
+    o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+    o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(out + i * 4) = o;
+  }
+}
+
 }  // namespace
+
+int kl_launch_p_gather_il(const float* EKp, const float* const* CtxKp, int n_ctx, const int* idx, const int* ctx, int B, int T, int W,
+                          int V, int ctx_vocab, bf16_t* out, hipStream_t stream) {
+  if (n_ctx < 0 || n_ctx > 8 || !EKp || !idx || !out || (n_ctx > 0 && (!ctx || !CtxKp))) return KL_ERR_ARG;
+  KlCtxTabs tabs;
+  memset(&tabs, 0, sizeof(tabs));
+  for (int n = 0; n < n_ctx; ++n) tabs.t[n] = CtxKp[n];
+  long g = ((long)T * B * W + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(p_gather_il_kernel, dim3((unsigned)g), dim3(256), 0, stream, EKp, tabs, n_ctx, idx, ctx, B, T, W, V, ctx_vocab, out);
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
 
 int kl_launch_permute_gate_cols_f32(const float* in, const float* bias, float* out, long rows, int W, hipStream_t stream) {
   const long n = rows * W;

@@ -465,7 +465,9 @@ def test_train_window_wide_forward(monkeypatch, depth, width, voc, B, T, n_ctx, 
     # six blocks per step: the 8-wave backward scan with the tile through registers two blocks ahead (lstm_scan_bwd_regtile_kernel);
     # KL_REGTILE=0 / KL_RT_LOCAL=0: the 16-wave kernel / write-through publishes at the same shape
     (2, 512, 64, 3072, 5, 1, True, {}), (2, 512, 64, 3072, 7, 1, False, {}), (3, 512, 40, 3072, 4, 0, True, {}),
-    (2, 512, 64, 3072, 5, 1, True, {"KL_REGTILE": "0"}), (2, 512, 64, 3072, 4, 1, True, {"KL_RT_LOCAL": "0"})])
+    (2, 512, 64, 3072, 5, 1, True, {"KL_REGTILE": "0"}), (2, 512, 64, 3072, 4, 1, True, {"KL_RT_LOCAL": "0"}),
+    # several context variables: layer 0's gate inputs gathered into bf16 P rows in front of the scan (kl_launch_p_gather_il)
+    (2, 512, 64, 1024, 4, 2, True, {}), (2, 512, 64, 3072, 3, 3, False, {})])
 def test_train_window_scan2(monkeypatch, depth, width, voc, B, T, n_ctx, use_masks, env):
     """Second-generation wide scans (lstm_scan2.hip: no K split in the forward scan, 32-row phases, double-buffered
     tiles, counted waits, gate-interleaved G): gradients, loss and carried state against the f64 oracle."""
