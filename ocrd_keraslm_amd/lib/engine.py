@@ -414,22 +414,26 @@ class HipLM:
                 self.loss_acc[:2] += wgt * self._part_loss[:2]
                 self.loss_acc[3] = torch.maximum(self.loss_acc[3], self._part_loss[3])
 
-    # stream counts the second-generation scans take at width 512 (32 row groups x 2..6 row blocks of 16, lstm_scan2.hip)
-    FAST_STREAMS = (3072, 2048, 1536, 1024)
+    # Stream counts per (physical) width that run on the fastest kernels, and the count from which a batch that is none of them
+    # is regrouped: width 512 -- what the second-generation scans take (32 row groups x 2..6 row blocks of 16, lstm_scan2.hip);
+    # width 1024 -- the eight-wave scans serve up to 1024 streams (lstm_scan_w32.hip), beyond them the launch-per-step kernels
+    # (2048 streams: 1.4 M chars/s against 5.2 M); width 128 -- 4096 streams in one piece run at half the rate of 2 x 2048.
+    FAST_STREAMS = {512: ((3072, 2048, 1536, 1024), 1025), 1024: ((1024, 512), 1025), 128: ((2048,), 4096)}
 
     def _stream_groups(self, B, T):
         """[(first, end)] stream ranges of one training batch.  One range, unless (a) the batch is beyond what a launch
         sequence addresses (32-bit offsets into a layer's gate rows, T * B * 4W bf16) -- it would fall through to the
-        launch-per-step kernels --, or (b) at width 512 it is above 1024 streams and not one of the counts the second-
-        generation scans take: then the largest such counts are peeled off as long as 512 streams or more remain
-        (2560 -> 2048 + 512, 3584 -> 3072 + 512, 4096 -> 3072 + 1024) and only the rest runs on the first-generation scans."""
+        launch-per-step kernels --, or (b) it is none of the stream counts the fastest kernels of its width take and large
+        enough (FAST_STREAMS): then the largest such counts are peeled off as long as 512 streams or more remain
+        (width 512: 2560 -> 2048 + 512, 3584 -> 3072 + 512, 4096 -> 3072 + 1024) and only the rest runs on the slower path."""
         limit = self.max_streams_per_launch or (0xfffffff0 // (T * 4 * self.pwidth * 2))
-        fast = [f for f in self.FAST_STREAMS if f <= limit] if (self.pwidth == 512 and T >= 3 and not self.max_streams_per_launch) else []
+        fast, regroup_from = self.FAST_STREAMS.get(self.pwidth, ((), 0))
+        fast = [f for f in fast if f <= limit] if (T >= 3 and not self.max_streams_per_launch) else []
         parts, b0 = [], 0
         while B - b0 > 0:
             rem = B - b0
             take = rem
-            if fast and rem > fast[-1] and rem not in fast:
+            if fast and rem not in fast and (rem >= regroup_from or b0 > 0 or rem > limit):
                 f = next((f for f in fast if f <= rem and (rem - f == 0 or rem - f >= 512)), None)
                 if f is not None:
                     take = f

@@ -21,7 +21,7 @@ shapes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]] or [
     (2, 512, 256, 1, 256), (2, 512, 256, 1, 512), (2, 512, 256, 1, 128)]
 for depth, width, length, n_ctx, B in shapes:
     try:
-        leg, lm = bench.training_leg(device, depth, width, length, n_ctx, B, 8, 3, corpus)
+        leg, lm = bench.training_leg(device, depth, width, length, n_ctx, B, int(os.environ.get("KL_SWEEP_STEPS", "8")), 3, corpus)
         del lm
         torch.cuda.empty_cache()
         print("depth %d width %4d length %3d contexts %d streams %4d: %8.2f ms/step %7.2f M chars/s  %.1f %% of the MFMA roof"
