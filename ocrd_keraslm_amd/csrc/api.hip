@@ -1496,7 +1496,9 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
   };
   // 256 hypotheses or more, widths of 256, 384, 512, ...: one launch per layer, tiles of 64 hypotheses x 32 units with the
   // state rows read through the pool slots and the weights from the hi / lo arrays as they are (step_tile.hip)
-  if (n >= KL_BIG_STEP_N && h->inc_tile && V < 1024 && d.EF) {
+  // (width 1024 already from 129 hypotheses: inc_cell_kernel cannot hold two row tiles of K = 2048 in LDS there, and with one
+  //  its W / 16 x n / 16 workgroups read every weight 16 times at 250 hypotheses -- 90 us per step against 51 on 64-row tiles)
+  if ((n >= KL_BIG_STEP_N || (W >= 1024 && n > 128)) && h->inc_tile && V < 1024 && d.EF) {
     if (!h->inc_ready) KL_TRY(prepare_incremental(h, s));
     int e = 0;
     for (int l = 0; l < L && e == 0; ++l) {
