@@ -305,7 +305,7 @@ class HipLM:
             # forward, i.e. the persistent scans; it is the buffer train_window uses anyway)
             training_ws = self.precision == hipabi.KL_PREC_BF16
             probs = torch.empty((B, T, self.voc_size), dtype=torch.float32, device=self.device) if want_probs else None
-            parts = self._stream_groups(B, T) if training_ws else [(0, B)]
+            parts = self._stream_groups(B, T) if training_ws else self._rating_groups(B)
             if len(parts) == 1:
                 ws = self._workspace(B, T, training_ws)
                 hipabi.check(self.lib.kl_forward_window(self.handle, B, T, _ptr(idx_d), _ptr(ctx_d), _ptr(tgt_d),
@@ -316,7 +316,7 @@ class HipLM:
                 # the means over the batch are the size-weighted sums of the groups' means)
                 if self._part_loss is None:
                     self._part_loss = torch.zeros_like(self.loss_acc)
-                ws = self._workspace(max(b1 - b0 for b0, b1 in parts), T, True)
+                ws = self._workspace(max(b1 - b0 for b0, b1 in parts), T, training_ws)
                 for b0, b1 in parts:
                     self._part_loss.zero_()
                     hipabi.check(self.lib.kl_forward_window(self.handle, b1 - b0, T, _ptr(idx_d[b0:b1]),
@@ -413,6 +413,24 @@ class HipLM:
                     self.grads.add_(self._part_grads, alpha=wgt)
                 self.loss_acc[:2] += wgt * self._part_loss[:2]
                 self.loss_acc[3] = torch.maximum(self.loss_acc[3], self._part_loss[3])
+
+    def _rating_groups(self, B):
+        """[(first, end)] stream ranges of a rating window (split precision): the persistent split-precision scans keep a
+        workgroup's weights in registers, one workgroup per CU, at most four 16-stream row blocks each -- 256 streams at depth 2 /
+        width 512, 128 at depth 3 or 4, 512 at width 256 (lstm_scan.hip, kl_launch_scan_fwd_split) --; more streams in one call
+        fell through to the launch-per-step kernels (1024 x 256 characters: 62.6 ms against 4 x 4.3).  Streams are independent:
+        a larger batch runs as groups of that many."""
+        W, L = self.pwidth, self.depth
+        cus = min(256, self.torch.cuda.get_device_properties(self.device).multi_processor_count)
+        if W in (64, 128, 256, 512) and L <= 4:
+            cap = 64 * (cus // (L * (W // 16)))
+        elif W == 1024:
+            cap = 64 * (cus // (W // 16))
+        else:
+            cap = 0
+        if cap <= 0 or B <= cap:
+            return [(0, B)]
+        return [(b0, min(B, b0 + cap)) for b0 in range(0, B, cap)]
 
     # Stream counts per (physical) width that run on the fastest kernels, and the count from which a batch that is none of them
     # is regrouped: width 512 -- what the second-generation scans take (32 row groups x 2..6 row blocks of 16, lstm_scan2.hip);

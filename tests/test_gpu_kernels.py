@@ -337,7 +337,10 @@ def test_step_batch_bf16_within_1e3():
                                                        # zero-padded widths
                                                        (2, 100, 50, 3, 12, 1), (1, 33, 20, 20, 5, 0),
                                                        # deeper than four layers (launch-per-step kernels, packs of four layers)
-                                                       (6, 128, 30, 5, 9, 1), (9, 64, 20, 2, 6, 2)])
+                                                       (6, 128, 30, 5, 9, 1), (9, 64, 20, 2, 6, 2),
+                                                       # more streams than the persistent split-precision scan takes in one call
+                                                       # (256 at depth 2 / width 512, 128 at depth 3): groups of streams
+                                                       (2, 512, 64, 300, 4, 1), (3, 512, 40, 270, 3, 2)])
 def test_forward_window_parity(depth, width, voc, B, T, n_ctx):
     """F1-F6 stateful windows (rating.py:490, 516): two consecutive windows carry state."""
     from ocrd_keraslm_amd.lib import hipabi
