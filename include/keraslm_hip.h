@@ -110,6 +110,12 @@ size_t kl_window_workspace_bytes(const kl_handle* h, int B, int T, int training)
  * accuracy are means over the B rows, the other positions carry no gradient. */
 int kl_set_window_mode(kl_handle* h, int last_only);
 
+/* Rows the means of kl_train_window are taken over: 0 (default) = its B.  A caller that PADS a batch with dummy streams
+ * (targets -1: no loss, no gradient) up to a stream count the persistent scans are instantiated for passes the real count
+ * here, so that loss, accuracy and gradient stay those of the reference's mean over the real B*T positions
+ * (rating.py:178, Keras' mean over the batch). */
+int kl_set_loss_rows(kl_handle* h, int rows);
+
 int kl_forward_window(kl_handle* h, int B, int T, const int32_t* idx, const int32_t* ctx, const int32_t* tgt,
                       float* states, float* probs, float* loss_acc, void* ws, size_t ws_bytes, void* stream);
 

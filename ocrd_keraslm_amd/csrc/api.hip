@@ -120,6 +120,7 @@ struct kl_handle {
   bool inc_ready = false;       // the incremental step's fragment-major operands match the current weights (prepare_incremental)
   bool big_ready = false;       // ... and those of the gather + GEMM path (prepare_big_step)
   int last_only = 0;            // stateless windows: one target per row, at the last position (kl_set_window_mode)
+  int loss_rows = 0;            // rows the training means are taken over when the batch carries dummy streams (kl_set_loss_rows; 0: B)
   bool sentinel = true;         // wide scans hand off by data sentinels instead of counters (KL_SENTINEL=0: counters)
   bool gemm_an = true;          // weight gradients read the backward scan's dZ K-major, no transposed copy (KL_GEMM_AN=0: dZ^T)
   bool xcd_local = false;       // KL_XCD_LOCAL=1: sentinel hand-off inside one XCD through its L2 (plain stores) where the placement allows
@@ -1093,7 +1094,8 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   const bool top_masked = masks != nullptr && L > 1;
   const bf16_t* Htop = top_masked ? w.Hd[L - 1] : (const bf16_t*)w.H[L - 1] + BW;
   // (one kernel where it applies -- V = 256, width 512: the logits never reach memory --, else GEMM + softmax)
-  const float inv_count = 1.0f / (h->last_only ? (float)B : (float)BT);
+  const int mean_rows = (h->loss_rows > 0 && h->loss_rows <= B) ? h->loss_rows : B;      // (a padded batch: the real streams)
+  const float inv_count = 1.0f / (h->last_only ? (float)mean_rows : (float)mean_rows * (float)T);
   int fe = KL_ERR_SHAPE;
   if (h->logits_ws && loss_acc != nullptr && w.rowstat != nullptr && V == Vp)
     fe = kl_launch_logits_ce_ws(Htop, d.E_hi, tgt, w.dlogits, w.rowstat, B, T, W, V, Vp, inv_count, h->last_only, s);
@@ -1725,6 +1727,12 @@ int run_graphed(kl_handle* h, const kl_handle::GraphKey& key, hipStream_t s, con
 
 }  // namespace
 
+extern "C" int kl_set_loss_rows(kl_handle* h, int rows) {
+  if (!h || rows < 0) return KL_ERR_ARG;
+  h->loss_rows = rows;
+  return 0;
+}
+
 extern "C" int kl_set_window_mode(kl_handle* h, int last_only) {
   if (!h) return KL_ERR_ARG;
   h->last_only = last_only ? 1 : 0;
@@ -1775,7 +1783,7 @@ extern "C" int kl_train_window(kl_handle* h, int B, int T, const int32_t* idx, c
   if (masks)
     KL_TRY(hip_ok(hipMemcpyAsync(w.s_masks, masks, (size_t)h->cfg.depth * B * h->cfg.width * sizeof(float),
                                  hipMemcpyDeviceToDevice, s)));
-  kl_handle::GraphKey key{1, B, T, (masks ? 1 : 0) | (h->last_only ? 4 : 0), h->precision, states, loss_acc, ws, grads};
+  kl_handle::GraphKey key{1, B, T, (masks ? 1 : 0) | (h->last_only ? 4 : 0), h->precision, states, loss_acc, ws, grads, h->loss_rows};      // (last field: the count baked into the captured launches)
   return run_graphed(h, key, s, [&]() {
     return train_window_body(h, B, T, w.s_idx, w.s_ctx, w.s_tgt, states, masks ? w.s_masks : nullptr, grads, loss_acc,
                              ws, ws_bytes, stream);

@@ -89,6 +89,8 @@ class HipLM:
         self.max_streams_per_launch = 0      # 0: what the kernels address (train_window splits larger batches into groups)
         self._part_grads = None
         self._part_loss = None
+        self._pad_states = {}
+        self.pad_streams = True              # pad a group of streams up to the next fast count (HipLM._padded_streams)
         self._step_ws = None
         self._step_ws_bytes = {}
         self.last_only = False
@@ -381,7 +383,8 @@ class HipLM:
                 if self.padded and masks_d.shape[-1] == self.width:      # (whatever the padded units get is multiplied by zero)
                     masks_d = torch.nn.functional.pad(masks_d, (0, self.pwidth - self.width), value=1.0).contiguous()
             parts = self._stream_groups(B, T)
-            if len(parts) == 1:
+            padded = [self._padded_streams(b1 - b0, T) for b0, b1 in parts]
+            if len(parts) == 1 and padded[0] == B:
                 ws = self._workspace(B, T, True)
                 hipabi.check(self.lib.kl_train_window(self.handle, B, T, _ptr(idx_d), _ptr(ctx_d), _ptr(tgt_d),
                                                       _ptr(self.states), _ptr(masks_d), _ptr(self.grads),
@@ -389,23 +392,50 @@ class HipLM:
                              "kl_train_window")
                 return
             # More streams than one launch sequence addresses (the scans index a layer's gate rows, T * B * 4W bf16, with 32-bit
-            # buffer offsets: 3072 streams at cfg2): the streams are independent, so the batch runs as groups of streams one
-            # after the other -- each on the persistent-scan path -- and the gradient of the mean over all B*T positions is
-            # the size-weighted sum of the groups' gradients (the regularisers' part is the same in every group: weights sum to 1).
+            # buffer offsets: 3072 streams at cfg2), or a count none of the fast kernels takes: the streams are independent, so
+            # the batch runs as groups of streams one after the other -- each on the persistent-scan path, a group that is just
+            # short of a fast count PADDED with dummy streams (targets -1: no loss, no gradient; kl_set_loss_rows keeps the
+            # means those over the real streams) -- and the gradient of the mean over all B*T positions is the size-weighted sum
+            # of the groups' gradients (the regularisers' part is the same in every group: the weights sum to 1).
             if self._part_grads is None:
                 self._part_grads = torch.zeros_like(self.grads)
             if self._part_loss is None:
                 self._part_loss = torch.zeros_like(self.loss_acc)
-            ws = self._workspace(max(b1 - b0 for b0, b1 in parts), T, True)
-            for i, (b0, b1) in enumerate(parts):
-                wgt = (b1 - b0) / B
+            ws = self._workspace(max(padded), T, True)
+            for i, ((b0, b1), Bp) in enumerate(zip(parts, padded)):
+                n = b1 - b0
+                wgt = n / B
                 self._part_loss.zero_()
-                m = masks_d[:, b0:b1].contiguous() if masks_d is not None else None
+                m = masks_d[:, b0:b1] if masks_d is not None else None
                 c = ctx_d[b0:b1] if ctx_d is not None else None
-                hipabi.check(self.lib.kl_train_window(self.handle, b1 - b0, T, _ptr(idx_d[b0:b1]), _ptr(c), _ptr(tgt_d[b0:b1]),
-                                                      _ptr(self.states[b0:b1]), _ptr(m), _ptr(self._part_grads),
-                                                      _ptr(self._part_loss), _ptr(ws), ws.numel(), self._stream()),
-                             "kl_train_window")
+                x, y, st = idx_d[b0:b1], tgt_d[b0:b1], self.states[b0:b1]
+                if Bp != n:
+                    x = torch.nn.functional.pad(x, (0, 0, 0, Bp - n))
+                    y = torch.nn.functional.pad(y, (0, 0, 0, Bp - n), value=-1)
+                    if c is not None:
+                        c = torch.nn.functional.pad(c, (0, 0) * (c.dim() - 1) + (0, Bp - n))
+                    if m is not None:
+                        # (the dummy streams' keep-masks repeat real streams': the register-tile backward scan keeps a mask as
+                        #  one bit per cell plus ONE scale per thread and refuses a mask with a second non-zero value)
+                        m = torch.cat([m, m[:, :Bp - n]], dim=1)
+                    st = self._pad_states.get(Bp)
+                    if st is None:      # (one buffer per padded count: its address is part of the replayed launch sequence's key)
+                        st = self._pad_states[Bp] = torch.zeros((Bp,) + tuple(self.states.shape[1:]), dtype=torch.float32,
+                                                                device=self.device)
+                    st[:n] = self.states[b0:b1]
+                    st[n:] = 0
+                    hipabi.check(self.lib.kl_set_loss_rows(self.handle, n), "kl_set_loss_rows")
+                if m is not None:
+                    m = m.contiguous()
+                try:
+                    hipabi.check(self.lib.kl_train_window(self.handle, Bp, T, _ptr(x), _ptr(c), _ptr(y), _ptr(st), _ptr(m),
+                                                          _ptr(self._part_grads), _ptr(self._part_loss), _ptr(ws), ws.numel(),
+                                                          self._stream()), "kl_train_window")
+                finally:
+                    if Bp != n:
+                        hipabi.check(self.lib.kl_set_loss_rows(self.handle, 0), "kl_set_loss_rows")
+                if Bp != n:
+                    self.states[b0:b1] = st[:n]
                 if i == 0:
                     torch.mul(self._part_grads, wgt, out=self.grads)
                     self.loss_acc[2] += self._part_loss[2]
@@ -413,6 +443,18 @@ class HipLM:
                     self.grads.add_(self._part_grads, alpha=wgt)
                 self.loss_acc[:2] += wgt * self._part_loss[:2]
                 self.loss_acc[3] = torch.maximum(self.loss_acc[3], self._part_loss[3])
+
+    def _padded_streams(self, n, T):
+        """the stream count a group of n streams is run at: the next count the second-generation scans take (width 512) if that
+        is at most 15 % more -- 1000 streams as 1024 run 36 % faster than on the first-generation scans --, else n"""
+        if self.pwidth != 512 or T < 3 or self.max_streams_per_launch or not self.pad_streams:
+            return n
+        fast = self.FAST_STREAMS[512][0]
+        limit = 0xfffffff0 // (T * 4 * self.pwidth * 2)
+        if n in fast:
+            return n
+        up = [f for f in fast if n < f <= limit and f <= 1.15 * n]
+        return min(up) if up else n
 
     def _rating_groups(self, B):
         """[(first, end)] stream ranges of a rating window (split precision): the persistent split-precision scans keep a
@@ -451,7 +493,9 @@ class HipLM:
         while B - b0 > 0:
             rem = B - b0
             take = rem
-            if fast and rem not in fast and (rem >= regroup_from or b0 > 0 or rem > limit):
+            if rem <= limit and self._padded_streams(rem, T) != rem:
+                pass      # (just short of a fast count: the whole rest, padded)
+            elif fast and rem not in fast and (rem >= regroup_from or b0 > 0 or rem > limit):
                 f = next((f for f in fast if f <= rem and (rem - f == 0 or rem - f >= 512)), None)
                 if f is not None:
                     take = f

@@ -54,6 +54,7 @@ SIGNATURES = {
                                  C.c_void_p]),
     "kl_trace_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "kl_set_window_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "kl_set_loss_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "kl_trace_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int]),
     "kl_trace_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int),
                                 C.POINTER(C.c_double)]),

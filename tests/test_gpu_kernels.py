@@ -660,6 +660,40 @@ def test_train_consecutive_windows_reuse_buffers(depth, width, voc, B, T):
         st = [got_st[:, k].astype(np.float64) for k in range(2 * depth)]
 
 
+@pytest.mark.parametrize("depth,width,voc,B,T,use_masks", [(2, 512, 64, 1000, 5, True), (2, 512, 64, 3000, 3, False), (3, 512, 40, 2500, 3, True),
+                                                           # (the register-tile backward scan: one mask scale per thread)
+                                                           (2, 512, 64, 3000, 8, True)])
+def test_train_window_padded_streams(depth, width, voc, B, T, use_masks):
+    """A stream count just short of one the second-generation scans take (1000 -> 1024, 3000 -> 3072; 2500 = 1536 + 964 -> 1024)
+    is padded with dummy streams (targets -1) and kl_set_loss_rows keeps the means those over the real streams: loss, accuracy,
+    gradients and the carried states of the real streams must equal those of the unpadded batch (HipLM.pad_streams = False:
+    first-generation scans)."""
+    from ocrd_keraslm_amd.lib import hipabi
+    cfg, w, _ = make_model(depth, width, voc)
+    rng = np.random.default_rng(14)
+    idx = rng.integers(1, voc, (B, T)); tgt = rng.integers(1, voc, (B, T))
+    tgt[rng.random((B, T)) < 0.05] = -1                      # (some padded positions among the real streams too)
+    ctx = rng.integers(0, 200, (B, 1, 1)).repeat(T, axis=1)
+    masks = ((rng.random((depth, B, width)) >= 0.1) / 0.9).astype(np.float32) if use_masks else None
+    res = {}
+    for name, pad in (("plain", False), ("padded", True)):
+        lm = make_model(depth, width, voc)[2]
+        lm.set_weights(w, hipabi.KL_PREC_BF16)
+        lm.pad_streams = pad
+        lm.reset_states(B)
+        lm.loss_acc.zero_()
+        for _ in range(2):
+            lm.train_window(idx, ctx, tgt, masks)
+        res[name] = (np.array(lm.read_loss()), lm.grads.cpu().numpy().copy(), lm.states.cpu().numpy().copy())
+        assert lm.states.shape[0] == B
+    assert any(lm._padded_streams(b1 - b0, T) != b1 - b0 for b0, b1 in lm._stream_groups(B, T))
+    l0, g0, s0 = res["plain"]; l1, g1, s1 = res["padded"]
+    assert abs(l0[0] - l1[0]) < 1e-3 * l0[0] and abs(l0[2] - l1[2]) < 1e-5 * abs(l0[2]), (l0, l1)
+    assert abs(l0[1] - l1[1]) < 2e-3, (l0, l1)
+    assert np.abs(s0 - s1).max() < 2e-2
+    assert np.linalg.norm(g0 - g1) < 2e-2 * np.linalg.norm(g0), np.linalg.norm(g0 - g1) / np.linalg.norm(g0)
+
+
 @pytest.mark.parametrize("depth,width,voc,B,T,limit,use_masks", [(2, 512, 64, 2048, 6, 1024, True), (2, 512, 64, 2560, 5, 1024, False),
                                                                  (2, 128, 40, 200, 7, 64, True)])
 def test_train_window_stream_groups(depth, width, voc, B, T, limit, use_masks):
