@@ -444,17 +444,55 @@ class HipLM:
                 self.loss_acc[:2] += wgt * self._part_loss[:2]
                 self.loss_acc[3] = torch.maximum(self.loss_acc[3], self._part_loss[3])
 
+    # Width 512, measured ms per training step at length 256 (tools/probe_shape_sweep.py): the second-generation scans' counts ...
+    FAST_MS = {1024: 10.0, 1536: 14.6, 2048: 18.9, 3072: 24.4}
+    # ... and the first-generation scans by started blocks of 512 streams (384 streams 6.3, 512: 6.8, 640: 10.3, 768: 10.9, 1280: 16.8,
+    # 1792: 18.4, 2560: 29.8, 3584: 42.1)
+    SLOW_MS = (0.0, 6.8, 10.9, 16.8, 18.4, 29.8, 36.0, 42.1, 48.0)
+
+    def _plan_512(self, B, limit):
+        """[(streams, run as)] for a batch of B streams at width 512: the cheapest way -- by the measured step times above, which
+        scale with the window length alike -- to cut it into groups that each run either as they are (a count the second-generation
+        scans take, or anything on the first-generation scans) or padded with dummy streams up to such a count."""
+        fast = {f: ms for f, ms in self.FAST_MS.items() if f <= limit}
+
+        def single(n):
+            best = (self.SLOW_MS[min(len(self.SLOW_MS) - 1, -(-n // 512))] * (1.0 if n >= 256 else 0.7), n) if n <= limit else (1e9, n)
+            for f, ms in fast.items():
+                if f >= n and ms < best[0] and self.pad_streams:
+                    best = (ms, f)
+                elif f == n and ms < best[0]:
+                    best = (ms, f)
+            return best
+
+        memo = {}
+
+        def plan(r):
+            if r in memo:
+                return memo[r]
+            ms, run = single(r)
+            best = (ms, [(r, run)])
+            for f, fms in fast.items():
+                if f < r:
+                    sub = plan(r - f)
+                    if fms + sub[0] + 0.3 < best[0]:      # (0.3 ms: a group's own launches, gradient accumulation)
+                        best = (fms + sub[0] + 0.3, [(f, f)] + sub[1])
+            memo[r] = best
+            return best
+
+        groups, rest = [], B
+        top = max(fast) if fast else 0
+        while top and rest > 2 * top:      # (far beyond the largest count: whole groups of it, the search only over the rest)
+            groups.append((top, top))
+            rest -= top
+        return groups + plan(rest)[1]
+
     def _padded_streams(self, n, T):
-        """the stream count a group of n streams is run at: the next count the second-generation scans take (width 512) if that
-        is at most 15 % more -- 1000 streams as 1024 run 36 % faster than on the first-generation scans --, else n"""
-        if self.pwidth != 512 or T < 3 or self.max_streams_per_launch or not self.pad_streams:
+        """the stream count a group of n streams is run at (see _plan_512), else n"""
+        if self.pwidth != 512 or T < 3 or self.max_streams_per_launch:
             return n
-        fast = self.FAST_STREAMS[512][0]
-        limit = 0xfffffff0 // (T * 4 * self.pwidth * 2)
-        if n in fast:
-            return n
-        up = [f for f in fast if n < f <= limit and f <= 1.15 * n]
-        return min(up) if up else n
+        plan = self._plan_512(n, 0xfffffff0 // (T * 4 * self.pwidth * 2))
+        return plan[0][1] if len(plan) == 1 else n
 
     def _rating_groups(self, B):
         """[(first, end)] stream ranges of a rating window (split precision): the persistent split-precision scans keep a
@@ -487,15 +525,19 @@ class HipLM:
         enough (FAST_STREAMS): then the largest such counts are peeled off as long as 512 streams or more remain
         (width 512: 2560 -> 2048 + 512, 3584 -> 3072 + 512, 4096 -> 3072 + 1024) and only the rest runs on the slower path."""
         limit = self.max_streams_per_launch or (0xfffffff0 // (T * 4 * self.pwidth * 2))
+        if self.pwidth == 512 and T >= 3 and not self.max_streams_per_launch:
+            parts, b0 = [], 0
+            for n, _run in self._plan_512(B, limit):
+                parts.append((b0, b0 + n))
+                b0 += n
+            return parts
         fast, regroup_from = self.FAST_STREAMS.get(self.pwidth, ((), 0))
         fast = [f for f in fast if f <= limit] if (T >= 3 and not self.max_streams_per_launch) else []
         parts, b0 = [], 0
         while B - b0 > 0:
             rem = B - b0
             take = rem
-            if rem <= limit and self._padded_streams(rem, T) != rem:
-                pass      # (just short of a fast count: the whole rest, padded)
-            elif fast and rem not in fast and (rem >= regroup_from or b0 > 0 or rem > limit):
+            if fast and rem not in fast and (rem >= regroup_from or b0 > 0 or rem > limit):
                 f = next((f for f in fast if f <= rem and (rem - f == 0 or rem - f >= 512)), None)
                 if f is not None:
                     take = f
