@@ -488,8 +488,15 @@ class HipLM:
         return groups + plan(rest)[1]
 
     def _padded_streams(self, n, T):
-        """the stream count a group of n streams is run at (see _plan_512), else n"""
-        if self.pwidth != 512 or T < 3 or self.max_streams_per_launch:
+        """the stream count a group of n streams is run at: width 512 see _plan_512; width 1024: the eight-wave scans give each of
+        their 8 row groups whole blocks of 16 streams, a step costs ~6.3 ms per started 128 streams (300 streams 21.6 ms, 384: 19.2;
+        1000: 59.6, 1024: 50.0) -- rounded up to a multiple of 128; else n"""
+        if T < 3 or self.max_streams_per_launch:
+            return n
+        if self.pwidth == 1024:
+            up = -(-n // 128) * 128
+            return up if (self.pad_streams and n > 128 and up <= 0xfffffff0 // (T * 4 * self.pwidth * 2)) else n
+        if self.pwidth != 512:
             return n
         plan = self._plan_512(n, 0xfffffff0 // (T * 4 * self.pwidth * 2))
         return plan[0][1] if len(plan) == 1 else n

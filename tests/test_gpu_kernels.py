@@ -662,7 +662,9 @@ def test_train_consecutive_windows_reuse_buffers(depth, width, voc, B, T):
 
 @pytest.mark.parametrize("depth,width,voc,B,T,use_masks", [(2, 512, 64, 1000, 5, True), (2, 512, 64, 3000, 3, False), (3, 512, 40, 2500, 3, True),
                                                            # (the register-tile backward scan: one mask scale per thread)
-                                                           (2, 512, 64, 3000, 8, True)])
+                                                           (2, 512, 64, 3000, 8, True),
+                                                           # width 1024: up to a multiple of 128 streams (the eight-wave scans' row groups)
+                                                           (2, 1024, 40, 300, 4, True)])
 def test_train_window_padded_streams(depth, width, voc, B, T, use_masks):
     """A stream count just short of one the second-generation scans take (1000 -> 1024, 3000 -> 3072; 2500 = 1536 + 964 -> 1024)
     is padded with dummy streams (targets -1) and kl_set_loss_rows keeps the means those over the real streams: loss, accuracy,
