@@ -519,6 +519,7 @@ def main():
     # ---- the reference's own model sizes (README.md:252-254: the published model is depth 2, width 128, length 256;
     # its README example width 64): training at 1024 streams and at the reference's batching
     ref_models = None
+    other_streams = None
     if rank == 0 and world == 1 and not args.no_extra_shapes:
         ref_models = {}
         for Wm in (128, 64):
@@ -533,6 +534,17 @@ def main():
                 ref_models["width_%d" % Wm] = {"error": repr(err)}
         ref_models["note"] = "depth 2, length 256, V=256, 1 context; width 128 = the published model's topology (README.md:252-254)"
         torch.cuda.empty_cache()
+        # cfg2 at stream counts beside the default: 1000 and 4096 streams (the engine pads / regroups such batches around the
+        # counts the persistent scans take, HipLM._stream_groups), 2 context variables at the default count
+        other_streams = {}
+        for name, nc, Bo in (("streams_1000", N_CTX, 1000), ("streams_4096", N_CTX, 4096), ("contexts_2_streams_%d" % B, 2, B)):
+            try:
+                leg, lmo = training_leg(device, DEPTH, WIDTH, LENGTH, nc, Bo, 10, 3, corpus)
+                del lmo
+                other_streams[name] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps", "mfma_frac")}
+            except Exception as err:
+                other_streams[name] = {"error": repr(err)}
+            torch.cuda.empty_cache()
 
     # ---- end to end: Rater.train over synthetic files (rank 0, one GPU): what the Python above the ABI costs
     end_to_end = None
@@ -565,7 +577,7 @@ def main():
                        # (a throughput run: the timed steps pass over each stream's windows several times, the loss means nothing)
                        "corpus_passes": (args.warmup + args.steps) / max(n_windows, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_torch": cpu_torch, "incremental": incremental,
-            "rating_window": rating, "small_batch": small_batch, "cfg5": cfg5, "reference_models": ref_models, "end_to_end": end_to_end,
+            "rating_window": rating, "small_batch": small_batch, "cfg5": cfg5, "reference_models": ref_models, "other_stream_counts": other_streams, "end_to_end": end_to_end,
         }
         print(json.dumps(line))
     if world > 1:
