@@ -1,10 +1,9 @@
 """Host-side latency of ONE incremental step as Rater.predict issues it (rating.py:578-639): the call itself, and the call
 plus the copy of the probabilities to the host -- the GPU idle in between, as in a beam search.
   python tools/probe_step_latency.py [n ...]"""
-import os, sys, time
+import sys, time
 import numpy as np, torch
 sys.path.insert(0, '.')
-from ocrd_keraslm_amd.lib import hipabi
 from ocrd_keraslm_amd.lib.engine import HipLM
 L, W, V = 2, 512, 256
 lm = HipLM(L, W, V, 1)
