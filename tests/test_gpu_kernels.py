@@ -249,6 +249,39 @@ def test_step_batch_repeatable_bitwise(depth, width, voc, n):
         assert np.array_equal(pool, runs[0][1])
 
 
+@pytest.mark.parametrize("depth,width,voc,n,n_ctx", [(2, 512, 256, 120, 1), (2, 512, 64, 700, 1), (3, 128, 40, 90, 2), (2, 1024, 64, 200, 1)])
+def test_step_batch_beam_pattern(depth, width, voc, n, n_ctx):
+    """The slots as a beam search uses them (rating.py:809-880): several hypotheses continue the SAME parent (slot_in with
+    repeats), their new states go to free slots anywhere in the pool, parents that nobody continues are dropped -- against
+    the f64 oracle, which is handed the gathered parent states."""
+    from ocrd_keraslm_amd.lib import hipabi
+    cfg, w, lm = make_model(depth, width, voc, n_ctx)
+    lm.set_weights(w, hipabi.KL_PREC_SPLIT)
+    n_slots = 3 * n + 5
+    lm.ensure_pool(n_slots)
+    lm.pool.zero_()
+    rng = np.random.default_rng(21)
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    ctx = rng.integers(0, 200, (n, n_ctx))
+    live = rng.permutation(n_slots)[:n]                        # slots of the current hypotheses (all-zero states)
+    st = O.zero_states(cfg, n, np.float64)                     # ... and the oracle's copy of them, row i <-> live[i]
+    worst = 0.0
+    for step in range(14):
+        parents = np.sort(rng.integers(0, n, n))               # row indices into `live`: repeats, and rows left out
+        slot_in = live[parents]
+        free = np.setdiff1d(np.arange(n_slots), slot_in)       # (a new state must not overwrite a state read in this call)
+        slot_out = rng.permutation(free)[:n]
+        idx = rng.integers(0, voc, n)
+        ref, st = O.step_batch(cfg, w64, idx, ctx, [s[parents] for s in st])
+        probs = lm.step_slots(idx, ctx, slot_in, slot_out).cpu().numpy()
+        worst = max(worst, np.abs(probs - ref).max())
+        live = slot_out
+    assert worst < 2e-5, worst
+    pool = lm.pool_read(live)
+    for k in range(2 * depth):
+        assert np.abs(pool[:, k] - st[k]).max() < 1e-4
+
+
 def test_state_dist2_matches_numpy():
     """kl_state_dist2 (history clustering, rating.py:887-916): squared distances between state entries of pool slots"""
     from ocrd_keraslm_amd.lib import hipabi
