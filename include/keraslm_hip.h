@@ -110,7 +110,8 @@ size_t kl_window_workspace_bytes(const kl_handle* h, int B, int T, int training)
  * accuracy are means over the B rows, the other positions carry no gradient. */
 int kl_set_window_mode(kl_handle* h, int last_only);
 
-/* Rows the means of kl_train_window are taken over: 0 (default) = its B.  A caller that PADS a batch with dummy streams
+/* Rows the means of kl_train_window (and of kl_forward_window in bf16 precision on a training-size workspace: validation
+ * windows) are taken over: 0 (default) = its B.  A caller that PADS a batch with dummy streams
  * (targets -1: no loss, no gradient) up to a stream count the persistent scans are instantiated for passes the real count
  * here, so that loss, accuracy and gradient stay those of the reference's mean over the real B*T positions
  * (rating.py:178, Keras' mean over the batch). */

@@ -1037,8 +1037,9 @@ static int forward_window_body(kl_handle* h, int B, int T, const int32_t* idx, c
     KL_TRY(forward_impl(h, B, T, idx, ctx, states, nullptr, 1, w, s));
     const bf16_t* Htop = (const bf16_t*)w.H[L - 1] + (size_t)B * W;
     KL_TRY(kl_launch_gemm_tn(Htop, h->d.E_hi, w.logits, nullptr, BT, V, W, W, W, V, 0, 1, 1.f, s));
-    KL_TRY(kl_launch_softmax_ce(w.logits, V, BT, V, tgt, B, T, 1.0f / (h->last_only ? (float)B : (float)BT), nullptr, 0,
-                                tgt ? loss_acc : nullptr, w.rowstat, 1, s, h->last_only));
+    const int mean_rows = (h->loss_rows > 0 && h->loss_rows <= B) ? h->loss_rows : B;      // (a padded batch: kl_set_loss_rows)
+    KL_TRY(kl_launch_softmax_ce(w.logits, V, BT, V, tgt, B, T, 1.0f / (h->last_only ? (float)mean_rows : (float)mean_rows * (float)T),
+                                nullptr, 0, tgt ? loss_acc : nullptr, w.rowstat, 1, s, h->last_only));
     if (probs) {
       if (B == 1) KL_TRY(hip_ok(hipMemcpyAsync(probs, w.logits, (size_t)T * V * sizeof(float), hipMemcpyDeviceToDevice, s)));
       else KL_TRY(kl_launch_rows_tm_to_bm(w.logits, V, probs, B, T, V, s));
@@ -1756,7 +1757,7 @@ extern "C" int kl_forward_window(kl_handle* h, int B, int T, const int32_t* idx,
   if (h->cfg.n_ctx > 0)
     KL_TRY(hip_ok(hipMemcpyAsync(w.s_ctx, ctx, BT * h->cfg.n_ctx * sizeof(int), hipMemcpyDeviceToDevice, s)));
   if (tgt) KL_TRY(hip_ok(hipMemcpyAsync(w.s_tgt, tgt, BT * sizeof(int), hipMemcpyDeviceToDevice, s)));
-  kl_handle::GraphKey key{0, B, T, (tgt ? 1 : 0) | (probs ? 2 : 0) | (h->last_only ? 4 : 0), h->precision, states, loss_acc, ws, nullptr, layout};
+  kl_handle::GraphKey key{0, B, T, (tgt ? 1 : 0) | (probs ? 2 : 0) | (h->last_only ? 4 : 0) | (h->loss_rows << 3), h->precision, states, loss_acc, ws, nullptr, layout};      // (loss_rows: baked into the captured launches)
   KL_TRY(run_graphed(h, key, s, [&]() {
     return forward_window_body(h, B, T, w.s_idx, w.s_ctx, tgt ? w.s_tgt : nullptr, states, probs ? w.s_probs : nullptr,
                                loss_acc, ws, ws_bytes, stream);

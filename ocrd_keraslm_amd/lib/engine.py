@@ -308,7 +308,10 @@ class HipLM:
             training_ws = self.precision == hipabi.KL_PREC_BF16
             probs = torch.empty((B, T, self.voc_size), dtype=torch.float32, device=self.device) if want_probs else None
             parts = self._stream_groups(B, T) if training_ws else self._rating_groups(B)
-            if len(parts) == 1:
+            # (validation windows -- bf16, a loss and no probabilities wanted -- are padded like training batches)
+            padded = [self._padded_streams(b1 - b0, T) if (training_ws and not want_probs and tgt_d is not None) else b1 - b0
+                      for b0, b1 in parts]
+            if len(parts) == 1 and padded[0] == B:
                 ws = self._workspace(B, T, training_ws)
                 hipabi.check(self.lib.kl_forward_window(self.handle, B, T, _ptr(idx_d), _ptr(ctx_d), _ptr(tgt_d),
                                                         _ptr(self.states), _ptr(probs), _ptr(self.loss_acc), _ptr(ws),
@@ -318,16 +321,35 @@ class HipLM:
                 # the means over the batch are the size-weighted sums of the groups' means)
                 if self._part_loss is None:
                     self._part_loss = torch.zeros_like(self.loss_acc)
-                ws = self._workspace(max(b1 - b0 for b0, b1 in parts), T, training_ws)
-                for b0, b1 in parts:
+                ws = self._workspace(max(padded), T, training_ws)
+                for (b0, b1), Bp in zip(parts, padded):
+                    n = b1 - b0
                     self._part_loss.zero_()
-                    hipabi.check(self.lib.kl_forward_window(self.handle, b1 - b0, T, _ptr(idx_d[b0:b1]),
-                                                            _ptr(ctx_d[b0:b1] if ctx_d is not None else None),
-                                                            _ptr(tgt_d[b0:b1] if tgt_d is not None else None),
-                                                            _ptr(self.states[b0:b1]), _ptr(probs[b0:b1] if probs is not None else None),
-                                                            _ptr(self._part_loss), _ptr(ws), ws.numel(), self._stream()),
-                                 "kl_forward_window")
-                    self.loss_acc[:2] += ((b1 - b0) / B) * self._part_loss[:2]
+                    x, c, st = idx_d[b0:b1], (ctx_d[b0:b1] if ctx_d is not None else None), self.states[b0:b1]
+                    y = tgt_d[b0:b1] if tgt_d is not None else None
+                    if Bp != n:
+                        x = torch.nn.functional.pad(x, (0, 0, 0, Bp - n))
+                        y = torch.nn.functional.pad(y, (0, 0, 0, Bp - n), value=-1)
+                        if c is not None:
+                            c = torch.nn.functional.pad(c, (0, 0) * (c.dim() - 1) + (0, Bp - n))
+                        st = self._pad_states.get(Bp)
+                        if st is None:
+                            st = self._pad_states[Bp] = torch.zeros((Bp,) + tuple(self.states.shape[1:]), dtype=torch.float32,
+                                                                    device=self.device)
+                        st[:n] = self.states[b0:b1]
+                        st[n:] = 0
+                        hipabi.check(self.lib.kl_set_loss_rows(self.handle, n), "kl_set_loss_rows")
+                    try:
+                        hipabi.check(self.lib.kl_forward_window(self.handle, Bp, T, _ptr(x), _ptr(c), _ptr(y), _ptr(st),
+                                                                _ptr(probs[b0:b1] if probs is not None else None),
+                                                                _ptr(self._part_loss), _ptr(ws), ws.numel(), self._stream()),
+                                     "kl_forward_window")
+                    finally:
+                        if Bp != n:
+                            hipabi.check(self.lib.kl_set_loss_rows(self.handle, 0), "kl_set_loss_rows")
+                    if Bp != n:
+                        self.states[b0:b1] = st[:n]
+                    self.loss_acc[:2] += (n / B) * self._part_loss[:2]
                     self.loss_acc[3] = torch.maximum(self.loss_acc[3], self._part_loss[3])
             if want_probs and float(self.loss_acc[3].item()) != 0.0:
                 # (the caller reads the probabilities next, so this sync is not an extra one)

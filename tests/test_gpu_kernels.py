@@ -721,8 +721,13 @@ def test_train_window_padded_streams(depth, width, voc, B, T, use_masks):
             lm.train_window(idx, ctx, tgt, masks)
         res[name] = (np.array(lm.read_loss()), lm.grads.cpu().numpy().copy(), lm.states.cpu().numpy().copy())
         assert lm.states.shape[0] == B
+        # ... and a validation window (bf16 forward, loss only): padded the same way
+        lm.forward_window(idx, ctx, tgt, want_probs=False)
+        res[name] += (np.array(lm.read_loss()), lm.states.cpu().numpy().copy())
     assert any(lm._padded_streams(b1 - b0, T) != b1 - b0 for b0, b1 in lm._stream_groups(B, T))
-    l0, g0, s0 = res["plain"]; l1, g1, s1 = res["padded"]
+    l0, g0, s0, v0, t0 = res["plain"]; l1, g1, s1, v1, t1 = res["padded"]
+    assert abs(v0[0] - v1[0]) < 2e-3 * v0[0] and abs(v0[1] - v1[1]) < 2e-3, (v0, v1)
+    assert np.abs(t0 - t1).max() < 3e-2
     assert abs(l0[0] - l1[0]) < 1e-3 * l0[0] and abs(l0[2] - l1[2]) < 1e-5 * abs(l0[2]), (l0, l1)
     assert abs(l0[1] - l1[1]) < 2e-3, (l0, l1)
     assert np.abs(s0 - s1).max() < 2e-2
