@@ -800,7 +800,9 @@ def test_handoff_flavours_agree_bitwise(B, windows, env):
 
 @pytest.mark.parametrize("depth,width,voc,B,T", [(2, 128, 50, 6, 12), (2, 512, 64, 128, 9), (1, 64, 30, 3, 5),
                                                  # big enough for the fused output layer (V = 256, width 512, B*T >= 8192)
-                                                 (2, 512, 256, 1024, 8)])
+                                                 (2, 512, 256, 1024, 8),
+                                                 # ... a batch the engine pads with dummy windows (1000 -> 1024): the means stay over 1000
+                                                 (2, 512, 64, 1000, 6)])
 def test_stateless_window_mode(depth, width, voc, B, T):
     """kl_set_window_mode(1): the reference's stateless graph (rating.py:126-129, 1123-1126) -- windows start
     from zero state, ONE target per window at its last position, loss / accuracy are means over the B
