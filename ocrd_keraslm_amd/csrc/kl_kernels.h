@@ -7,6 +7,30 @@
 
 typedef unsigned short bf16_t;
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the function ON A DEVICE: a launcher that needs more than 64 KiB
+// of dynamic LDS keeps, per kernel instantiation, what each device has been granted so far (one `static KlLdsGrant` per
+// instantiation) and sets the attribute only when a launch needs more -- the call costs microseconds, the incremental
+// step is a handful of them.  Safe against two threads stepping at once (the slow path is serialised).
+#include <atomic>
+#include <mutex>
+#define KL_MAX_DEVICES 64
+struct KlLdsGrant {
+  std::atomic<size_t> granted[KL_MAX_DEVICES];
+  std::mutex slow;
+};
+static inline int kl_grant_lds(KlLdsGrant& g, const void* fn, size_t lds) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return KL_ERR_LAUNCH;
+  if (dev < 0 || dev >= KL_MAX_DEVICES)      // (no room to remember: set it every time)
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : KL_ERR_LAUNCH;
+  if (lds <= g.granted[dev].load(std::memory_order_acquire)) return 0;
+  std::lock_guard<std::mutex> lock(g.slow);
+  if (lds <= g.granted[dev].load(std::memory_order_relaxed)) return 0;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;
+  g.granted[dev].store(lds, std::memory_order_release);
+  return 0;
+}
+
 // ---- gemm.hip -----------------------------------------------------------
 // recurrent halves of all layers' activation rows for the fused incremental step (step_big.hip)
 struct KlGatherRec {
@@ -274,7 +298,30 @@ struct KlIncCellArgs {
                                        // hi and lo planes interleaved per block when split == 3); KF null for layer 0
   const float* T1; const int* i1; const float* T2; const int* i2; const float* bias;    // z init: T1[i1[r]] + T2[i2[r]] + bias (null: none)
 };
-int kl_launch_inc_cell(const KlIncCellArgs& a, hipStream_t stream);      // KL_ERR_SHAPE: not applicable
+// kl_step_batch_host: the per-hypothesis indices of a step as part of the KERNEL ARGUMENTS (up to KL_HOST_STEP_MAX rows; 3 KiB of the
+// 4 KiB a dispatch may carry): pool slots as they are, characters and the one context variable as halfwords
+#define KL_HOST_STEP_MAX 256
+struct KlHostIdx {
+  int slot_in[KL_HOST_STEP_MAX];
+  int slot_out[KL_HOST_STEP_MAX];
+  unsigned short idx[KL_HOST_STEP_MAX];
+  unsigned short ctx[KL_HOST_STEP_MAX];
+};
+struct KlHostTargets { unsigned short t[KL_HOST_STEP_MAX]; };
+// what the last launch of a host-driven step delivers into (device-visible) host memory, see step_finish_kernel
+struct KlStepFinish {
+  int n, V, W;
+  const float* logits; long ld;      // device [n][V]: logits (softmax != 0) or probabilities
+  int softmax, by_target, head_k;
+  const int* target;                 // device, or null: KlHostTargets in the kernel arguments (n <= KL_HOST_STEP_MAX)
+  const float* pool; long slot_ld; const int* slot_out;      // device; heads = the first head_k * W floats of the new slots
+  float* probs_host; float* heads_host; unsigned* done_host; unsigned ticket;
+  unsigned* counter;                 // device, zero between steps
+};
+int kl_launch_step_finish(const KlStepFinish& a, const KlHostTargets* tx, hipStream_t stream);
+// hx != null: the indices come from *hx (slot_in / slot_out / the VALUES behind i1 / i2 of `a` are ignored; i1 / i2 non-null
+// still mean "table rows by index"); slots_copy (device, n ints) receives slot_out for the launches that follow
+int kl_launch_inc_cell(const KlIncCellArgs& a, hipStream_t stream, const KlHostIdx* hx = nullptr, int* slots_copy = nullptr);      // KL_ERR_SHAPE: not applicable
 
 // ---- step_tile.hip: the same for n >= KL_BIG_STEP_N, TR x 128 tiles with the operands read once (variant: timing builds, 0)
 int kl_launch_inc_tile(const KlIncCellArgs& a, int variant, hipStream_t stream, int rows = -1);      // KL_ERR_SHAPE: not applicable; rows: 64 / 128 per tile, -1 = by size

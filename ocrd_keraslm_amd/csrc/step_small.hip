@@ -73,7 +73,16 @@ struct IncCell {
   int h_off, c_off, x_off;          // float offsets inside a slot: this layer's h and c, the layer below's h (-1: layer 0)
   const bf16_t* UF; const bf16_t* KF;      // fragment-major [4W / 16][W / 32][planes][64][8]
   const float* T1; const int* i1; const float* T2; const int* i2; const float* bias;       // z init (tables [.][4W], bias [4W])
+  int* slots_copy;                  // HX kernels, layer 0: slot_out of every row is also left here for the launches behind
 };
+
+// HX kernels (kl_step_batch_host): the per-hypothesis indices arrive IN THE KERNEL ARGUMENTS (KlHostIdx, kl_kernels.h) -- the
+// dispatch packet's own memory, no copy to the device in front of the launch and no index array to chase through L2.  They are
+// read straight from the kernarg segment (constant address space: scalar loads where the row is uniform); the by-value
+// parameter itself is never named, so the compiler keeps no private copy of it.
+typedef const int __attribute__((address_space(4))) * kx_int_p;
+typedef const unsigned short __attribute__((address_space(4))) * kx_u16_p;
+constexpr int KX_OFF = (int)((sizeof(IncCell) + 7) & ~(size_t)7);      // offset of the KlHostIdx parameter behind IncCell
 
 // hardware exp2 / reciprocal gates (1 ulp each; step_tile.hip's): the ocml forms cost ~250 instructions per cell
 __device__ __forceinline__ float gate_sigmoid(float x) {
@@ -92,9 +101,17 @@ __device__ __forceinline__ float gate_tanh(float x) {
 // division in the staging (a wave stages whole rows), hardware exp2 / rcp gates.
 // GEN: widths 64 and 128 (the reference's README example and its published model), K = 64, 128 or 256 -- a wave instruction of the
 // staging covers several rows, or the x and the h part of one; else W is a multiple of 256 and a wave stages whole rows.
-template <int NMT, bool LO, bool GEN>
-__global__ __launch_bounds__(512) void inc_cell_kernel(const IncCell a) {
+template <int NMT, bool LO, bool GEN, bool HX>
+__device__ __forceinline__ void inc_cell_body(const IncCell& a) {
   constexpr int ROWS = 16 * NMT, NW = 8, RPW = ROWS / NW, NPL = LO ? 2 : 1;
+  const char __attribute__((address_space(4))) * const kx =
+      (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + KX_OFF;
+  auto slot_in_of = [&](int row) __attribute__((always_inline)) {
+    return HX ? ((kx_int_p)(kx + offsetof(KlHostIdx, slot_in)))[row] : a.slot_in[row];
+  };
+  auto slot_out_of = [&](int row) __attribute__((always_inline)) {
+    return HX ? ((kx_int_p)(kx + offsetof(KlHostIdx, slot_out)))[row] : a.slot_out[row];
+  };
   const int W = a.W;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,25 +138,32 @@ __global__ __launch_bounds__(512) void inc_cell_kernel(const IncCell a) {
 #pragma unroll
     for (int m = 0; m < NMT; ++m) {
       const int row = min(r0 + m * 16 + er, a.n - 1);
-      e_in[m] = a.slot_in[row];
-      e_out[m] = a.slot_out[row];
-      e_i1[m] = a.i1 ? a.i1[row] : row;
-      e_i2[m] = a.i2 ? a.i2[row] : row;
+      e_in[m] = slot_in_of(row);
+      e_out[m] = slot_out_of(row);
+      if (HX) {      // (a.i1 / a.i2 non-null only say "by index": the values are the kernel arguments')
+        e_i1[m] = a.i1 ? (int)((kx_u16_p)(kx + offsetof(KlHostIdx, idx)))[row] : row;
+        e_i2[m] = a.i2 ? (int)((kx_u16_p)(kx + offsetof(KlHostIdx, ctx)))[row] : row;
+      } else {
+        e_i1[m] = a.i1 ? a.i1[row] : row;
+        e_i2[m] = a.i2 ? a.i2[row] : row;
+      }
     }
   }
+  if (HX && a.slots_copy && blockIdx.x == 0 && wave == 7 && lane < ROWS && r0 + lane < a.n)
+    a.slots_copy[r0 + lane] = slot_out_of(r0 + lane);
   // the slots of this wave's RPW staging rows (uniform addresses: scalar loads); GEN: lane r < ROWS holds the slots of row r
   int sl_in[RPW], sl_out[RPW];
   int sl_all_in = 0, sl_all_out = 0;
   if (GEN) {
     const int row = min(r0 + (lane < ROWS ? lane : 0), a.n - 1);
-    sl_all_in = a.slot_in[row];
-    sl_all_out = a.slot_out[row];
+    sl_all_in = slot_in_of(row);
+    sl_all_out = slot_out_of(row);
   }
 #pragma unroll
   for (int rr = 0; rr < RPW; ++rr) {
     const int row = min(r0 + wave * RPW + rr, a.n - 1);
-    sl_in[rr] = GEN ? 0 : a.slot_in[row];
-    sl_out[rr] = GEN ? 0 : a.slot_out[row];
+    sl_in[rr] = GEN ? 0 : slot_in_of(row);
+    sl_out[rr] = GEN ? 0 : slot_out_of(row);
   }
 
   const int nks = K >> 5, nks_x = Kx >> 5;         // k-steps of 32; the first nks_x belong to x . K
@@ -353,7 +377,72 @@ __global__ __launch_bounds__(512) void inc_cell_kernel(const IncCell a) {
 #endif
 }
 
+template <int NMT, bool LO, bool GEN>
+__global__ __launch_bounds__(512) void inc_cell_kernel(const IncCell a) {
+  inc_cell_body<NMT, LO, GEN, false>(a);
+}
+
+// ... with the indices in the kernel arguments (hx is read through the kernarg segment pointer, see KX_OFF)
+template <int NMT, bool LO, bool GEN>
+__global__ __launch_bounds__(512) void inc_cell_hx_kernel(const IncCell a, const KlHostIdx hx) {
+  inc_cell_body<NMT, LO, GEN, true>(a);
+}
+
 constexpr size_t LDS_LIMIT = 150 * 1024;
+
+// ---- last launch of a host-driven step (kl_step_batch_host): softmax over the logits rows (the arithmetic of
+// softmax_ce_kernel: first maximum, expf, one division) and delivery INTO HOST MEMORY -- the probabilities (whole rows, or per
+// row the one character the caller will look at), optionally the first head_k state vectors of every new state (history
+// clustering, rating.py:887-916) --, then one word that tells the waiting host thread that everything has arrived: every
+// workgroup fences its stores at system scope and takes a ticket, the last one resets the counter and writes `ticket` to
+// *done (the host spins on that word instead of synchronising with the stream: kl_step_wait).
+constexpr int FX_OFF = (int)((sizeof(KlStepFinish) + 7) & ~(size_t)7);      // offset of the KlHostTargets parameter
+__global__ __launch_bounds__(256) void step_finish_kernel(const KlStepFinish a, const KlHostTargets tx) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row < a.n) {
+    const float* x = a.logits + (long)row * a.ld;
+    int t = -1;
+    if (a.by_target) {
+      if (a.target) t = a.target[row];
+      else t = ((kx_u16_p)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + FX_OFF))[row];
+    }
+    float mx = 0.f, inv = 1.f;
+    if (a.softmax) {
+      mx = -INFINITY;
+      for (int v = lane; v < a.V; v += 64) mx = fmaxf(mx, x[v]);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+      float sum = 0.f;
+      for (int v = lane; v < a.V; v += 64) sum += expf(x[v] - mx);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+      inv = 1.f / sum;
+    }
+    if (a.by_target) {
+      if (lane == 0) a.probs_host[row] = (t >= 0 && t < a.V) ? (a.softmax ? expf(x[t] - mx) * inv : x[t]) : 0.f;
+    } else {
+      float* out = a.probs_host + (long)row * a.V;
+      for (int v = lane; v < a.V; v += 64) out[v] = a.softmax ? expf(x[v] - mx) * inv : x[v];
+    }
+    if (a.head_k > 0) {
+      const float4* src = reinterpret_cast<const float4*>(a.pool + (long)a.slot_out[row] * a.slot_ld);
+      float4* dst = reinterpret_cast<float4*>(a.heads_host + (long)row * a.head_k * a.W);
+      const int n4 = a.head_k * a.W / 4;      // (the head vectors are the first head_k * W floats of a slot; W % 4 == 0)
+      for (int i = lane; i < n4; i += 64) dst[i] = src[i];
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned got = atomicAdd(a.counter, 1u);
+    if (got == gridDim.x - 1) {
+      atomicExch(a.counter, 0u);
+      __threadfence_system();
+      __hip_atomic_store(a.done_host, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
 
 }  // namespace
 
@@ -365,9 +454,11 @@ extern "C" int kl_test_read_inc_stamps(unsigned long long* out) {
 
 // one LSTM cell step of layer `l` for n hypotheses with pool slots; KL_ERR_SHAPE = not applicable (the caller takes the
 // launch-per-layer kernels of lstm_step.hip).
-int kl_launch_inc_cell(const KlIncCellArgs& p, hipStream_t stream) {
+int kl_launch_inc_cell(const KlIncCellArgs& p, hipStream_t stream, const KlHostIdx* hx, int* slots_copy) {
   const int W = p.W;
-  if (p.n < 1 || ((W & 255) && W != 64 && W != 128) || !p.pool || !p.slot_in || !p.slot_out || !p.UF) return KL_ERR_SHAPE;
+  if (p.n < 1 || ((W & 255) && W != 64 && W != 128) || !p.pool || !p.UF) return KL_ERR_SHAPE;
+  if (!hx && (!p.slot_in || !p.slot_out)) return KL_ERR_SHAPE;
+  if (hx && p.n > KL_HOST_STEP_MAX) return KL_ERR_SHAPE;
   const bool lo = p.split == 3;
   if (p.x_off >= 0 && !p.KF) return KL_ERR_ARG;
   const int K = p.x_off >= 0 ? 2 * W : W;
@@ -382,15 +473,18 @@ int kl_launch_inc_cell(const KlIncCellArgs& p, hipStream_t stream) {
   a.h_off = p.h_off; a.c_off = p.c_off; a.x_off = p.x_off;
   a.UF = p.UF; a.KF = p.KF;
   a.T1 = p.T1; a.i1 = p.i1; a.T2 = p.T2; a.i2 = p.i2; a.bias = p.bias;
+  a.slots_copy = slots_copy;
   dim3 grid(W / 16, (p.n + 16 * nmt - 1) / (16 * nmt));
 #define KL_IC_CASE(NMT_, LO_, GEN_)                                                                                         \
   do {                                                                                                                      \
-    static size_t granted = 0;      /* (per instantiation: the attribute is set when a launch needs more than any before) */ \
-    if (lds > granted) {                                                                                                    \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&inc_cell_kernel<NMT_, LO_, GEN_>),                            \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;   \
-      granted = lds;                                                                                                        \
+    if (hx) {                                                                                                               \
+      static KlLdsGrant grant_hx;                                                                                           \
+      if (kl_grant_lds(grant_hx, reinterpret_cast<const void*>(&inc_cell_hx_kernel<NMT_, LO_, GEN_>), lds)) return KL_ERR_LAUNCH; \
+      hipLaunchKernelGGL((inc_cell_hx_kernel<NMT_, LO_, GEN_>), grid, dim3(512), lds, stream, a, *hx);                      \
+      break;                                                                                                                \
     }                                                                                                                       \
+    static KlLdsGrant grant;                                                                                                \
+    if (kl_grant_lds(grant, reinterpret_cast<const void*>(&inc_cell_kernel<NMT_, LO_, GEN_>), lds)) return KL_ERR_LAUNCH;   \
     hipLaunchKernelGGL((inc_cell_kernel<NMT_, LO_, GEN_>), grid, dim3(512), lds, stream, a);                                \
   } while (0)
 #define KL_IC_CASE2(NMT_, LO_) do { if (gen) KL_IC_CASE(NMT_, LO_, true); else KL_IC_CASE(NMT_, LO_, false); } while (0)
@@ -398,5 +492,14 @@ int kl_launch_inc_cell(const KlIncCellArgs& p, hipStream_t stream) {
   else { if (lo) KL_IC_CASE2(1, true); else KL_IC_CASE2(1, false); }
 #undef KL_IC_CASE2
 #undef KL_IC_CASE
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+int kl_launch_step_finish(const KlStepFinish& a, const KlHostTargets* tx, hipStream_t stream) {
+  if (a.n < 1 || !a.logits || !a.probs_host || !a.done_host || !a.counter) return KL_ERR_ARG;
+  if (a.head_k > 0 && (!a.pool || !a.slot_out || !a.heads_host || (a.W & 3))) return KL_ERR_ARG;
+  if (a.by_target && !a.target && (!tx || a.n > KL_HOST_STEP_MAX)) return KL_ERR_ARG;
+  static const KlHostTargets none = {};
+  hipLaunchKernelGGL(step_finish_kernel, dim3((a.n + 3) / 4), dim3(256), 0, stream, a, tx ? *tx : none);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }

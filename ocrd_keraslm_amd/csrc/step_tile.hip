@@ -601,12 +601,8 @@ static int launch_inc_tile(const KlIncCellArgs& p, int variant, hipStream_t stre
   if (lds < (size_t)TR * (TC + 4) * 4) lds = (size_t)TR * (TC + 4) * 4;      // ... or the epilogue's f32 tile
 #define KL_IT_CASE(LO_, VAR_)                                                                                               \
   do {                                                                                                                      \
-    static size_t granted = 0;      /* (per instantiation: the attribute is set when a launch needs more than any before) */ \
-    if (lds > granted) {                                                                                                    \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&inc_tile_kernel<TR, LO_, VAR_>),                              \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;   \
-      granted = lds;                                                                                                        \
-    }                                                                                                                       \
+    static KlLdsGrant grant;        /* (per instantiation and device: the attribute is set when a launch needs more than any before) */ \
+    if (kl_grant_lds(grant, reinterpret_cast<const void*>(&inc_tile_kernel<TR, LO_, VAR_>), lds)) return KL_ERR_LAUNCH;     \
     hipLaunchKernelGGL((inc_tile_kernel<TR, LO_, VAR_>), dim3(a.nx * a.ny), dim3(512), lds, stream, a);                     \
   } while (0)
   if (!lo) KL_IT_CASE(false, 0);
@@ -644,12 +640,9 @@ int kl_launch_out_softmax(const float* pool, long slot_ld, const int* slot_out, 
   const size_t lds = (size_t)(lo ? 2 : 1) * 16 * W * 2 + (size_t)16 * 260 * 4;
   if (lds > 150 * 1024) return KL_ERR_SHAPE;
   const dim3 grid((n + 15) / 16);
-  static size_t granted[2] = {0, 0};      // (per instantiation: the attribute is set when a launch needs more than any before)
-  if (lds > granted[lo]) {
-    const void* fn = lo ? reinterpret_cast<const void*>(&out_softmax_kernel<true>) : reinterpret_cast<const void*>(&out_softmax_kernel<false>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;
-    granted[lo] = lds;
-  }
+  static KlLdsGrant grant[2];      // (per instantiation and device: the attribute is set when a launch needs more than any before)
+  const void* fn = lo ? reinterpret_cast<const void*>(&out_softmax_kernel<true>) : reinterpret_cast<const void*>(&out_softmax_kernel<false>);
+  if (kl_grant_lds(grant[lo], fn, lds)) return KL_ERR_LAUNCH;
   if (lo) hipLaunchKernelGGL(out_softmax_kernel<true>, grid, dim3(512), lds, stream, a);
   else hipLaunchKernelGGL(out_softmax_kernel<false>, grid, dim3(512), lds, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;

@@ -30,20 +30,23 @@ def test_cfg3_full_size_chained_parity():
         lm.set_weights(w, prec)
         lm.ensure_pool(2 * n)
         engines[name] = lm
-    st = O.zero_states(cfg, n, np.float64)
+    # the engines step all 1024 hypotheses; the f64 oracle follows a quarter of them (hypotheses are independent rows:
+    # 256 rows drawn over all sixteen 64-row tiles, first and last row included) -- the oracle was 50 of this test's 60 s
+    sub = np.unique(np.concatenate([[0, n - 1], rng.choice(n, 254, replace=False)]))
+    st = O.zero_states(cfg, len(sub), np.float64)
     a, b = np.arange(n), np.arange(n, 2 * n)
     drift = {k: np.zeros(steps) for k in engines}
-    rows = np.arange(n)
+    rows = np.arange(len(sub))
     t0 = time.time()
     for s in range(steps):
-        ref, st = O.step_batch(cfg, w64, ids[s], ctx, st)
+        ref, st = O.step_batch(cfg, w64, ids[s][sub], ctx[sub], st)
         for name, lm in engines.items():
-            probs = lm.step_slots(ids[s], ctx, a, b).cpu().numpy()
+            probs = lm.step_slots(ids[s], ctx, a, b)[sub].cpu().numpy()
             drift[name][s] = np.abs(probs - ref).max()
         a, b = b, a
         # north_star's own criterion: the probability of the character that actually comes next
         if s + 1 < steps:
-            nxt = ids[s + 1]
+            nxt = ids[s + 1][sub]
             assert np.all(np.isfinite(ref[rows, nxt]))
     oracle_s = time.time() - t0
     d = drift["split"]
@@ -57,6 +60,6 @@ def test_cfg3_full_size_chained_parity():
     assert d.max() < 1e-3, (d.max(), int(d.argmax()))
     assert np.all(np.isfinite(db)) and db.max() < 5e-2
     # carried states after 512 steps (split precision)
-    pool = engines["split"].pool_read(a)
+    pool = engines["split"].pool_read(a)[sub]
     for k in range(2 * depth):
         assert np.abs(pool[:, k] - st[k]).max() < 1e-3, k

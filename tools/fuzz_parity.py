@@ -9,6 +9,7 @@ sys.path.insert(0, '.')
 from oracle import lstm_oracle as O
 from ocrd_keraslm_amd.lib import hipabi
 from ocrd_keraslm_amd.lib.engine import HipLM
+from tests.gradcheck import gradient_table
 
 
 
@@ -41,15 +42,14 @@ def run(n_cases, seed, verbose=True):
       om = ([None] + [masks[l].astype(np.float64) for l in range(1, depth)]) if use_masks else None
       ref_p, ref_st, cache = O.forward_window(cfg, w64, idx, ctx, [s.astype(np.float64) for s in st0], om, keep_cache=True)
       ce, acc, _ = O.crossentropy(ref_p, tgt)
-      g_ref = O.backward_window(cfg, w64, idx, ctx, tgt, ref_p, cache, om)
+      g_data = O.backward_window(cfg, w64, idx, ctx, tgt, ref_p, cache, om, with_regularisers=False)
       lm.loss_acc.zero_()
       lm.train_window(idx, ctx, tgt, masks)
       l, a, r = lm.read_loss()
-      grads = lm.get_grads()
-      worst = 0.0
-      for name, off, rows, cols in lm.layout:
-          got = grads[name].reshape(g_ref[name].shape)
-          worst = max(worst, np.abs(got - g_ref[name]).max() / (np.abs(g_ref[name]).max() + 1e-12))
+      # (E / Ctx*: the total AND the back-propagated part alone, tests/gradcheck.py)
+      table = gradient_table(lm.layout, lm.get_grads(), g_data, O.regulariser_grads(cfg, w64))
+      worst = max(max(e["max_over_maxnorm"], e.get("data_max_over_maxnorm", 0.0) if e.get("data_ref_norm", 0.0) > 0 else 0.0)
+                  for e in table.values())
       st = lm.get_states()
       sterr = max(np.abs(st[:, k] - ref_st[k]).max() for k in range(2 * depth))
       # rating window in split precision from the same start
