@@ -149,6 +149,27 @@ size_t kl_step_workspace_bytes(const kl_handle* h, int n);
 int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, float* pool, const int32_t* slot_in,
                   const int32_t* slot_out, float* probs, void* ws, size_t ws_bytes, void* stream);
 
+/* The same step as a BEAM SEARCH issues it (rating.py:809-826 rate_best, :689-691 generate, each through
+ * Rater.predict, rating.py:578-639): one call per character with the GPU idle in between, so what counts is the time
+ * from the call to the numbers being in the caller's hands, not the kernels' own.  Differences to kl_step_batch:
+ *   - idx, ctx, slot_in, slot_out (and target) are HOST arrays; up to 256 hypotheses they travel inside the kernel
+ *     arguments of the launches (no copy to the device, no index array for the kernels to chase), beyond that in one copy;
+ *   - the results are delivered into HOST memory the device can write (kl_host_alloc): probs_host receives [n][V], or --
+ *     target != NULL -- [n]: per row the probability of character target[i] alone (all a lattice decoder looks at,
+ *     rating.py:838-843); head_k > 0 also delivers the first head_k state vectors of every new state, [n][head_k][W]
+ *     (history clustering compares exactly those, rating.py:887-916);
+ *   - nothing has to synchronise with the stream: *done_host becomes `ticket` once everything above has arrived
+ *     (kl_step_wait spins on that word; use a different ticket for every step).
+ * pool, ws: device.  ws_bytes >= kl_step_host_workspace_bytes(h, n); one workspace per handle and stream. */
+void* kl_host_alloc(size_t bytes);      /* zeroed, page-locked, device-visible host memory; NULL on failure */
+void kl_host_free(void* p);
+size_t kl_step_host_workspace_bytes(const kl_handle* h, int n);
+int kl_step_batch_host(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, const int32_t* slot_in,
+                       const int32_t* slot_out, const int32_t* target, float* pool, int head_k, float* probs_host,
+                       float* heads_host, uint32_t* done_host, uint32_t ticket, void* ws, size_t ws_bytes, void* stream);
+/* returns 0 once *done_host == ticket; KL_ERR_LAUNCH / KL_ERR_STATE after timeout_s seconds without it */
+int kl_step_wait(const uint32_t* done_host, uint32_t ticket, double timeout_s);
+
 /* Squared L2 distances between state vectors of pool slots, for beam history
  * clustering (rating.py:887-916): out[i] = || pool[a[i]][k] - pool[b[i]][k] ||^2
  * for state entry k (0 = h1, 1 = c1, ...). */

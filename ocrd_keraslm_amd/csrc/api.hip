@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <functional>
 #include <utility>
@@ -117,6 +118,9 @@ struct kl_handle {
   bool scan_enabled = true;     // persistent scans (KL_SCAN=0 forces the launch-per-step path)
   bool seq_bwd = true;          // layer-sequential backward scans for many row blocks (KL_SEQ_BWD=0: always fused)
   bool wide_bwd = true;         // ... with 64-unit workgroups (KL_WIDE_BWD=0: thin workgroups)
+  void* host_step_ready = nullptr;      // kl_step_batch_host: the workspace whose ticket counter has been zeroed
+  std::vector<int32_t> host_pack;       // ... its packed index block for the copy to the device (n > 256, fall-backs)
+  bool host_kernarg = true;             // ... indices in the kernel arguments (KL_HOST_KERNARG=0: always the copy)
   bool inc_ready = false;       // the incremental step's fragment-major operands match the current weights (prepare_incremental)
   bool big_ready = false;       // ... and those of the gather + GEMM path (prepare_big_step)
   int last_only = 0;            // stateless windows: one target per row, at the last position (kl_set_window_mode)
@@ -977,6 +981,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   if (env6n) h->out_fused_min = atoi(env6n);
   const char* env6o = getenv("KL_INC_SMALL_MIN");
   if (env6o) h->inc_small_min = atoi(env6o);
+  const char* env6p = getenv("KL_HOST_KERNARG");
+  h->host_kernarg = !(env6p && env6p[0] == '0');
   const char* env8 = getenv("KL_SCAN2");
   if (env8) h->scan2 = atoi(env8) != 0;
   const char* env8b = getenv("KL_SCAN2_ROWS");
@@ -1629,6 +1635,140 @@ int kl_step_batch(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, f
   KL_TRY(kl_launch_thin_gemm(&op, n, V, probs, V, nullptr, split, s));
   KL_TRY(kl_launch_softmax_ce(probs, V, n, V, nullptr, n, 1, 1.f, nullptr, 0, nullptr, nullptr, 0, s));
   return 0;
+}
+
+// ---- the incremental step as a beam search issues it: one step per character, the GPU idle in between ----------------
+// (rating.py:809-826 rate_best, :689-691 generate: predict -> look at the probabilities -> decide -> predict ...)
+void* kl_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return nullptr;
+  memset(p, 0, bytes);
+  return p;
+}
+
+void kl_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
+size_t kl_step_host_workspace_bytes(const kl_handle* h, int n) {
+  if (!h || n < 1) return 0;
+  Carver cv(nullptr);
+  cv.take<unsigned>(64);                                             // the finish launch's ticket counter (zero between steps)
+  cv.take<float>((size_t)n * h->cfg.voc_size);                      // logits / probabilities
+  cv.take<int32_t>((size_t)n * (4 + (h->cfg.n_ctx > 0 ? h->cfg.n_ctx : 1)));      // indices on the device (n > 256 and fall-backs)
+  return align_up(cv.off, 256) + kl_step_workspace_bytes(h, n);
+}
+
+int kl_step_batch_host(kl_handle* h, int n, const int32_t* idx, const int32_t* ctx, const int32_t* slot_in,
+                       const int32_t* slot_out, const int32_t* target, float* pool, int head_k, float* probs_host,
+                       float* heads_host, uint32_t* done_host, uint32_t ticket, void* ws, size_t ws_bytes, void* stream) {
+  if (!h || !idx || !pool || !slot_in || !slot_out || !probs_host || !done_host || n < 1) return KL_ERR_ARG;
+  if (h->cfg.n_ctx > 0 && !ctx) return KL_ERR_ARG;
+  if (head_k < 0 || head_k > 2 * h->cfg.depth || (head_k > 0 && !heads_host)) return KL_ERR_ARG;
+  if (!h->precision) return KL_ERR_STATE;
+  if (!ws || ws_bytes < kl_step_host_workspace_bytes(h, n)) return KL_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const kl_config& c = h->cfg;
+  const int W = c.width, L = c.depth, V = c.voc_size, C = c.n_ctx;
+  const long slot_ld = (long)2 * L * W;
+  Derived& d = h->d;
+  Carver cv(ws);
+  unsigned* counter = cv.take<unsigned>(64);
+  float* logits = cv.take<float>((size_t)n * V);
+  int32_t* dev_idx = cv.take<int32_t>((size_t)n * (4 + (C > 0 ? C : 1)));
+  unsigned char* rest = reinterpret_cast<unsigned char*>(ws) + align_up(cv.off, 256);
+  const size_t rest_bytes = ws_bytes - align_up(cv.off, 256);
+  if (!h->host_step_ready) {      // (the counter of a fresh workspace; afterwards every finish launch leaves it zero)
+    KL_TRY(kl_zero_async(counter, 64 * sizeof(unsigned), s));
+    h->host_step_ready = ws;
+  } else if (h->host_step_ready != ws) {
+    KL_TRY(kl_zero_async(counter, 64 * sizeof(unsigned), s));
+    h->host_step_ready = ws;
+  }
+  KlStepFinish f;
+  memset(&f, 0, sizeof(f));
+  f.n = n; f.V = V; f.W = W; f.logits = logits; f.ld = V;
+  f.by_target = target != nullptr; f.head_k = head_k;
+  f.pool = pool; f.slot_ld = slot_ld;
+  f.probs_host = probs_host; f.heads_host = heads_host; f.done_host = done_host; f.ticket = ticket; f.counter = counter;
+  // ---- up to 256 hypotheses on the 16-unit cell kernels: every index travels in the kernel arguments
+  bool in_range = n <= KL_HOST_STEP_MAX && V <= 65535 && C == 1 && h->inc_small && d.EF && h->host_kernarg;
+  for (int i = 0; i < n && in_range; ++i)
+    in_range = idx[i] >= 0 && idx[i] < V && ctx[i] >= 0 && ctx[i] < c.ctx_vocab && (!target || (target[i] >= 0 && target[i] < V));
+  if (in_range && ((W & 255) == 0 || W == 64 || W == 128) && !(W >= 1024 && n > 128)) {
+    static thread_local KlHostIdx hx;
+    static thread_local KlHostTargets tx;
+    for (int i = 0; i < n; ++i) {
+      hx.slot_in[i] = slot_in[i]; hx.slot_out[i] = slot_out[i];
+      hx.idx[i] = (unsigned short)idx[i]; hx.ctx[i] = (unsigned short)ctx[i];
+      if (target) tx.t[i] = (unsigned short)target[i];
+    }
+    if (!h->inc_ready) KL_TRY(prepare_incremental(h, s));
+    const int split = h->precision;
+    const float* P = h->params;
+    int e = 0;
+    for (int l = 0; l < L && e == 0; ++l) {
+      KlIncCellArgs a;
+      memset(&a, 0, sizeof(a));
+      a.n = n; a.W = W; a.split = split;
+      a.pool = pool; a.slot_ld = slot_ld;
+      a.h_off = 2 * l * W; a.c_off = (2 * l + 1) * W; a.x_off = l > 0 ? 2 * (l - 1) * W : -1;
+      a.UF = d.UF[l]; a.KF = d.KF[l];
+      a.bias = P + h->off_b[l];
+      if (l == 0) {      // (i1 / i2 non-null = "table rows by index"; the values are hx's)
+        a.T1 = d.EK; a.i1 = dev_idx; a.T2 = d.CtxK[0]; a.i2 = dev_idx;
+      }
+      e = kl_launch_inc_cell(a, s, &hx, l == 0 ? dev_idx : nullptr);
+      if (e == KL_ERR_SHAPE && l > 0) return e;
+    }
+    if (e == 0) {
+      KlOperand op;
+      memset(&op, 0, sizeof(op));
+      op.A = pool + (size_t)2 * (L - 1) * W; op.lda = slot_ld; op.row_index = dev_idx; op.a_is_f32 = 1;
+      op.WT_hi = d.E_hi; op.WT_lo = split == 3 ? d.E_lo : nullptr; op.ldw = W; op.K = W;
+      KL_TRY(kl_launch_thin_gemm(&op, n, V, logits, V, nullptr, split, s));
+      f.softmax = 1; f.slot_out = dev_idx;
+      return kl_launch_step_finish(f, target ? &tx : nullptr, s);
+    }
+    if (e != KL_ERR_SHAPE) return e;
+  }
+  // ---- everything else: ONE copy of the packed indices to the device, the device-pointer step, delivery by the finish launch
+  {
+    const int Cc = C > 0 ? C : 1;
+    std::vector<int32_t>& pk = h->host_pack;
+    pk.resize((size_t)n * (4 + Cc));
+    memcpy(pk.data(), idx, (size_t)n * 4);
+    memcpy(pk.data() + n, slot_in, (size_t)n * 4);
+    memcpy(pk.data() + 2 * (size_t)n, slot_out, (size_t)n * 4);
+    if (target) memcpy(pk.data() + 3 * (size_t)n, target, (size_t)n * 4);
+    else memset(pk.data() + 3 * (size_t)n, 0, (size_t)n * 4);
+    if (C > 0) memcpy(pk.data() + 4 * (size_t)n, ctx, (size_t)n * C * 4);
+    if (hipMemcpyAsync(dev_idx, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess) return KL_ERR_LAUNCH;
+    KL_TRY(kl_step_batch(h, n, dev_idx, C > 0 ? dev_idx + 4 * (size_t)n : nullptr, pool, dev_idx + n, dev_idx + 2 * (size_t)n, logits,
+                         rest, rest_bytes, stream));
+    f.softmax = 0; f.slot_out = dev_idx + 2 * (size_t)n;
+    f.target = target ? dev_idx + 3 * (size_t)n : nullptr;
+    return kl_launch_step_finish(f, nullptr, s);
+  }
+}
+
+int kl_step_wait(const uint32_t* done_host, uint32_t ticket, double timeout_s) {
+  if (!done_host) return KL_ERR_ARG;
+  const volatile uint32_t* flag = done_host;
+  struct timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (unsigned spins = 0;; ++spins) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ticket) return 0;
+    __builtin_ia32_pause();
+    if ((spins & 0x3ff) == 0x3ff) {
+      struct timespec t1;
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > timeout_s) {
+        // (a failed launch never writes the word: report what the runtime says rather than spin for ever)
+        return hipGetLastError() == hipSuccess ? KL_ERR_STATE : KL_ERR_LAUNCH;
+      }
+    }
+  }
 }
 
 int kl_state_dist2(const kl_handle* h, int n, const float* pool, const int32_t* a, const int32_t* b, int k, float* out,

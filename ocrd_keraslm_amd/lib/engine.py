@@ -92,12 +92,16 @@ class HipLM:
         self._pad_states = {}
         self.pad_streams = True              # pad a group of streams up to the next fast count (HipLM._padded_streams)
         self._step_ws = None
+        self._step_host_ws = None
+        self._hio = None
         self._step_ws_bytes = {}
         self.last_only = False
         self._rng = np.random.default_rng(0)
 
     def __del__(self):
         try:
+            if getattr(self, "_hio", None) is not None:
+                self._host_io_free()
             if getattr(self, "handle", None):
                 self.lib.kl_destroy(self.handle)
                 self.handle = None
@@ -648,6 +652,66 @@ class HipLM:
         heads = self.pool.index_select(0, so.long())[:, :k, :self.width].reshape(n, -1)
         both = torch.cat([probs, heads], dim=1).cpu().numpy()
         return both[:, :self.voc_size], both[:, self.voc_size:].reshape(n, k, self.width)
+
+    # ---- the step as a beam search issues it (kl_step_batch_host): host indices in, host results out, no stream synchronisation
+    def _host_io(self, n, head_k):
+        """page-locked, device-visible host buffers (kl_host_alloc) for up to n hypotheses: probabilities, head vectors,
+        the arrival word; kept and grown as needed"""
+        io = getattr(self, "_hio", None)
+        if io is not None and io["n"] >= n and io["head_k"] >= head_k:
+            return io
+        if io is not None:
+            self._host_io_free()
+        n_cap = max(256, 1 << (n - 1).bit_length())
+        sizes = {"probs": n_cap * self.voc_size * 4, "heads": max(1, n_cap * head_k * self.pwidth) * 4, "done": 64}
+        io = {"n": n_cap, "head_k": head_k, "ticket": 0, "ptr": {}, "np": {}}
+        for name, nbytes in sizes.items():
+            ptr = self.lib.kl_host_alloc(nbytes)
+            if not ptr:
+                raise hipabi.KlError("kl_host_alloc(%d) failed" % nbytes)
+            io["ptr"][name] = ptr
+            ctype = C.c_uint32 if name == "done" else C.c_float
+            io["np"][name] = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(nbytes // 4,))
+        self._hio = io
+        return io
+
+    def _host_io_free(self):
+        io = getattr(self, "_hio", None)
+        if io is not None:
+            self._hio = None
+            self.torch.cuda.synchronize(self.device)      # (nothing may still be writing into the buffers)
+            for ptr in io["ptr"].values():
+                self.lib.kl_host_free(ptr)
+
+    def step_host(self, idx, ctx, slot_in, slot_out, target=None, head_k=0, timeout=20.0):
+        """One LSTM step for n hypotheses with HOST index arrays, results on the HOST (numpy): `Rater.predict`'s arithmetic
+        (rating.py:578-639) at the latency a beam search sees.  Returns (probs, heads): probs [n][V], or [n] -- the
+        probability of character target[i] for every row -- when `target` is given; heads [n][head_k][W] (the first head_k
+        state vectors of the new states) or None.  The returned arrays are the caller's (copies of the delivery buffers)."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32).reshape(-1)
+        n = idx.shape[0]
+        ctx = np.ascontiguousarray(ctx, dtype=np.int32).reshape(n, -1) if self.n_ctx else None
+        si = np.ascontiguousarray(slot_in, dtype=np.int32).reshape(-1)
+        so = np.ascontiguousarray(slot_out, dtype=np.int32).reshape(-1)
+        tg = np.ascontiguousarray(target, dtype=np.int32).reshape(-1) if target is not None else None
+        io = self._host_io(n, head_k)
+        nws = self._step_ws_bytes.get(("host", n))
+        if nws is None:
+            nws = self._step_ws_bytes[("host", n)] = int(self.lib.kl_step_host_workspace_bytes(self.handle, n))
+        if self._step_host_ws is None or self._step_host_ws.numel() < nws:
+            self._step_host_ws = self.torch.empty(nws, dtype=self.torch.uint8, device=self.device)
+        io["ticket"] = ticket = (io["ticket"] % 0x7fffffff) + 1
+        stream = C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+        hipabi.check(self.lib.kl_step_batch_host(
+            self.handle, n, idx.ctypes.data, ctx.ctypes.data if ctx is not None else None, si.ctypes.data, so.ctypes.data,
+            tg.ctypes.data if tg is not None else None, _ptr(self.pool), int(head_k), io["ptr"]["probs"], io["ptr"]["heads"],
+            io["ptr"]["done"], ticket, _ptr(self._step_host_ws), self._step_host_ws.numel(), stream), "kl_step_batch_host")
+        hipabi.check(self.lib.kl_step_wait(io["ptr"]["done"], ticket, float(timeout)), "kl_step_wait")
+        probs = io["np"]["probs"][:n].copy() if tg is not None else io["np"]["probs"][:n * self.voc_size].reshape(n, -1).copy()
+        heads = None
+        if head_k:
+            heads = io["np"]["heads"][:n * head_k * self.pwidth].reshape(n, head_k, self.pwidth)[:, :, :self.width].copy()
+        return probs, heads
 
     def to_device_i32(self, a):
         """one host-to-device transfer of an int32 array (rows stay contiguous views)"""

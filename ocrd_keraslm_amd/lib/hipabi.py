@@ -50,6 +50,13 @@ SIGNATURES = {
     "kl_step_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "kl_step_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "kl_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "kl_host_free": (None, [C.c_void_p]),
+    "kl_step_host_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "kl_step_batch_host": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
+    "kl_step_wait": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double]),
     "kl_state_dist2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                  C.c_void_p]),
     "kl_trace_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -115,18 +115,25 @@ class EdgeTracks(object):
             out.append(self.text[self.alt[i]][p - 1] if p else self.incoming[self.parent[i]].value[-1])
         return out
 
+    def targets(self, rows):
+        """id of the character each track of the batch consumes next (the one whose probability `advance` looks at)"""
+        rows = np.asarray(rows)
+        return np.fromiter((self.ids[a][p] for a, p in zip(self.alt[rows], self.pos[rows])), dtype=np.int64, count=len(rows))
+
     def advance(self, rows, probs, new_states):
-        """consume one character on every track of the batch"""
+        """consume one character on every track of the batch; probs: [n, V] rows, or [n] -- already the probabilities
+        of `targets(rows)`"""
         rows = np.asarray(rows)
         alt, pos = self.alt[rows], self.pos[rows]
-        target = np.fromiter((self.ids[a][p] for a, p in zip(alt, pos)), dtype=np.int64, count=len(rows))
+        target = self.targets(rows)
         if not target.all():
             for k, (a, p) in enumerate(zip(alt, pos)):
                 if self.unmapped[a][p] and self.text[a][p] not in self.reported[a]:
                     self.reported[a].add(self.text[a][p])
                     self.logger.error('unmapped character "%s" at input alternative %d of element %s', self.text[a][p],
                                       self.alternatives[a].index or k, self.element.id if self.element else "space")
-        p_next = np.maximum(np.asarray(probs, dtype=np.float64)[np.arange(len(rows)), target], 1e-99)
+        probs = np.asarray(probs, dtype=np.float64)
+        p_next = np.maximum(probs if probs.ndim == 1 else probs[np.arange(len(rows)), target], 1e-99)
         # (math.log(p, 2) element by element, as the reference computes it (rating.py:843): np.log2 -- and numpy's own log --
         #  can differ from libm in the last bit, and ties and the +2.5 / +15 margins are decided on exact values)
         lg = np.fromiter((log(x, 2) for x in p_next.tolist()), dtype=np.float64, count=len(rows))
@@ -147,7 +154,8 @@ class EdgeTracks(object):
 def decode_edge(tracks, finished, predict, batch_size, max_batches, close_states=None):
     """Walk all tracks of an edge through their alternatives (rating.py:796-851).
 
-    predict(last_chars, states) -> (probs [n, V], new states); close_states(a, b) -> whether two state handles are
+    predict(last_chars, states, targets) -> (probs, new states) with probs [n, V] or -- an engine that delivers only what
+    is looked at -- [n], the probabilities of the characters `targets`; close_states(a, b) -> whether two state handles are
     within the clustering distance (None: no history clustering).  Finished tracks end up in `finished`."""
     # the waiting list: track numbers + keys.  It starts in creation order (UNSORTED, as in the reference, whose first
     # batch is therefore cut off the end of the creation order) and is kept sorted from the first re-queueing on.
@@ -175,7 +183,7 @@ def decode_edge(tracks, finished, predict, batch_size, max_batches, close_states
         if len(finished) and tracks.cum[batch[0]] >= finished.best_cost(tracks) + FINISHED_MARGIN:
             break
         # ---- one character on every track of the batch
-        probs, new_states = predict(tracks.last_chars(batch), [tracks.state[i] for i in batch])
+        probs, new_states = predict(tracks.last_chars(batch), [tracks.state[i] for i in batch], tracks.targets(batch))
         tracks.advance(batch, probs, new_states)
         # ---- back into the waiting list, unless hopeless against its current head
         nkeys = tracks.keys(np.asarray(batch))

@@ -820,22 +820,35 @@ class Rater(object):
         c_i = self.mapping[0]
         return np.fromiter((c_i.get(c, 0) for c in candidates), dtype=np.int32, count=len(candidates))
 
-    def _predict_refs(self, candidates, states, context, heads=False):
+    def _predict_refs(self, candidates, states, context, heads=False, targets=None):
         """device-resident variant of predict(): states are StateRef (or None = zero
         state); returns (probs [n,V] float32 array, list of new StateRef).  All index vectors travel to
         the GPU in ONE transfer; with `heads` the first `depth` vectors of every new state come back with
         the probabilities, so that history clustering (rating.py:887-916) compares them on the host
-        instead of synchronising with the GPU once per candidate pair."""
+        instead of synchronising with the GPU once per candidate pair.
+
+        An engine with `step_host` (HipLM: kl_step_batch_host) takes the index vectors as host arrays inside its launches
+        and delivers into host memory without a stream synchronisation; with `targets` (the character ids a lattice
+        decoder will look at, rating.py:838-843) it returns probs [n] -- those probabilities alone."""
         pool = self._state_pool()
         n = len(candidates)
         new = [pool.ref() for _ in range(n)]
         ctx = np.asarray(windows.clamp_context(context), dtype=np.int32)
+        lm = self.model
+        if hasattr(lm, "step_host"):
+            slot_in = np.fromiter((s.slot if s is not None else pool.zero_slot for s in states), dtype=np.int32, count=n)
+            slot_out = np.fromiter((r.slot for r in new), dtype=np.int32, count=n)
+            probs, hv = lm.step_host(self._ids(candidates), np.broadcast_to(ctx, (n, len(ctx))), slot_in, slot_out,
+                                     target=targets, head_k=self.depth if heads else 0)
+            if heads:
+                for r, v in zip(new, hv):
+                    r.head = v
+            return probs, new
         packed = np.empty((3 + len(ctx), n), dtype=np.int32)
         packed[0] = self._ids(candidates)
         packed[1] = np.fromiter((s.slot if s is not None else pool.zero_slot for s in states), dtype=np.int32, count=n)
         packed[2] = np.fromiter((r.slot for r in new), dtype=np.int32, count=n)
         packed[3:] = ctx[:, None]
-        lm = self.model
         hv = None
         if hasattr(lm, "to_device_i32"):
             dev = lm.to_device_i32(packed)
@@ -953,8 +966,8 @@ class Rater(object):
         graph.nodes[start_node]['traceback'] = start_traceback[0]
         clustering = bool(beam_clustering_dist)
 
-        def predict(chars, states):
-            return self._predict_refs(chars, states, context, heads=clustering)
+        def predict(chars, states, targets=None):
+            return self._predict_refs(chars, states, context, heads=clustering, targets=targets)
 
         def close_states(a, b):
             return all(self._state_distance_below(a, b, k, beam_clustering_dist) for k in range(self.depth))

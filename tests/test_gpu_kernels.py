@@ -283,6 +283,73 @@ def test_step_batch_beam_pattern(depth, width, voc, n, n_ctx):
         assert np.abs(pool[:, k] - st[k]).max() < 1e-4
 
 
+@pytest.mark.parametrize("depth,width,voc,n,n_ctx,env", [
+    # kernel-argument indices (n <= 256, one context variable, widths 64 / 128 / multiples of 256): one and two row tiles
+    (2, 512, 256, 120, 1, {}), (2, 512, 256, 30, 1, {}), (2, 512, 64, 256, 1, {}), (2, 128, 60, 128, 1, {}), (3, 256, 40, 7, 1, {}),
+    (2, 64, 50, 200, 1, {}), (4, 1024, 64, 100, 1, {}), (2, 512, 256, 1, 1, {}),
+    # the same shape through the copy of the packed indices (the fall-back of everything below)
+    (2, 512, 256, 120, 1, {"KL_HOST_KERNARG": "0"}),
+    # what the kernel-argument form does not take: more than 256 rows, 0 / 2 context variables, padded widths, width 1024 beyond 128 rows
+    (2, 512, 64, 700, 1, {}), (3, 128, 40, 90, 2, {}), (2, 512, 64, 40, 0, {}), (2, 100, 50, 30, 1, {}), (2, 1024, 64, 200, 1, {})])
+def test_step_host_beam_pattern(monkeypatch, depth, width, voc, n, n_ctx, env):
+    """kl_step_batch_host (the step as rate_best / generate issue it, rating.py:809-826, 689-691): HOST index arrays, results
+    delivered into host memory and awaited on the arrival word -- with the slots as a beam search uses them (repeated
+    parents, new states anywhere in the pool), alternating between whole probability rows and the per-row target
+    probability, with and without the head vectors of the new states; against the f64 oracle."""
+    from ocrd_keraslm_amd.lib import hipabi
+    with monkeypatch.context() as mp:
+        for k, v in env.items():
+            mp.setenv(k, v)
+        cfg, w, lm = make_model(depth, width, voc, n_ctx)      # (the switches are read when the handle is created)
+    lm.set_weights(w, hipabi.KL_PREC_SPLIT)
+    n_slots = 3 * n + 5
+    lm.ensure_pool(n_slots)
+    lm.pool.zero_()
+    rng = np.random.default_rng(22)
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    ctx = rng.integers(0, 200, (n, n_ctx))
+    live = rng.permutation(n_slots)[:n]
+    st = O.zero_states(cfg, n, np.float64)
+    worst = worst_head = 0.0
+    for step in range(12):
+        parents = np.sort(rng.integers(0, n, n))
+        slot_in = live[parents]
+        free = np.setdiff1d(np.arange(n_slots), slot_in)
+        slot_out = rng.permutation(free)[:n]
+        idx = rng.integers(0, voc, n)
+        ref, st = O.step_batch(cfg, w64, idx, ctx, [s[parents] for s in st])
+        head_k = (0, depth, 1)[step % 3]
+        if step % 2:
+            target = rng.integers(0, voc, n)
+            probs, heads = lm.step_host(idx, ctx, slot_in, slot_out, target=target, head_k=head_k)
+            assert probs.shape == (n,)
+            worst = max(worst, np.abs(probs - ref[np.arange(n), target]).max())
+        else:
+            probs, heads = lm.step_host(idx, ctx, slot_in, slot_out, head_k=head_k)
+            assert probs.shape == (n, voc)
+            worst = max(worst, np.abs(probs - ref).max())
+        if head_k:
+            assert heads.shape == (n, head_k, width)
+            for k in range(head_k):
+                worst_head = max(worst_head, np.abs(heads[:, k] - st[k]).max())
+        else:
+            assert heads is None
+        live = slot_out
+    assert worst < 2e-5, worst
+    assert worst_head < 1e-4, worst_head
+    pool = lm.pool_read(live)
+    for k in range(2 * depth):
+        assert np.abs(pool[:, k] - st[k]).max() < 1e-4
+    # ... and interleaved with the device-pointer entry point on the same pool
+    idx = rng.integers(0, voc, n)
+    free = np.setdiff1d(np.arange(n_slots), live)
+    out_a, out_b = free[:n], free[n:2 * n]
+    p_dev = lm.step_slots(idx, ctx, live, out_a).cpu().numpy()
+    p_host, _ = lm.step_host(idx, ctx, live, out_b)
+    assert np.abs(p_dev - p_host).max() < 5e-6
+    assert np.abs(lm.pool_read(out_a) - lm.pool_read(out_b)).max() < 2e-5
+
+
 def test_state_dist2_matches_numpy():
     """kl_state_dist2 (history clustering, rating.py:887-916): squared distances between state entries of pool slots"""
     from ocrd_keraslm_amd.lib import hipabi
