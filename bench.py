@@ -417,15 +417,18 @@ def main():
         lm.prepare(hipabi.KL_PREC_SPLIT)
         legs = {}
         for N, S in ((1024, 512), (128, 512), (32, 512)):
-            # (a leg lasts 10-20 ms: measured twice, the faster one kept -- the first may still see the clocks ramp up)
-            runs = [incremental_leg(lm, device, DEPTH, WIDTH, N_CTX, N, S, seed=3 + rank) for _ in range(2)]
-            legs[N] = dict(min(runs, key=lambda r: r["us_per_step"]), best_of=2)
+            # (a leg lasts 10-20 ms: measured five times -- the first may still see the clocks ramp up --, the MEDIAN reported)
+            runs = sorted((incremental_leg(lm, device, DEPTH, WIDTH, N_CTX, N, S, seed=3 + rank) for _ in range(5)),
+                          key=lambda r: r["us_per_step"])
+            legs[N] = dict(runs[len(runs) // 2], median_of=len(runs), fastest_us_per_step=runs[0]["us_per_step"],
+                           slowest_us_per_step=runs[-1]["us_per_step"])
         if world > 1:
             t = torch.tensor([legs[1024]["value"], legs[128]["value"]], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             legs[1024]["value"], legs[128]["value"] = float(t[0].item()), float(t[1].item())
         incremental = {"value": legs[1024]["value"], "unit": "hypotheses*chars/s", "hypotheses": 1024, "chars": 512,
-                       "precision": "split-bf16 (3 MFMA passes)", "n_gpus": world, "best_of": 2,
+                       "precision": "split-bf16 (3 MFMA passes)", "n_gpus": world, "median_of": 5,
+                       "fastest_us_per_step": legs[1024]["fastest_us_per_step"], "slowest_us_per_step": legs[1024]["slowest_us_per_step"],
                        "us_per_step": legs[1024]["us_per_step"], "gpu_us_per_step": legs[1024]["gpu_us_per_step"],
                        "algorithmic_bytes_per_step": legs[1024]["algorithmic_bytes_per_step"],
                        "hbm_frac": legs[1024]["hbm_frac"], "mfma_frac": legs[1024]["mfma_frac"],
@@ -437,6 +440,27 @@ def main():
                        "n32": {"value": legs[32]["value"], "hypotheses": 32, "us_per_step": legs[32]["us_per_step"],
                                "gpu_us_per_step": legs[32]["gpu_us_per_step"],
                                "note": "a beam of 10 with 3 alternatives per edge (rate_best's default width, rating.py:712); this rank's GPU"}}
+
+    # ---- the step as a beam search sees it (rating.py:809-826): one call per character, the GPU idle in between, wall time
+    # from the call to the probabilities in host memory; and Rater.rate_best itself on a synthetic 600-edge page lattice
+    beam = None
+    if not args.no_incremental and rank == 0 and world == 1:
+        try:
+            import importlib.util
+            def _tool(name):
+                spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", name + ".py"))
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                return mod
+            beam = _tool("probe_step_latency").run((30, 128), DEPTH, WIDTH, VOC, steps=400, skip=100)
+            beam["rate_best_ms_per_edge"] = _tool("probe_rate_best").run(600, pages=3, clustering=0)
+            beam["rate_best_clustering_ms_per_edge"] = _tool("probe_rate_best").run(600, pages=3, clustering=5)
+            beam["note"] = ("median wall microseconds of ONE incremental step with the GPU idle before it: device_entry = index copy + "
+                            "kl_step_batch + copy of the probabilities back (round 3's Rater._predict_refs); host_entry = kl_step_batch_host "
+                            "(indices in the kernel arguments, delivery into host memory, arrival word) with whole rows / only the target "
+                            "characters' probabilities / plus the head vectors history clustering compares")
+        except Exception as err:      # (diagnostic block: never costs the metric line)
+            beam = {"error": repr(err)}
 
     # ---- rating windows (rate / rate2 / test): the stateful windowed forward in split precision with probabilities out,
     # at the reference's batching (1 stream x 256 chars, rating.py:490) and at 64 streams; rank 0 reports its own GPU
@@ -578,7 +602,7 @@ def main():
                        "parallelism": "dp%d" % world,
                        # (a throughput run: the timed steps pass over each stream's windows several times, the loss means nothing)
                        "corpus_passes": (args.warmup + args.steps) / max(n_windows, 1)},
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_torch": cpu_torch, "incremental": incremental,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_torch": cpu_torch, "incremental": incremental, "beam_step_latency": beam,
             "rating_window": rating, "small_batch": small_batch, "cfg5": cfg5, "reference_models": ref_models, "other_stream_counts": other_streams, "end_to_end": end_to_end,
         }
         print(json.dumps(line))

@@ -120,12 +120,13 @@ class EdgeTracks(object):
         rows = np.asarray(rows)
         return np.fromiter((self.ids[a][p] for a, p in zip(self.alt[rows], self.pos[rows])), dtype=np.int64, count=len(rows))
 
-    def advance(self, rows, probs, new_states):
+    def advance(self, rows, probs, new_states, target=None):
         """consume one character on every track of the batch; probs: [n, V] rows, or [n] -- already the probabilities
-        of `targets(rows)`"""
+        of `targets(rows)` (`target`: that array, if the caller has it)"""
         rows = np.asarray(rows)
         alt, pos = self.alt[rows], self.pos[rows]
-        target = self.targets(rows)
+        if target is None:
+            target = self.targets(rows)
         if not target.all():
             for k, (a, p) in enumerate(zip(alt, pos)):
                 if self.unmapped[a][p] and self.text[a][p] not in self.reported[a]:
@@ -183,8 +184,9 @@ def decode_edge(tracks, finished, predict, batch_size, max_batches, close_states
         if len(finished) and tracks.cum[batch[0]] >= finished.best_cost(tracks) + FINISHED_MARGIN:
             break
         # ---- one character on every track of the batch
-        probs, new_states = predict(tracks.last_chars(batch), [tracks.state[i] for i in batch], tracks.targets(batch))
-        tracks.advance(batch, probs, new_states)
+        target = tracks.targets(batch)
+        probs, new_states = predict(tracks.last_chars(batch), [tracks.state[i] for i in batch], target)
+        tracks.advance(batch, probs, new_states, target)
         # ---- back into the waiting list, unless hopeless against its current head
         nkeys = tracks.keys(np.asarray(batch))
         for i, key in zip(batch, nkeys):

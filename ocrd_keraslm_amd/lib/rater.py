@@ -101,6 +101,15 @@ class StatePool(object):
     def ref(self):
         return StateRef(self, self.take())
 
+    def refs(self, n):
+        """n fresh handles at once (a beam search takes one per hypothesis and character)"""
+        while len(self.free) < n:
+            self._grow(2 * self.capacity)
+        slots = self.free[-n:]
+        del self.free[-n:]
+        slots.reverse()                      # (the order `take` would have handed them out in)
+        return [StateRef(self, slot) for slot in slots], slots
+
     def fetch(self, slot):
         return self.engine.pool_read([slot])[0]
 
@@ -832,18 +841,19 @@ class Rater(object):
         decoder will look at, rating.py:838-843) it returns probs [n] -- those probabilities alone."""
         pool = self._state_pool()
         n = len(candidates)
-        new = [pool.ref() for _ in range(n)]
         ctx = np.asarray(windows.clamp_context(context), dtype=np.int32)
         lm = self.model
         if hasattr(lm, "step_host"):
-            slot_in = np.fromiter((s.slot if s is not None else pool.zero_slot for s in states), dtype=np.int32, count=n)
-            slot_out = np.fromiter((r.slot for r in new), dtype=np.int32, count=n)
-            probs, hv = lm.step_host(self._ids(candidates), np.broadcast_to(ctx, (n, len(ctx))), slot_in, slot_out,
+            new, slots = pool.refs(n)
+            zero = pool.zero_slot
+            slot_in = np.array([s.slot if s is not None else zero for s in states], dtype=np.int32)
+            probs, hv = lm.step_host(self._ids(candidates), np.tile(ctx, (n, 1)), slot_in, np.array(slots, dtype=np.int32),
                                      target=targets, head_k=self.depth if heads else 0)
             if heads:
                 for r, v in zip(new, hv):
                     r.head = v
             return probs, new
+        new = [pool.ref() for _ in range(n)]
         packed = np.empty((3 + len(ctx), n), dtype=np.int32)
         packed[0] = self._ids(candidates)
         packed[1] = np.fromiter((s.slot if s is not None else pool.zero_slot for s in states), dtype=np.int32, count=n)
