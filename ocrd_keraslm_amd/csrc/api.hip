@@ -151,6 +151,10 @@ struct kl_handle {
   bool scan2_bf16 = true;       // KL_SCAN2_BF16=0: f32 instead of bf16 for what the scans exchange with later kernels (P, dH, c for backward)
   bool logits_ws = true;        // KL_LOGITS_WS = 0: GEMM + softmax kernel for the training window's output layer instead of the fused kernel
   bool proj_ws = true;          // KL_PROJ_WS = 0: the ring GEMM for the gate inputs P of the second-generation scans too
+  bool fwd8 = false;            // KL_FWD8 = 1: the eight-wave, barrier-free forward scan (lstm_scan_fwd8.hip) where it applies -- correct, but
+                                // no faster than the 16-wave kernel yet (3.49 against 3.44 ms per launch at 3072 streams)
+  bool fwd8_local = true;       // KL_FWD8_LOCAL = 0: write-through publishes in the eight-wave forward scan even where its partners share an XCD
+  int fwd8_pf = -1;             // KL_FWD8_PF = 0..3: where it requests its tiles (default by phases per step)
   bool rt_local = true;         // KL_RT_LOCAL = 0: write-through publishes in the register-tile backward scan even where its partners share an XCD
   bool regtile = true;          // KL_REGTILE = 0: the backward scan's tiles by LDS-DMA at every size (else through registers from five blocks per step)
   bool scan2_flags = true;      // KL_SCAN2_FLAGS = 0: the backward scan hands over by data sentinels at every size (else by flags from three blocks per step)
@@ -510,6 +514,8 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       a.B = B; a.T = T; a.W = W;
       a.UT = d.UT_hi[l];
       const bool v2 = w.scan2_rows != 0;
+      // the eight-wave scan (lstm_scan_fwd8.hip) takes bf16 P rows only: layer 0's gate inputs are gathered in front of it
+      const bool f8 = v2 && h->fwd8 && w.scan2_rows == 32 && h->scan2_bf16 && h->sentinel_roll && T >= 3;
       if (l > 0) {
         const bool masked_in = masks != nullptr && (l - 1) > 0;
         const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
@@ -524,7 +530,7 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
         KL_TRY(pe);
         a.P = w.P1;
         a.p_bf16 = v2 && h->scan2_bf16 ? 1 : 0;
-      } else if (v2 && c.n_ctx > 1) {
+      } else if (v2 && (c.n_ctx > 1 || f8)) {
         // several context variables: the scan's table mode adds ONE context row to the character row, so the gate inputs
         // of layer 0 are gathered into P rows first (as the layers above get them from proj_ws_kernel)
         KL_TRY(kl_launch_p_gather_il(d.EKp, d.CtxKp.data(), c.n_ctx, idx, ctx, B, T, W, c.voc_size, c.ctx_vocab,
@@ -567,11 +573,21 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       // (two phases ahead needs the rows to have been published a phase before the request: three or more phases per workgroup)
       a.pf_mode = h->scan2_pf >= 0 ? h->scan2_pf : (v2 && kl_scan_wide2_phases(B, T, W, w.scan2_rows, 4) >= 3 ? 2 : 1);
       if (l == L - 1) h->trace_begin(0, s);
-      if (v2) KL_TRY(kl_launch_scan_fwd_wide2(a, w.scan2_rows, s));
+      bool took8 = false;
+      if (f8 && a.sentinel == 2) {
+        KlScanFwdWide a8 = a;
+        a8.xcc_slots = h->fwd8_local ? w.scan_status + 4 : nullptr;
+        a8.pf_mode = h->fwd8_pf >= 0 ? h->fwd8_pf : 1;
+        const int e8 = kl_launch_scan_fwd8(a8, s);
+        if (e8 != KL_ERR_SHAPE) KL_TRY(e8);
+        took8 = e8 == 0;
+      }
+      if (took8) {}
+      else if (v2) KL_TRY(kl_launch_scan_fwd_wide2(a, w.scan2_rows, s));
       else KL_TRY(kl_launch_scan_fwd_wide(a, s));
       if (l == L - 1) {
         h->trace_persistent[0] = true;
-        h->trace_name[0] = v2 ? "lstm_scan_fwd_wide2_kernel" : "lstm_scan_fwd_wide_kernel";
+        h->trace_name[0] = took8 ? "lstm_scan_fwd8_kernel" : v2 ? "lstm_scan_fwd_wide2_kernel" : "lstm_scan_fwd_wide_kernel";
         h->trace_flops[0] = (double)B * T * (2.0 * W * 4.0 * W);   // one layer's recurrent contraction
         h->trace_end(0, s);
       }
@@ -995,6 +1011,12 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   if (env8i) h->logits_ws = atoi(env8i) != 0;
   const char* env8h = getenv("KL_PROJ_WS");
   if (env8h) h->proj_ws = atoi(env8h) != 0;
+  const char* env8m = getenv("KL_FWD8");
+  if (env8m) h->fwd8 = atoi(env8m) != 0;
+  const char* env8n = getenv("KL_FWD8_LOCAL");
+  if (env8n) h->fwd8_local = atoi(env8n) != 0;
+  const char* env8o = getenv("KL_FWD8_PF");
+  if (env8o) h->fwd8_pf = atoi(env8o);
   const char* env8l = getenv("KL_RT_LOCAL");
   if (env8l) h->rt_local = atoi(env8l) != 0;
   const char* env8k = getenv("KL_REGTILE");

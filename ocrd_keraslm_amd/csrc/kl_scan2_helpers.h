@@ -1,0 +1,135 @@
+// Device helpers of the second-generation scans (lstm_scan2.hip, lstm_scan_fwd8.hip): asynchronous loads the compiler does
+// not know about, LDS-DMA forms, the 4 x 4 quad transpose, armed landing zones.  Included inside each file's anonymous
+// namespace, after kl_scan_common.h.
+#pragma once
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// ---- asynchronous loads the compiler does not know about (waited for by count, wait_vm) ----
+// The destination registers count as written at the end of the asm statement; every consumer sits
+// behind a wait + "+v" fence (use_regs) so that nothing reads them before the data has landed.
+// The destinations are read-write operands: the caller sets them to all-ones first, which no valid datum is, so
+// that "has landed" can be CHECKED after an optimistic counted wait (a register with a load in flight reads
+// as its old value).
+__device__ __forceinline__ void aload16_glb(u32x4& d, const void* sbase, unsigned voff) {
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void aload8_glb(u32x2& d, const void* sbase, unsigned voff) {
+  asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "+v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void aload4_glb(unsigned& d, const void* sbase, unsigned voff) {
+  asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void aload2_glb(unsigned& d, const void* sbase, unsigned voff) {
+  asm volatile("s_nop 4\n\tglobal_load_ushort %0, %1, %2" : "+v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void aload16_buf(u32x4& d, __amdgpu_buffer_rsrc_t r, unsigned voff) {
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(d) : "v"(voff), "s"(r) : "memory");
+}
+__device__ __forceinline__ void use_regs(u32x4& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void use_regs(u32x2& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void use_regs(unsigned& a) { asm volatile("" : "+v"(a)); }
+
+// LDS-DMA of one 1 KiB tile piece: lane l lands at lds_addr + 16 l; source = lane offset + scalar offset
+__device__ __forceinline__ void glds16_sc1_s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+      : "memory");
+}
+
+// ... as a streaming ("nt") load: served by the XCD's L2 without the coherence actions of an sc1 load -- for partners
+// that were verified to share that L2 (XCD-local hand-off, kl_scan_common.h)
+__device__ __forceinline__ void glds16_nt_s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+      : "memory");
+}
+
+__device__ __forceinline__ float dpp_x1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_x2(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+}
+// lane k of a quad holds m[r] = M[k][r]; afterwards m[r] = M[r][k]
+__device__ __forceinline__ void quad_transpose(f32x4& m, int k) {
+  const bool odd = k & 1, hi = k & 2;
+  {
+    const float s0 = odd ? m[0] : m[1], s1 = odd ? m[2] : m[3];
+    const float r0 = dpp_x1(s0), r1 = dpp_x1(s1);
+    if (odd) { m[0] = r0; m[2] = r1; } else { m[1] = r0; m[3] = r1; }
+  }
+  {
+    const float s0 = hi ? m[0] : m[2], s1 = hi ? m[1] : m[3];
+    const float r0 = dpp_x2(s0), r1 = dpp_x2(s1);
+    if (hi) { m[0] = r0; m[1] = r1; } else { m[2] = r0; m[3] = r1; }
+  }
+}
+
+__device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
+
+// Every LDS landing zone of a DMA is ARMED with 0xFFFFFFFF words before the DMA is issued and checked after the
+// counted wait: the count is a good estimate of "landed", not a proof -- with stores among the younger operations the
+// wait was observed to pass before an older load's data had arrived (B = 1536: a few lanes of the gate-input pieces
+// still held the previous phase's values), and a tile buffer still holds the VALID-looking tile of two phases ago.
+// 0xFFFFFFFF is neither a finite float, nor a pair of finite bf16, nor a table-row offset.
+__device__ __forceinline__ void arm16(unsigned char* p) {
+  *reinterpret_cast<uint4*>(p) = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+}
+// a 16-byte piece of a tile is there once none of its four dwords is all-ones (armed LDS, or the sentinel the
+// producers' buffer was pre-filled with): dword writes are atomic and two finite bf16 never make 0xFFFFFFFF
+__device__ __forceinline__ bool piece_there(const unsigned char* p) {
+  const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+  return max(max(v.x, v.y), max(v.z, v.w)) != 0xFFFFFFFFu;
+}
+__device__ __forceinline__ bool landed16(const unsigned char* p) {      // (re-read on every call)
+  asm volatile("" ::: "memory");
+  const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+  return v.x != 0xFFFFFFFFu && v.y != 0xFFFFFFFFu && v.z != 0xFFFFFFFFu && v.w != 0xFFFFFFFFu;
+}
+
+// plain LDS-DMA of one 1 KiB piece (lane l lands at lds_addr + 16 l); source = lane offset into the buffer
+__device__ __forceinline__ void glds16_plain(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(lds_addr)
+      : "memory");
+}
+// ... of 256 bytes (lane l lands at lds_addr + 4 l); source = lane offset + scalar offset
+__device__ __forceinline__ void glds4_plain_s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dword %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+      : "memory");
+}
+
+// ... of 16 bytes per lane from rsrc[voff + soff] (plain load: data of an earlier kernel); lane l lands at lds_addr + 16 l
+__device__ __forceinline__ void glds16_plain_s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+      : "memory");
+}
+
+// ... coherent across XCDs (hand-off flags)
+__device__ __forceinline__ void glds4_sc1_s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dword %1, %2, %3 offen sc1 lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+      : "memory");
+}
+
