@@ -472,7 +472,7 @@ int plan_scan2(const kl_handle* h, int B, int T, bool km_plan, bool need_bwd) {
   if (W != 512) return 0;      // (one tile row = one 1 KiB DMA piece)
   if (h->wide_fwd_min <= 0 || !kl_scan_fwd_wide_applicable(B, T, W) || ((B + 15) / 16) * (W / 64) < h->wide_fwd_min) return 0;
   if (need_bwd && (!h->wide_bwd || !h->seq_bwd || !h->sentinel_bwd || !h->sentinel_roll || !kl_scan_wide2_phases(B, T, W, 16, 6))) return 0;
-  const int p16 = kl_scan_wide2_phases(B, T, W, 16, 4), p32 = kl_scan_wide2_phases(B, T, W, 32, 4);
+  const int p16 = kl_scan_wide2_phases(B, T, W, 16, 5), p32 = kl_scan_wide2_phases(B, T, W, 32, 4);
   if (h->scan2_rows == 16) return p16 ? 16 : 0;
   if (h->scan2_rows == 32) return p32 ? 32 : 0;
   // (by shape, measured at B = 1024 .. 3072: 32-row phases as soon as a workgroup has two of them per step)
@@ -571,7 +571,7 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       else
         KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)n_rb * T, s));
       // (two phases ahead needs the rows to have been published a phase before the request: three or more phases per workgroup)
-      a.pf_mode = h->scan2_pf >= 0 ? h->scan2_pf : (v2 && kl_scan_wide2_phases(B, T, W, w.scan2_rows, 4) >= 3 ? 2 : 1);
+      a.pf_mode = h->scan2_pf >= 0 ? h->scan2_pf : (v2 && kl_scan_wide2_phases(B, T, W, w.scan2_rows, w.scan2_rows == 16 ? 5 : 4) >= 3 ? 2 : 1);
       if (l == L - 1) h->trace_begin(0, s);
       bool took8 = false;
       if (f8 && a.sentinel == 2) {

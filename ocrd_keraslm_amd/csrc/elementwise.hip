@@ -119,6 +119,7 @@ __global__ void softmax_ce_kernel(float* __restrict__ logits, long ld, int rows,
     const int tt = time_major ? row / B : row % T;
     t = tgt[(long)b * T + tt];
     if (last_only && tt != T - 1) { t = -1; counts = false; }
+    if (t < -1) { t = -1; counts = false; }      // (a dummy stream added by the caller's padding: no loss, no gradient, NO accuracy either)
   }
   // probabilities are written back over the logits for the callers that read them (rating); a
   // training window only needs dlogits and the row statistics, so it skips that pass over HBM
@@ -195,6 +196,7 @@ __global__ void softmax_ce_v256_kernel(float* __restrict__ logits, long ld, int 
     const int tt = time_major ? row / B : row % T;
     t = tgt[(long)b * T + tt];
     if (last_only && tt != T - 1) { t = -1; counts = false; }
+    if (t < -1) { t = -1; counts = false; }      // (a dummy stream added by the caller's padding: no loss, no gradient, NO accuracy either)
   }
   float pt = 0.f;
 #pragma unroll

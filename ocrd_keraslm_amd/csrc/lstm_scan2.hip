@@ -870,6 +870,7 @@ __global__ __launch_bounds__(1024, 1) void logits_ce_ws_kernel(const KlLogitsCe 
       int t = a.tgt[(long)b * a.T + tt];
       bool counts = true;
       if (a.last_only && tt != a.T - 1) { t = -1; counts = false; }
+      if (t < -1) { t = -1; counts = false; }      // (a dummy stream added by the caller's padding: no accuracy either)
 #pragma unroll
       for (int k = 0; k < 4; ++k) e[k] *= inv;
       // the target's probability sits in lane t / 4, register t % 4 (t is uniform: one row per pass)
@@ -1774,7 +1775,8 @@ int kl_scan_wide2_phases(int B, int T, int W, int rows, int max_np) {
 
 int kl_launch_scan_fwd_wide2(KlScanFwdWide a, int rows, hipStream_t stream) {
   const int W = a.W;
-  const int np = kl_scan_wide2_phases(a.B, a.T, W, rows, 4);
+  // (16-row phases: up to five per workgroup and step -- 2560 streams; 32-row phases: up to four)
+  const int np = kl_scan_wide2_phases(a.B, a.T, W, rows, rows == 16 ? 5 : 4);
   if (!np || (rows != 16 && rows != 32)) return KL_ERR_SHAPE;
   if (!a.sentinel || a.HT || a.HdT) return KL_ERR_SHAPE;
   const bool tab = a.P == nullptr;
@@ -1795,7 +1797,9 @@ int kl_launch_scan_fwd_wide2(KlScanFwdWide a, int rows, hipStream_t stream) {
   do {                                                                             \
     if (np == 2) KL_F2_CASE(KS, NB_, 2, TAB_);                                     \
     else if (np == 3) KL_F2_CASE(KS, NB_, 3, TAB_);                                \
-    else KL_F2_CASE(KS, NB_, 4, TAB_);                                             \
+    else if (np == 4) KL_F2_CASE(KS, NB_, 4, TAB_);                                \
+    else if (NB_ == 1) KL_F2_CASE(KS, 1, 5, TAB_);                                 \
+    else return KL_ERR_SHAPE;                                                      \
   } while (0)
 #define KL_F2_TAB(KS, NB_)                          \
   do {                                              \

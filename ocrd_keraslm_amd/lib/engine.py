@@ -91,6 +91,7 @@ class HipLM:
         self._part_loss = None
         self._pad_states = {}
         self.pad_streams = True              # pad a group of streams up to the next fast count (HipLM._padded_streams)
+        self.plan_override = None            # width 512: a stream plan to use instead of _plan_512's (tests)
         self._step_ws = None
         self._step_host_ws = None
         self._hio = None
@@ -333,7 +334,8 @@ class HipLM:
                     y = tgt_d[b0:b1] if tgt_d is not None else None
                     if Bp != n:
                         x = torch.nn.functional.pad(x, (0, 0, 0, Bp - n))
-                        y = torch.nn.functional.pad(y, (0, 0, 0, Bp - n), value=-1)
+                        if y is not None:      # (-2, not the -1 of a padded tail: a dummy stream is no hit for the accuracy either)
+                            y = torch.nn.functional.pad(y, (0, 0, 0, Bp - n), value=-2)
                         if c is not None:
                             c = torch.nn.functional.pad(c, (0, 0) * (c.dim() - 1) + (0, Bp - n))
                         st = self._pad_states.get(Bp)
@@ -437,7 +439,9 @@ class HipLM:
                 x, y, st = idx_d[b0:b1], tgt_d[b0:b1], self.states[b0:b1]
                 if Bp != n:
                     x = torch.nn.functional.pad(x, (0, 0, 0, Bp - n))
-                    y = torch.nn.functional.pad(y, (0, 0, 0, Bp - n), value=-1)
+                    # (-2, not the -1 of a padded tail: Keras counts an all-zero target row as a hit when class 0 wins, a dummy stream
+                    #  must not be counted at all)
+                    y = torch.nn.functional.pad(y, (0, 0, 0, Bp - n), value=-2)
                     if c is not None:
                         c = torch.nn.functional.pad(c, (0, 0) * (c.dim() - 1) + (0, Bp - n))
                     if m is not None:
@@ -470,48 +474,44 @@ class HipLM:
                 self.loss_acc[:2] += wgt * self._part_loss[:2]
                 self.loss_acc[3] = torch.maximum(self.loss_acc[3], self._part_loss[3])
 
-    # Width 512, measured ms per training step at length 256 (tools/probe_shape_sweep.py): the second-generation scans' counts ...
-    FAST_MS = {1024: 10.0, 1536: 14.6, 2048: 18.9, 3072: 24.4}
-    # ... and the first-generation scans by started blocks of 512 streams (384 streams 6.3, 512: 6.8, 640: 10.3, 768: 10.9, 1280: 16.8,
-    # 1792: 18.4, 2560: 29.8, 3584: 42.1)
-    SLOW_MS = (0.0, 6.8, 10.9, 16.8, 18.4, 29.8, 36.0, 42.1, 48.0)
-
     def _plan_512(self, B, limit):
-        """[(streams, run as)] for a batch of B streams at width 512: the cheapest way -- by the measured step times above, which
-        scale with the window length alike -- to cut it into groups that each run either as they are (a count the second-generation
-        scans take, or anything on the first-generation scans) or padded with dummy streams up to such a count."""
-        fast = {f: ms for f, ms in self.FAST_MS.items() if f <= limit}
-
-        def single(n):
-            best = (self.SLOW_MS[min(len(self.SLOW_MS) - 1, -(-n // 512))] * (1.0 if n >= 256 else 0.7), n) if n <= limit else (1e9, n)
-            for f, ms in fast.items():
-                if f >= n and ms < best[0] and self.pad_streams:
-                    best = (ms, f)
-                elif f == n and ms < best[0]:
-                    best = (ms, f)
-            return best
-
-        memo = {}
-
-        def plan(r):
-            if r in memo:
-                return memo[r]
-            ms, run = single(r)
-            best = (ms, [(r, run)])
-            for f, fms in fast.items():
-                if f < r:
-                    sub = plan(r - f)
-                    if fms + sub[0] + 0.3 < best[0]:      # (0.3 ms: a group's own launches, gradient accumulation)
-                        best = (fms + sub[0] + 0.3, [(f, f)] + sub[1])
-            memo[r] = best
-            return best
-
-        groups, rest = [], B
-        top = max(fast) if fast else 0
-        while top and rest > 2 * top:      # (far beyond the largest count: whole groups of it, the search only over the rest)
-            groups.append((top, top))
-            rest -= top
-        return groups + plan(rest)[1]
+        """[(streams, run as)] for a batch of B streams at width 512.  The second-generation scans take every multiple of 512
+        from 1024 to 3072 streams (32 row groups x 2 .. 6 row blocks of 16, lstm_scan2.hip) and are faster per stream than the
+        first generation at ANY count above 512 (tools/probe_shape_sweep.py, and timed against the alternatives by
+        test_stream_plan_is_the_fastest): so a batch is rounded up to whole blocks of 512 streams with dummy streams, and what no
+        single launch sequence addresses (`limit`: 32-bit offsets into a layer's gate rows, T * B * 4W bf16) or holds (3072) is
+        cut into groups of the largest count (3584 -> 2560 + 1024, 4096 -> 3072 + 1024, 6144 -> 2 x 3072).  No table of measured
+        times: nothing here has to be re-measured when a kernel changes."""
+        if self.plan_override is not None:      # (tests time the rule's choice against other plans: [(streams, run as), ...])
+            if sum(n for n, _run in self.plan_override) == B:
+                return list(self.plan_override)
+            return [(B, dict(self.plan_override).get(B, B))]
+        unit = 512
+        max_units = min(6, limit // unit)
+        if not self.pad_streams or B <= unit or max_units < 2:
+            if B <= limit:
+                return [(B, B)]
+            # (windows so long that fewer than 1024 streams fit a launch sequence: groups of the largest size the kernels address)
+            chunk = limit // unit * unit if limit >= unit else max(16, limit // 16 * 16)
+            return [(min(chunk, B - b0), min(chunk, B - b0)) for b0 in range(0, B, chunk)]
+        # groups of the largest count first (the more row blocks a workgroup serves per step, the cheaper a stream: 3072 + 1024
+        # beats 2 x 2048), the rest in one group -- or two, if it would otherwise be a single block of 512 (first generation)
+        units = -(-B // unit)
+        sizes = []
+        while units > max_units + 1:
+            sizes.append(max_units)
+            units -= max_units
+        if units > max_units:
+            sizes += [max_units - 1, 2]
+        elif units > 0:
+            sizes.append(units)
+        plan, left = [], B
+        for u in sizes:
+            run = u * unit
+            n = min(run, left)
+            plan.append((n, run))
+            left -= n
+        return [(n, run) for n, run in plan if n > 0]
 
     def _padded_streams(self, n, T):
         """the stream count a group of n streams is run at: width 512 see _plan_512; width 1024: the eight-wave scans give each of
