@@ -1358,6 +1358,9 @@ constexpr int bwd3_lds_bytes() { return 2 * 64 * 1024 + 8 * B3_ZT_WAVE * 4 + 4 *
     if ((k_) == 7) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[36:39], %0, %1, %2 offen offset:3072 sc1" :: "v"(voff1_), "s"(rsrc_), "s"(soff_) : "memory", KL_B4_TILE_CLOBBER); \
   } while (0)
 
+// (KL_NO_REGTILE: tools/build_agpr_tu.sh could not set the register-allocation attribute this kernel needs -- another compiler
+// version --: it is left out, kl_scan_bwd_regtile_min_np() then keeps every shape on the 16-wave kernel)
+#ifndef KL_NO_REGTILE
 template <int NP>
 __global__ __launch_bounds__(512, 1) void lstm_scan_bwd_regtile_kernel(const KlScanBwd a) {
   static_assert(NP >= 5, "a tile is requested two blocks ahead of its use and posted two blocks behind its publish");
@@ -1644,6 +1647,7 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_bwd_regtile_kernel(const KlS
   SSTAMP_FLUSH();
   if (a.db) atomicAdd(a.db + (long)((tid & 255) >> 6) * W + u0 + (tid & 63), dbsum);
 }
+#endif      // KL_NO_REGTILE
 
 }  // namespace
 
@@ -1918,6 +1922,10 @@ int kl_launch_scan_bwd_wide2(KlScanBwd a, hipStream_t stream) {
 }
 
 // register-landing tiles (lstm_scan_bwd_regtile_kernel): flags only, from this many blocks per workgroup and step
+#ifdef KL_NO_REGTILE
+int kl_scan_bwd_regtile_min_np() { return 1 << 30; }
+int kl_launch_scan_bwd_regtile(KlScanBwd, hipStream_t) { return KL_ERR_SHAPE; }
+#else
 int kl_scan_bwd_regtile_min_np() { return 5; }
 int kl_launch_scan_bwd_regtile(KlScanBwd a, hipStream_t stream) {
   const int W = a.W;
@@ -1939,6 +1947,7 @@ int kl_launch_scan_bwd_regtile(KlScanBwd a, hipStream_t stream) {
 #undef KL_B4_CASE
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
+#endif      // KL_NO_REGTILE
 
 #ifdef KL_STAMP
 extern "C" int kl_test_scan2_stamps(unsigned long long* out, int reset) {

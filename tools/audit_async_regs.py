@@ -79,6 +79,9 @@ def audit_agprs(path, kernel_substr="lstm_scan_bwd_regtile", min_kernels=2):
     not as a spill slot, not as a copy of one of the pinned register variables -- and every one of them must have been
     built with the accumulator registers the hand-written statements use (a0..a5, a8..a39) inside its 256 registers."""
     text = open(path).read()
+    if text.startswith("; KL_NO_REGTILE"):      # (tools/build_agpr_tu.sh's fall-back build: the kernels are not in it)
+        print(f"*{kernel_substr}* kernels left out of this build (KL_NO_REGTILE): nothing to check")
+        return 0
     lines = text.split("\n")
     kernel = None
     in_asm = False
