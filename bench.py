@@ -369,7 +369,10 @@ def main():
     roofline = None
     if rank == 0:
         hipabi.check(lm.lib.kl_trace_enable(lm.handle, 1))
-        step(args.warmup + args.steps, all_reduce=False)    # rank 0 only: no collective in this leg
+        # (five traced steps, every layer's scan launch bracketed: 10 launches per direction at depth 2 -- the figure below is
+        # their AVERAGE, comparable with rocprofv3's per-kernel average over the same command)
+        for k in range(5):
+            step(args.warmup + args.steps + k, all_reduce=False)    # rank 0 only: no collective in this leg
         torch.cuda.synchronize()
         out = {}
         for kind in (0, 1):
@@ -391,7 +394,7 @@ def main():
         # HBM bytes per launch: NOT measured here (counters need their own rocprofv3 --pmc passes, tools/profile_round.sh);
         # taken from the committed summary of the same command at the same stream count, and labelled as such
         traffic, traffic_source = None, None
-        for tag in ("r03", "r02", "r01"):
+        for tag in ("r04", "r03", "r02", "r01"):
             fn = os.path.join("profiles", "%s_pmc_hbm_traffic_B%d.json" % (tag, B))
             try:
                 pmc = json.load(open(os.path.join(ROOT, fn)))

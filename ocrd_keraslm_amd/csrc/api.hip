@@ -151,6 +151,8 @@ struct kl_handle {
   bool scan2_bf16 = true;       // KL_SCAN2_BF16=0: f32 instead of bf16 for what the scans exchange with later kernels (P, dH, c for backward)
   bool logits_ws = true;        // KL_LOGITS_WS = 0: GEMM + softmax kernel for the training window's output layer instead of the fused kernel
   bool proj_ws = true;          // KL_PROJ_WS = 0: the ring GEMM for the gate inputs P of the second-generation scans too
+  bool w128 = true;             // KL_W128 = 0: the thin fused scans also at width 128 (lstm_scan_w128.hip: a workgroup per 16-row block, all units)
+  int w128_min = 512;           // ... from this many streams on (KL_W128_MIN; measured: 512 streams 3.08 against 3.15 ms per step, 256: 2.77 / 2.43)
   bool fwd8 = false;            // KL_FWD8 = 1: the eight-wave, barrier-free forward scan (lstm_scan_fwd8.hip) where it applies -- correct, but
                                 // no faster than the 16-wave kernel yet (3.49 against 3.44 ms per launch at 3072 streams)
   bool fwd8_local = true;       // KL_FWD8_LOCAL = 0: write-through publishes in the eight-wave forward scan even where its partners share an XCD
@@ -572,7 +574,7 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
         KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)n_rb * T, s));
       // (two phases ahead needs the rows to have been published a phase before the request: three or more phases per workgroup)
       a.pf_mode = h->scan2_pf >= 0 ? h->scan2_pf : (v2 && kl_scan_wide2_phases(B, T, W, w.scan2_rows, w.scan2_rows == 16 ? 5 : 4) >= 3 ? 2 : 1);
-      if (l == L - 1) h->trace_begin(0, s);
+      h->trace_begin(0, s);      // (every layer's scan launch is timed while tracing)
       bool took8 = false;
       if (f8 && a.sentinel == 2) {
         KlScanFwdWide a8 = a;
@@ -585,7 +587,7 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       if (took8) {}
       else if (v2) KL_TRY(kl_launch_scan_fwd_wide2(a, w.scan2_rows, s));
       else KL_TRY(kl_launch_scan_fwd_wide(a, s));
-      if (l == L - 1) {
+      {
         h->trace_persistent[0] = true;
         h->trace_name[0] = took8 ? "lstm_scan_fwd8_kernel" : v2 ? "lstm_scan_fwd_wide2_kernel" : "lstm_scan_fwd_wide_kernel";
         h->trace_flops[0] = (double)B * T * (2.0 * W * 4.0 * W);   // one layer's recurrent contraction
@@ -597,6 +599,35 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
   }
   if (!scanned)
     KL_TRY(kl_launch_p1_gather(d.EK, ctxk.data(), c.n_ctx, P + h->off_b[0], idx, ctx, B, T, 4 * W, w.P1, s));
+  // Width 128 (the reference's own model sizes): one layer per launch, a workgroup = a 16-row block of streams with ALL hidden
+  // units -- no hand-off between workgroups (lstm_scan_w128.hip).  Layer 0 takes the table rows gathered above, the layers above
+  // it their gate inputs from one product over all steps.
+  if (!scanned && training && h->scan_enabled && h->w128 && B >= h->w128_min && kl_scan_w128_applicable(B, T, W)) {
+    for (int l = 0; l < L; ++l) {
+      if (l > 0) {
+        const bool masked_in = masks != nullptr && (l - 1) > 0;
+        const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
+        KL_TRY(kl_launch_gemm_tn(X, d.KT_hi[l], w.P1, P + h->off_b[l], B * T, 4 * W, W, W, W, 4 * W, 0, 1, 1.f, s));
+      }
+      const bool masked = masks != nullptr && l > 0;
+      KlScanFwdWide a;
+      memset(&a, 0, sizeof(a));
+      a.B = B; a.T = T; a.W = W;
+      a.UT = d.UT_hi[l];
+      a.P = w.P1;
+      a.H = (bf16_t*)w.H[l]; a.C = w.C[l]; a.G = w.G[l];
+      a.Hd = masked ? w.Hd[l] : nullptr;
+      a.mask = masked ? masks + (size_t)l * BW : nullptr;
+      a.status = w.scan_status;
+      h->trace_begin(0, s);
+      KL_TRY(kl_launch_scan_fwd_w128(a, s));
+      h->trace_persistent[0] = true;
+      h->trace_name[0] = "lstm_scan_fwd_w128_kernel";
+      h->trace_flops[0] = (double)B * T * (2.0 * W * 4.0 * W);
+      h->trace_end(0, s);
+    }
+    scanned = true;
+  }
   // Width 1024 (the cfg5 topology): the recurrent weights of 16 units alone fill half of a 256-thread
   // workgroup's registers, so neither the fused scans (U and K resident) nor the 64-unit wide scans apply.
   // One layer per launch with the thin workgroups instead, the input side from one GEMM over all steps as
@@ -635,13 +666,13 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       } else {
         KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)((B + 15) / 16) * T, s));
       }
-      if (l == L - 1) h->trace_begin(0, s);
+      h->trace_begin(0, s);      // (every layer's scan launch is timed while tracing)
       const int e = w32 ? kl_launch_scan_fwd_w32(a, s) : kl_launch_scan_fwd(a, s);
       if (e == KL_ERR_SHAPE && l == 0) {
         all = false;          // (too many row blocks: the launch-per-step path below takes the window, P1 is in place)
       } else if (e != 0) {
         return e;
-      } else if (l == L - 1) {
+      } else {
         h->trace_persistent[0] = true;
         h->trace_name[0] = w32 ? "lstm_scan_fwd_w32_kernel" : "lstm_scan_fwd_kernel";
         h->trace_flops[0] = (double)B * T * (2.0 * W * 4.0 * W);
@@ -1011,6 +1042,10 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   if (env8i) h->logits_ws = atoi(env8i) != 0;
   const char* env8h = getenv("KL_PROJ_WS");
   if (env8h) h->proj_ws = atoi(env8h) != 0;
+  const char* env8p = getenv("KL_W128");
+  if (env8p) h->w128 = atoi(env8p) != 0;
+  const char* env8q = getenv("KL_W128_MIN");
+  if (env8q) h->w128_min = atoi(env8q);
   const char* env8m = getenv("KL_FWD8");
   if (env8m) h->fwd8 = atoi(env8m) != 0;
   const char* env8n = getenv("KL_FWD8_LOCAL");
@@ -1271,10 +1306,12 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   const bool wide_fits = h->wide_bwd && kl_scan_bwd_wide_applicable(B, T, W) && BTp == BT && (B & 7) == 0;
   // (width 1024 has no fused scan at all: always layer by layer)
   // (... and deeper than four layers: the fused scan's limit)
-  const bool sequential = h->scan_enabled && h->seq_bwd &&
+  // (width 128: the one-layer scans of lstm_scan_w128.hip, a workgroup per 16-row block with all units)
+  const bool seq128 = h->scan_enabled && h->seq_bwd && h->w128 && B >= h->w128_min && kl_scan_w128_applicable(B, T, W) && !w.scan2_bwd;
+  const bool sequential = seq128 || (h->scan_enabled && h->seq_bwd &&
                           ((L > 1 && L <= KL_SCAN_MAXL && (W == 512 || W == 256 || W == 128) && n_rb_all > 512 / (L * nug)) ||
                            W == 1024 || (L > KL_SCAN_MAXL && (W == 512 || W == 256 || W == 128 || W == 64))) &&
-                          (thin_fits || wide_fits);
+                          (thin_fits || wide_fits));
   if (sequential || w.scan2_bwd) {
     for (int l = L - 1; l >= 0; --l) {
       if (l < L - 1)   // dX_l = dZ_{l+1} . K_{l+1}^T  -> w.dH (free once the layer above has been scanned)
@@ -1321,7 +1358,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
         KL_TRY(kl_fill_u32_async(w.dZ[l], (size_t)T * BW * 4 * sizeof(bf16_t), 0xFFFFFFFFu, s));
       else
         KL_TRY(kl_zero_coherent_async(w.scan_cnt, (size_t)n_rb_all * T, s));
-      if (l == L - 1) h->trace_begin(1, s);
+      h->trace_begin(1, s);
       // wide (64-unit) workgroups share the dZ tile through LDS; the weight-gradient GEMMs read dZ K-major
       // as it is (dz_km), else the scan also writes dZ^T
       a.dZT = (!w.km_plan && BTp == BT && (B & 7) == 0) ? w.dZT : nullptr;
@@ -1329,7 +1366,15 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
       a.db = grads + h->off_b[l];
       if (rt) a.xcc_slots = h->rt_local ? w.scan_status + 4 : nullptr;
       int e = w.scan2_bwd ? (rt ? kl_launch_scan_bwd_regtile(a, s) : kl_launch_scan_bwd_wide2(a, s)) : (h->wide_bwd ? kl_launch_scan_bwd_wide(a, s) : KL_ERR_SHAPE);
-      bool w32 = false;
+      bool w32 = false, w128k = false;
+      if (e == KL_ERR_SHAPE && seq128) {
+        KlScanBwd a1 = a;
+        a1.dZT = nullptr;
+        a1.sentinel = 0;
+        e = kl_launch_scan_bwd_w128(a1, s);
+        w128k = e == 0;
+        if (w128k) a.dZT = nullptr;
+      }
       if (e == KL_ERR_SHAPE && !w.scan2_bwd && h->w32 && n_rb_all >= h->w32_min_rb && kl_scan_w32_applicable(B, T, W)) {
         // width 1024: eight-wave workgroups of 32 units (lstm_scan_w32.hip); every step starts out as sentinels
         if (a.sentinel != 1) KL_TRY(kl_fill_u32_async(w.dZ[l], (size_t)T * BW * 4 * sizeof(bf16_t), 0xFFFFFFFFu, s));
@@ -1349,10 +1394,10 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
         e = kl_launch_scan_bwd(a, s);
       }
       if (e != 0) return e;
-      if (l == L - 1) {
+      {
         h->trace_persistent[1] = true;
         h->trace_name[1] = w.scan2_bwd ? (rt ? "lstm_scan_bwd_regtile_kernel" : "lstm_scan_bwd_wide2_kernel")
-                                       : (w32 ? "lstm_scan_bwd_w32_kernel" : (wide ? "lstm_scan_bwd_wide_kernel" : "lstm_scan_bwd_kernel"));
+                                       : (w128k ? "lstm_scan_bwd_w128_kernel" : w32 ? "lstm_scan_bwd_w32_kernel" : (wide ? "lstm_scan_bwd_wide_kernel" : "lstm_scan_bwd_kernel"));
         h->trace_flops[1] = (double)B * T * (2.0 * W * 4.0 * W);   // one layer's recurrent contraction
         h->trace_end(1, s);
       }

@@ -185,6 +185,10 @@ struct KlScanFwdWide {
                                        // C then only receives block T, the carried-out state); null: every block goes to C in f32
   int p_bf16;                          // second generation: P is bf16 [T*B][W][4 gates] (8 bytes per cell) instead of f32
 };
+// width 128: a workgroup = a 16-row block of streams with ALL hidden units of one layer, no hand-off between workgroups
+// (lstm_scan_w128.hip); forward takes f32 P rows only; backward as the wide one-layer kernels (a.L == 1, db summed)
+bool kl_scan_w128_applicable(int B, int T, int W);
+int kl_launch_scan_fwd_w128(KlScanFwdWide args, hipStream_t stream);
 bool kl_scan_fwd_wide_applicable(int B, int T, int W);
 int kl_launch_scan_fwd_wide(KlScanFwdWide args, hipStream_t stream);
 // second generation: every workgroup serves NP = 2..max_np phases of `rows` (16 or 32) rows per step; 0 = not applicable
@@ -233,6 +237,7 @@ int kl_launch_scan_bwd_wide2(KlScanBwd args, hipStream_t stream);
 // kl_scan_bwd_regtile_min_np() blocks per workgroup and step
 int kl_launch_scan_bwd_regtile(KlScanBwd args, hipStream_t stream);
 int kl_launch_scan_bwd_w32(KlScanBwd args, hipStream_t stream);     // width 1024 (a.sentinel must be 1, a.L 1)
+int kl_launch_scan_bwd_w128(KlScanBwd args, hipStream_t stream);    // width 128 (a.L 1, a.dH f32)
 int kl_scan_bwd_regtile_min_np();
 // output projection + softmax + CE + dlogits of a training window in one pass (V = 256, width 512); KL_ERR_SHAPE = not applicable
 int kl_launch_logits_ce_ws(const bf16_t* X, const bf16_t* E, const int* tgt, bf16_t* dlogits, float* rowstat, int B, int T, int W,

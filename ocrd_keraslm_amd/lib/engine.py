@@ -548,8 +548,8 @@ class HipLM:
     # Stream counts per (physical) width that run on the fastest kernels, and the count from which a batch that is none of them
     # is regrouped: width 512 -- what the second-generation scans take (32 row groups x 2..6 row blocks of 16, lstm_scan2.hip);
     # width 1024 -- the eight-wave scans serve up to 1024 streams (lstm_scan_w32.hip), beyond them the launch-per-step kernels
-    # (2048 streams: 1.4 M chars/s against 5.2 M); width 128 -- 4096 streams in one piece run at half the rate of 2 x 2048.
-    FAST_STREAMS = {512: ((3072, 2048, 1536, 1024), 1025), 1024: ((1024, 512), 1025), 128: ((2048,), 4096)}
+    # (2048 streams: 1.4 M chars/s against 5.2 M).  (Width 128 runs any count in one piece since round 4: lstm_scan_w128.hip.)
+    FAST_STREAMS = {512: ((3072, 2048, 1536, 1024), 1025), 1024: ((1024, 512), 1025)}
 
     def _stream_groups(self, B, T):
         """[(first, end)] stream ranges of one training batch.  One range, unless (a) the batch is beyond what a launch

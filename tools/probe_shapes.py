@@ -28,3 +28,12 @@ if "cfg5" in what:
     leg, lm = bench.training_leg(device, 4, 1024, 512, 2, 512, st5, min(3, st5), corpus)
     print("cfg5 B=512: %.2f ms/step, %.0f chars/s, mfma %.3f" % (leg["ms_per_step"], leg["value"], leg["mfma_frac"]))
     print(json.dumps(leg))
+# any other shape: KL_SHAPE="depth,width,length,streams[,steps]" python tools/probe_shapes.py shape
+if "shape" in what:
+    for spec in os.environ.get("KL_SHAPE", "2,128,256,1024").split(";"):
+        v = [int(x) for x in spec.split(",")]
+        dep, wid, length, Bs = v[:4]
+        st = v[4] if len(v) > 4 else 20
+        leg, lm = bench.training_leg(device, dep, wid, length, bench.N_CTX, Bs, st, 3, corpus[:max(Bs, 64) * (bench.CORPUS // 1024)])
+        del lm
+        print("shape depth=%d width=%d length=%d streams=%d: %.3f ms/step, %.0f chars/s, mfma %.4f" % (dep, wid, length, Bs, leg["ms_per_step"], leg["value"], leg["mfma_frac"]))
