@@ -582,16 +582,11 @@ def test_train_window_scan2(monkeypatch, depth, width, voc, B, T, n_ctx, use_mas
 
 
 @pytest.mark.parametrize("depth,width,voc,B,T,n_ctx,use_masks,env,want", [
-    (2, 512, 64, 3072, 5, 1, True, {}, "lstm_scan_fwd8_kernel"),                       # three 32-row phases per step, tiles two phases ahead
-    (2, 512, 64, 3072, 9, 1, False, {}, "lstm_scan_fwd8_kernel"),                      # ... the tile ring goes round several times
-    (3, 512, 40, 3072, 4, 0, True, {}, "lstm_scan_fwd8_kernel"),                       # three layers, no context variable
-    (2, 512, 64, 3072, 4, 2, True, {}, "lstm_scan_fwd8_kernel"),                       # two context variables
-    (2, 512, 64, 2048, 6, 1, True, {"KL_SCAN2_ROWS": "32"}, "lstm_scan_fwd8_kernel"),  # two phases per step: tiles one phase ahead
-    (2, 512, 64, 3072, 5, 1, True, {"KL_FWD8_LOCAL": "0"}, "lstm_scan_fwd8_kernel"),   # write-through publishes
-    (2, 512, 64, 3072, 5, 1, True, {"KL_FWD8_PF": "0"}, "lstm_scan_fwd8_kernel"),      # tiles one phase ahead, requested at the top
-    (2, 512, 64, 3072, 5, 1, True, {"KL_FWD8_PF": "2"}, "lstm_scan_fwd8_kernel"),      # two ahead at the top: every request too early (the re-fetch path)
-    (2, 512, 64, 3072, 5, 1, True, {"KL_FWD8_PF": "3"}, "lstm_scan_fwd8_kernel"),
-    (2, 512, 64, 3072, 5, 1, True, {"KL_FWD8": "0"}, "lstm_scan_fwd_wide2_kernel")])   # the 16-wave scan at the same shape
+    (2, 512, 64, 3072, 9, 1, True, {}, "lstm_scan_fwd8_kernel"),                       # three 32-row phases per step, tiles two phases ahead; the ring goes round
+    (3, 512, 40, 3072, 4, 0, False, {}, "lstm_scan_fwd8_kernel"),                      # three layers, no context variable, no dropout
+    (2, 512, 64, 2048, 6, 2, True, {"KL_SCAN2_ROWS": "32"}, "lstm_scan_fwd8_kernel"),  # two phases per step: tiles one phase ahead; two contexts
+    (2, 512, 64, 3072, 5, 1, True, {"KL_FWD8_LOCAL": "0", "KL_FWD8_PF": "0"}, "lstm_scan_fwd8_kernel"),   # write-through publishes; tiles one ahead at the top
+    (2, 512, 64, 3072, 5, 1, True, {"KL_FWD8_PF": "2"}, "lstm_scan_fwd8_kernel")])     # two ahead at the top: every request too early (the re-fetch path)
 def test_train_window_fwd8(monkeypatch, depth, width, voc, B, T, n_ctx, use_masks, env, want):
     """The eight-wave forward scan (lstm_scan_fwd8.hip, KL_FWD8=1: two unit tiles per wave, no workgroup barrier, tile ring with
     LDS counters, last-arriver publish, layer 0's gate inputs gathered into P rows): gradients, loss and carried state
