@@ -153,8 +153,10 @@ struct kl_handle {
   bool proj_ws = true;          // KL_PROJ_WS = 0: the ring GEMM for the gate inputs P of the second-generation scans too
   bool w128 = true;             // KL_W128 = 0: the thin fused scans also at width 128 (lstm_scan_w128.hip: a workgroup per 16-row block, all units)
   int w128_min = 512;           // ... from this many streams on (KL_W128_MIN; measured: 512 streams 3.08 against 3.15 ms per step, 256: 2.77 / 2.43)
-  bool fwd8 = false;            // KL_FWD8 = 1: the eight-wave, barrier-free forward scan (lstm_scan_fwd8.hip) where it applies -- correct, but
-                                // no faster than the 16-wave kernel yet (3.49 against 3.44 ms per launch at 3072 streams)
+  bool fwd8 = true;             // KL_FWD8 = 0: the 16-wave forward scan also for the layers above the first (default: the eight-wave scan of
+                                // lstm_scan_fwd8.hip there -- 3.06 against 3.36 ms per launch at 3072 streams)
+  bool fwd8_all = false;        // KL_FWD8 = 2: ... also for layer 0 (its gate inputs gathered into P rows first)
+  bool fwd8_ls = true;          // KL_FWD8_LS = 0: the counter form of the eight-wave forward scan instead of the two-barrier form
   bool fwd8_local = true;       // KL_FWD8_LOCAL = 0: write-through publishes in the eight-wave forward scan even where its partners share an XCD
   int fwd8_pf = -1;             // KL_FWD8_PF = 0..3: where it requests its tiles (default by phases per step)
   bool rt_local = true;         // KL_RT_LOCAL = 0: write-through publishes in the register-tile backward scan even where its partners share an XCD
@@ -517,7 +519,10 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       a.UT = d.UT_hi[l];
       const bool v2 = w.scan2_rows != 0;
       // the eight-wave scan (lstm_scan_fwd8.hip) takes bf16 P rows only: layer 0's gate inputs are gathered in front of it
-      const bool f8 = v2 && h->fwd8 && w.scan2_rows == 32 && h->scan2_bf16 && h->sentinel_roll && T >= 3;
+      // (layer 0 with one context variable stays on the 16-wave scan's table mode: gathering its P rows first costs more --
+      //  1.25 ms at 3072 streams -- than the eight-wave scan saves; KL_FWD8=2 takes it for layer 0 as well)
+      const bool f8 = v2 && h->fwd8 && w.scan2_rows == 32 && h->scan2_bf16 && h->sentinel_roll && T >= 3 &&
+                      (l > 0 || c.n_ctx > 1 || h->fwd8_all);
       if (l > 0) {
         const bool masked_in = masks != nullptr && (l - 1) > 0;
         const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
@@ -579,8 +584,8 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       if (f8 && a.sentinel == 2) {
         KlScanFwdWide a8 = a;
         a8.xcc_slots = h->fwd8_local ? w.scan_status + 4 : nullptr;
-        a8.pf_mode = h->fwd8_pf >= 0 ? h->fwd8_pf : 1;
-        const int e8 = kl_launch_scan_fwd8(a8, s);
+        a8.pf_mode = h->fwd8_pf >= 0 ? h->fwd8_pf : (h->fwd8_ls ? 0 : 1);      // (measured at 3072 streams: two-barrier form 3.06 / 3.32 / 3.30 ms per launch with pf 0 / 1 / 3)
+        const int e8 = kl_launch_scan_fwd8(a8, s, h->fwd8_ls);
         if (e8 != KL_ERR_SHAPE) KL_TRY(e8);
         took8 = e8 == 0;
       }
@@ -1047,7 +1052,9 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   const char* env8q = getenv("KL_W128_MIN");
   if (env8q) h->w128_min = atoi(env8q);
   const char* env8m = getenv("KL_FWD8");
-  if (env8m) h->fwd8 = atoi(env8m) != 0;
+  if (env8m) { h->fwd8 = atoi(env8m) != 0; h->fwd8_all = atoi(env8m) == 2; }
+  const char* env8r = getenv("KL_FWD8_LS");
+  if (env8r) h->fwd8_ls = atoi(env8r) != 0;
   const char* env8n = getenv("KL_FWD8_LOCAL");
   if (env8n) h->fwd8_local = atoi(env8n) != 0;
   const char* env8o = getenv("KL_FWD8_PF");

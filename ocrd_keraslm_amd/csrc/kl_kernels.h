@@ -197,7 +197,7 @@ int kl_scan_wide2_phases(int B, int T, int W, int rows, int max_np);
 int kl_launch_scan_fwd_wide2(KlScanFwdWide args, int rows, hipStream_t stream);
 // ... 32-row phases on eight waves without workgroup barriers (lstm_scan_fwd8.hip): bf16 P rows, rolling sentinels; pf_mode 0..3
 // (see the kernel); KL_ERR_SHAPE = not applicable
-int kl_launch_scan_fwd8(KlScanFwdWide args, hipStream_t stream);
+int kl_launch_scan_fwd8(KlScanFwdWide args, hipStream_t stream, bool lockstep = false);      // lockstep: two workgroup barriers per phase instead of the LDS counters
 int kl_launch_permute_gate_cols_f32(const float* in, const float* bias, float* out, long rows, int W, hipStream_t stream);
 int kl_launch_permute_gate_rows_bf16(const bf16_t* in, bf16_t* out, int W, int K, hipStream_t stream);
 // layer 0's gate inputs as gate-interleaved bf16 P rows (time-major) from the permuted tables: several context variables

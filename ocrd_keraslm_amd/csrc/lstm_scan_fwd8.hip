@@ -69,7 +69,11 @@ __device__ __forceinline__ unsigned piece_state(const unsigned char* p) {
   return (armed ? 1u : 0u) | (sent ? 2u : 0u);
 }
 
-template <int NP>
+// LS ("lockstep"): the same eight waves, two unit tiles per wave, polled landing zones and coalesced stores, but the waves
+// meet at TWO workgroup barriers per phase (tile complete / staging complete) instead of going through the counters: no
+// `landed` / `released` / arrival bookkeeping, no looks ahead, waves 0-3 publish and waves 4-7 store the strips of the SAME
+// phase behind the second barrier.
+template <int NP, bool LS>
 __global__ __launch_bounds__(512, 1) void lstm_scan_fwd8_kernel(const KlScanFwdWide a) {
   constexpr int KSTEPS = 16, W = 512, NWG_RB = W / 64, ROWS = 32;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -307,16 +311,21 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_fwd8_kernel(const KlScanFwdW
       const int bufa = (n + ahead) % F8_RING;
       SSTAMP(0);
       if (at_top && alive && ask) {
-        // (the buffer was last read in phase n + ahead - 3: all eight waves must have released it)
-        alive = wait_ctr(bufa, 8u * (unsigned)((n + ahead) / F8_RING));
+        // (the buffer was last read in phase n + ahead - 3: all eight waves must have released it -- LS: they met at a barrier since)
+        if (!LS) alive = wait_ctr(bufa, 8u * (unsigned)((n + ahead) / F8_RING));
         arm_tile(bufa);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (alive) request_tile(ta, ra, bufa);
       }
       // ---- this wave's own rows of the tile (normally seen during the phase before), then everybody's
-      if (alive && !mine) F8_OWN_ROWS(t, r0, buf);
+      if (alive && (LS || !mine)) F8_OWN_ROWS(t, r0, buf);
       SSTAMP(8);
-      if (alive) alive = wait_ctr(4 + buf, 8u * (unsigned)(n / F8_RING + 1));
+      if (LS) {
+        __syncthreads();
+        alive = ctr_now(3) != 0;
+      } else if (alive) {
+        alive = wait_ctr(4 + buf, 8u * (unsigned)(n / F8_RING + 1));
+      }
       SSTAMP(1);
       // ---- MFMA phase: two row blocks x two unit tiles against the resident weights, all of K
       f32x4 acc[2][2];
@@ -347,21 +356,22 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_fwd8_kernel(const KlScanFwdW
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      bump(buf);      // released: this wave's last fragment read of the buffer is in the LDS queue in front of this
+      if (!LS) bump(buf);      // released: this wave's last fragment read of the buffer is in the LDS queue in front of this
       SSTAMP(2);
       // ---- the phase TWO before this one: all eight waves have long arrived at its publish (i.e. written their staging rows --
       // checked, not assumed), its cell states and masked outputs leave now, whole 128-byte lines, four rows per wave.  (In front
       // of the looks below: a wave that finds `landed` complete for a phase knows that everybody has read the staging set that
       // phase will overwrite.)
-      if (n > 1 && alive) {
+      if (!LS && n > 1 && alive) {
         alive = wait_ctr(8 + (n - 2) % F8_RING, 8u * (unsigned)((n - 2) / F8_RING + 1));
         if (alive) strips_store(prev_trow[1], strips_read((n - 2) % F8_RING), rs_cb, rs_hd);
       }
+      SSTAMP(11);
       // ---- a first look at this wave's rows of the NEXT phase (asked for behind the MFMAs of the phase before): a wave that is
       // ahead does not hold the others up at the top of the next phase
       // (only if they HAVE been asked for: with requests one phase ahead the buffer still holds the tile of three phases ago)
       mine = false;
-      if (have_next && alive && ahead == 2) {
+      if (!LS && have_next && alive && ahead == 2) {
         mine = look(t1, r1, buf1);
         if (mine) bump(4 + buf1);
       }
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_fwd8_kernel(const KlScanFwdW
       {
         const bool ask_tile = !at_top && alive && ask;
         if (ask_tile) {
-          alive = wait_ctr(bufa, 8u * (unsigned)((n + ahead) / F8_RING));
+          if (!LS) alive = wait_ctr(bufa, 8u * (unsigned)((n + ahead) / F8_RING));
           arm_tile(bufa);
         }
         if (have_next) arm_zin();
@@ -442,7 +452,31 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_fwd8_kernel(const KlScanFwdW
       SSTAMP(4);
       // ---- publish: the last wave to arrive stores the phase's 32 rows x 128 bytes (and arms block t + 3).  (The staging writes
       // above and the counter update pass through the LDS queue in order: no wait in between.)
-      {
+      if (LS) {
+        // second barrier: the staging tiles are complete; waves 0-3 publish (one 16-byte piece per lane, 8 rows per wave) and arm
+        // block t + 3, waves 4-7 store the cell states and masked outputs of this same phase
+        __syncthreads();
+        if (wave < 4) {
+          const int i = wave * 64 + lane, prow = i >> 3, seg = i & 7;
+          const uint4 v = *reinterpret_cast<const uint4*>(stage + prow * F8_ST_LD + seg * 16);
+          const unsigned off = (unsigned)((prow * W + seg * 8) * 2) + ((trow + B) * W + u0) * 2u;
+          if (!alive) store16(rs_hnull, 0u, 0u, v);
+          else if (local) store16(rs_h, off, 0u, v);
+          else store16_sc1(rs_h, off, v);
+          const uint4 ones = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+          const unsigned off3 = off + (unsigned)((long)2 * B * W * 2);
+          if (!alive || t + 3 > T) store16(rs_hnull, 0u, 0u, ones);
+          else if (local) store16(rs_h, off3, 0u, ones);
+          else store16_sc1(rs_h, off3, ones);
+        } else {
+          const int i = (wave - 4) * 64 + lane, prow = i >> 3, seg = i & 7;
+          const unsigned off = (unsigned)((prow * W + u0 + seg * 8) * 2);
+          const uint4 vc = *reinterpret_cast<const uint4*>(stage + F8_ST_TILE + prow * F8_ST_LD + seg * 16);
+          const uint4 vh = *reinterpret_cast<const uint4*>(stage + 2 * F8_ST_TILE + prow * F8_ST_LD + seg * 16);
+          if (a.Cb) store16(alive ? rs_cb : rs_cnull, off, (trow + B) * (unsigned)(W * 2), vc);
+          store16(alive ? rs_hd : rs_cnull, off, trow * (unsigned)(W * 2), vh);
+        }
+      } else {
         unsigned old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(ctr + 8 + buf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         old = __builtin_amdgcn_readfirstlane(old);
@@ -467,7 +501,7 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_fwd8_kernel(const KlScanFwdW
         }
       }
       // a second look at the next phase's rows
-      if (have_next && alive && !mine) {
+      if (!LS && have_next && alive && !mine) {
         mine = look(t1, r1, buf1);
         if (mine) bump(4 + buf1);
       }
@@ -488,7 +522,7 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_fwd8_kernel(const KlScanFwdW
   }
   // the last phase's cell states and masked outputs
   __syncthreads();
-  if (alive && ctr_now(3) != 0) {
+  if (!LS && alive && ctr_now(3) != 0) {
     if (n > 1) strips_store(prev_trow[1], strips_read((n - 2) % F8_RING), rs_cb, rs_hd);
     strips_store(prev_trow[0], strips_read((n - 1) % F8_RING), rs_cb, rs_hd);
   }
@@ -512,7 +546,7 @@ extern "C" int kl_test_fwd8_stamps(unsigned long long* out, int reset) {
 #endif
 
 // KL_ERR_SHAPE = not applicable (the caller takes lstm_scan_fwd_wide2_kernel)
-int kl_launch_scan_fwd8(KlScanFwdWide a, hipStream_t stream) {
+int kl_launch_scan_fwd8(KlScanFwdWide a, hipStream_t stream, bool lockstep) {
   if (a.W != 512 || !a.P || !a.p_bf16 || a.sentinel != 2 || a.HT || a.HdT || !a.G || !a.H || !a.C) return KL_ERR_SHAPE;
   const int np = kl_scan_wide2_phases(a.B, a.T, a.W, 32, 4);
   if (np < 2) return KL_ERR_SHAPE;
@@ -522,15 +556,17 @@ int kl_launch_scan_fwd8(KlScanFwdWide a, hipStream_t stream) {
   if (np == 2 && (a.pf_mode == 1 || a.pf_mode == 2)) a.pf_mode = 3;      // (two phases per step: the rows of phase n + 2 are this phase's own)
   dim3 grid(8 * (a.W / 64) * ((a.n_rg + 7) / 8)), block(512);
   const size_t lds = (size_t)F8_LDS;
-#define KL_F8_CASE(NP_)                                                                                             \
-  do {                                                                                                              \
-    static KlLdsGrant grant;                                                                                        \
-    if (kl_grant_lds(grant, reinterpret_cast<const void*>(&lstm_scan_fwd8_kernel<NP_>), lds)) return KL_ERR_LAUNCH; \
-    hipLaunchKernelGGL((lstm_scan_fwd8_kernel<NP_>), grid, block, lds, stream, a);                                  \
+#define KL_F8_CASE1(NP_, LS_)                                                                                            \
+  do {                                                                                                                   \
+    static KlLdsGrant grant;                                                                                             \
+    if (kl_grant_lds(grant, reinterpret_cast<const void*>(&lstm_scan_fwd8_kernel<NP_, LS_>), lds)) return KL_ERR_LAUNCH; \
+    hipLaunchKernelGGL((lstm_scan_fwd8_kernel<NP_, LS_>), grid, block, lds, stream, a);                                  \
   } while (0)
+#define KL_F8_CASE(NP_) do { if (lockstep) KL_F8_CASE1(NP_, true); else KL_F8_CASE1(NP_, false); } while (0)
   if (np == 2) KL_F8_CASE(2);
   else if (np == 3) KL_F8_CASE(3);
   else KL_F8_CASE(4);
 #undef KL_F8_CASE
+#undef KL_F8_CASE1
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }

@@ -102,17 +102,16 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_kernel(const KlScan
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) p_put(0, k, p_load(0, k));
-  // the gate inputs travel TWO steps ahead through registers (a step lasts ~1.5 us, a load from HBM under this load longer)
-  float4 pn[4], pnn[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) pn[k] = p_load(min(1, T - 1), k);
   __syncthreads();
 
   for (int t = 0; t < T; ++t) {
     const int p = t & 1;
-    if (t + 2 < T) {
+    // the gate inputs of the next step are on their way while this one computes (two steps ahead measured the same: the step
+    // is bound by its ~350 vector instructions per wave -- 4 cells per lane, 10 transcendentals each --, not by the loads)
+    float4 pn[4];
+    if (t + 1 < T) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) pnn[k] = p_load(t + 2, k);
+      for (int k = 0; k < 4; ++k) pn[k] = p_load(t + 1, k);
     }
     // ---- h[t-1] . U^T: 16 rows x this wave's 64 columns
     f32x4 acc[4];
@@ -158,8 +157,6 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_kernel(const KlScan
 #pragma unroll
       for (int k = 0; k < 4; ++k) p_put(p ^ 1, k, pn[k]);
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) pn[k] = pnn[k];
     __syncthreads();
     // ---- this step's rows to memory, whole rows
     const long trow = (long)t * B + row0;
@@ -238,13 +235,12 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_bwd_w128_kernel(const KlScan
     *reinterpret_cast<float4*>(smem + B_DH + (buf * 16 + c_row) * 512 + c_seg * 16) = v.d;
   };
   in_put((T - 1) & 1, in_load(T - 1));
-  // (two steps ahead through registers, as the forward scan's gate inputs)
-  In nxt = in_load(max(T - 2, 0)), nxt2 = nxt;
   __syncthreads();
 
   for (int t = T - 1; t >= 0; --t) {
     const int p = t & 1;
-    if (t > 1) nxt2 = in_load(t - 2);
+    In nxt;
+    if (t > 0) nxt = in_load(t - 1);
     // ---- dZ[t+1] . U^T (nothing comes back from beyond the window)
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t + 1 < T) {
@@ -278,7 +274,6 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_bwd_w128_kernel(const KlScan
       dbacc[0] += bf2f(bi); dbacc[1] += bf2f(bff); dbacc[2] += bf2f(bg); dbacc[3] += bf2f(bo);      // (what the weight gradients see: the rounded values)
     }
     if (t > 0) in_put(p ^ 1, nxt);
-    nxt = nxt2;
     __syncthreads();
     // ---- dZ[t] to memory, whole rows
     const long trow = (long)t * B + row0;

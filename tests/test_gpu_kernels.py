@@ -586,12 +586,15 @@ def test_train_window_scan2(monkeypatch, depth, width, voc, B, T, n_ctx, use_mas
     (3, 512, 40, 3072, 4, 0, False, {}, "lstm_scan_fwd8_kernel"),                      # three layers, no context variable, no dropout
     (2, 512, 64, 2048, 6, 2, True, {"KL_SCAN2_ROWS": "32"}, "lstm_scan_fwd8_kernel"),  # two phases per step: tiles one phase ahead; two contexts
     (2, 512, 64, 3072, 5, 1, True, {"KL_FWD8_LOCAL": "0", "KL_FWD8_PF": "0"}, "lstm_scan_fwd8_kernel"),   # write-through publishes; tiles one ahead at the top
-    (2, 512, 64, 3072, 5, 1, True, {"KL_FWD8_PF": "2"}, "lstm_scan_fwd8_kernel")])     # two ahead at the top: every request too early (the re-fetch path)
+    (2, 512, 64, 3072, 5, 1, True, {"KL_FWD8_PF": "2"}, "lstm_scan_fwd8_kernel"),      # two ahead at the top: every request too early (the re-fetch path)
+    # the counter form (no workgroup barrier in the loop: landed / released / arrival counters, last-arriver publish, strips two phases late)
+    (2, 512, 64, 3072, 9, 1, True, {"KL_FWD8_LS": "0"}, "lstm_scan_fwd8_kernel"),
+    (2, 512, 64, 2048, 6, 2, True, {"KL_FWD8_LS": "0", "KL_SCAN2_ROWS": "32"}, "lstm_scan_fwd8_kernel")])
 def test_train_window_fwd8(monkeypatch, depth, width, voc, B, T, n_ctx, use_masks, env, want):
     """The eight-wave forward scan (lstm_scan_fwd8.hip, KL_FWD8=1: two unit tiles per wave, no workgroup barrier, tile ring with
     LDS counters, last-arriver publish, layer 0's gate inputs gathered into P rows): gradients, loss and carried state
     against the f64 oracle, with the switches that move its tile requests and its publish path."""
-    monkeypatch.setenv("KL_FWD8", "1")      # (opt-in: it is no faster than the 16-wave kernel yet)
+    monkeypatch.setenv("KL_FWD8", "2")      # (also for layer 0, which by default stays on the 16-wave scan's table mode)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks, want_kernel=want)

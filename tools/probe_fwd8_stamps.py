@@ -40,10 +40,10 @@ per = n * T * L * np_f
 names = ['loop top (+ tile request at the top)', 'own rows landed + armed counter', 'MFMA phase + release', 'tile request + gate-input wait + next pieces',
          'epilogue math, G stores, staging', '(publisher) strips + arrival', '(publisher) publish + re-arm', 'strips + arrival / rotate']
 v = np.array(st[:8], dtype=np.float64) / per
-v[1] += st[8] / per; v[3] += (st[9] + st[10]) / per
+v[1] += st[8] / per; v[3] += (st[9] + st[10] + st[11]) / per
 print(f"B={B}: eight-wave forward scan, 32-row phases x {np_f} per step; cycles per phase of workgroup 0 wave 0; total {v.sum():.0f} = {v.sum() / 32:.0f} per row")
 for nm, x in zip(names, v):
     print(f"  {nm:48s} {x:8.1f}")
 print(f"  of own rows landed + counter: own rows (blocking look) {st[8] / per:.1f}, the rest waiting for the other waves")
-print(f"  of 'tile request + ...': early look at the next rows {st[9] / per:.1f}, gate-input wait {st[10] / per:.1f}, the rest: released counter + arming + requests")
+print(f"  of 'tile request + ...': strips of two phases ago {st[11] / per:.1f}, early look at the next rows {st[9] / per:.1f}, gate-input wait {st[10] / per:.1f}, the rest: released counter + arming + requests")
 print(f"  own rows not there at the counted wait: {st[12] / per:.4f} per phase; MFMA phases repeated (somebody's rows missing): {st[13] / per:.4f}")
