@@ -50,7 +50,7 @@ class FinishedBeam(object):
 
     def best_cost(self, tracks):
         kind, ref = self.items[0]
-        return ref.cum_cost if kind == "node" else float(tracks.cum[ref])
+        return ref.cum_cost if kind == "node" else tracks.cum[ref]
 
     def insert(self, key, item):
         pos = bisect_left(self.keys, key)
@@ -67,11 +67,16 @@ class FinishedBeam(object):
         kind, ref = self.items[i]
         if kind == "node":
             return ref.value, ref.state, ref.cum_cost
-        return tracks.text[tracks.alt[ref]], tracks.state[ref], float(tracks.cum[ref])
+        return tracks.text[tracks.alt[ref]], tracks.state[ref], tracks.cum[ref]
 
 
 class EdgeTracks(object):
-    """All (incoming hypothesis x alternative) pairs of one lattice edge."""
+    """All (incoming hypothesis x alternative) pairs of one lattice edge.
+
+    Plain Python lists, not arrays: an edge has a few dozen tracks (beam width x alternatives), and at that size every numpy
+    call costs more than the arithmetic it does -- the bookkeeping of an edge was 70 of the 110 microseconds a lattice edge took
+    with the model's step at 40 (round 4).  All costs are Python floats = IEEE doubles, the arithmetic and its order are those
+    of the array form (and of the reference): ties and the two margins are decided on identical values."""
 
     def __init__(self, incoming, alternatives, element, c_i, lm_weight, logger):
         n_in, n_alt = len(incoming), len(alternatives)
@@ -79,32 +84,31 @@ class EdgeTracks(object):
         self.alternatives = alternatives
         self.element = element
         self.text = [a.Unicode for a in alternatives]
-        self.length = np.array([len(t) for t in self.text], dtype=np.int64)
+        self.length = [len(t) for t in self.text]
         self.lm_weight = lm_weight
         # per alternative: ids of its characters (0 = unmapped; reported when a track first reaches one, once per
         # alternative and character, rating.py:830-837) and the confidence term every one of its characters costs
         # (rating.py:839-840)
-        self.ids = [np.array([c_i.get(char, 0) for char in alt.Unicode], dtype=np.int64) for alt in alternatives]
-        self.unmapped = [[char not in c_i for char in alt.Unicode] for alt in alternatives]
+        get = c_i.get
+        self.ids = [[get(char, 0) for char in t] for t in self.text]
+        self.unmapped = [[char not in c_i for char in t] for t in self.text]
         self.reported = [set() for _ in alternatives]
         self.logger = logger
-        self.conf_term = np.array([-log(max(a.conf, 1e-99), 2) * (1. - lm_weight) for a in alternatives])
+        self.conf_term = [-log(max(a.conf, 1e-99), 2) * (1. - lm_weight) for a in alternatives]
         # the tracks, in the order the reference creates its nodes: hypothesis-major, alternative-minor
-        self.parent = np.repeat(np.arange(n_in), n_alt)
-        self.alt = np.tile(np.arange(n_alt), n_in)
-        self.pos = np.zeros(n_in * n_alt, dtype=np.int64)
-        self.cum = np.repeat(np.array([h.cum_cost for h in incoming], dtype=np.float64), n_alt)
-        self.state = [incoming[p].state for p in self.parent]
+        self.parent = [p for p in range(n_in) for _ in range(n_alt)]
+        self.alt = list(range(n_alt)) * n_in
+        self.pos = [0] * (n_in * n_alt)
+        self.cum = [float(h.cum_cost) for h in incoming for _ in range(n_alt)]
+        self.state = [h.state for h in incoming for _ in range(n_alt)]
 
     def __len__(self):
         return len(self.parent)
 
     def keys(self, rows):
         """prospective cost: what the lists are ordered by"""
-        return self.cum[rows] + LOOKAHEAD * (self.length[self.alt[rows]] - self.pos[rows])
-
-    def finished(self, rows):
-        return self.pos[rows] == self.length[self.alt[rows]]
+        cum, length, alt, pos = self.cum, self.length, self.alt, self.pos
+        return [cum[i] + LOOKAHEAD * (length[alt[i]] - pos[i]) for i in rows]
 
     def last_chars(self, rows):
         """the character each track feeds into the model next: its own last one, or -- nothing consumed yet -- the
@@ -117,38 +121,38 @@ class EdgeTracks(object):
 
     def targets(self, rows):
         """id of the character each track of the batch consumes next (the one whose probability `advance` looks at)"""
-        rows = np.asarray(rows)
-        return np.fromiter((self.ids[a][p] for a, p in zip(self.alt[rows], self.pos[rows])), dtype=np.int64, count=len(rows))
+        ids, alt, pos = self.ids, self.alt, self.pos
+        return [ids[alt[i]][pos[i]] for i in rows]
 
     def advance(self, rows, probs, new_states, target=None):
         """consume one character on every track of the batch; probs: [n, V] rows, or [n] -- already the probabilities
-        of `targets(rows)` (`target`: that array, if the caller has it)"""
-        rows = np.asarray(rows)
-        alt, pos = self.alt[rows], self.pos[rows]
+        of `targets(rows)` (`target`: that list, if the caller has it)"""
         if target is None:
             target = self.targets(rows)
-        if not target.all():
-            for k, (a, p) in enumerate(zip(alt, pos)):
+        alt, pos, cum, state = self.alt, self.pos, self.cum, self.state
+        if not all(target):
+            for k, i in enumerate(rows):
+                a, p = alt[i], pos[i]
                 if self.unmapped[a][p] and self.text[a][p] not in self.reported[a]:
                     self.reported[a].add(self.text[a][p])
                     self.logger.error('unmapped character "%s" at input alternative %d of element %s', self.text[a][p],
                                       self.alternatives[a].index or k, self.element.id if self.element else "space")
         probs = np.asarray(probs, dtype=np.float64)
-        p_next = np.maximum(probs if probs.ndim == 1 else probs[np.arange(len(rows)), target], 1e-99)
+        p_next = (probs if probs.ndim == 1 else probs[np.arange(len(rows)), np.asarray(target)]).tolist()
+        w, conf = self.lm_weight, self.conf_term
         # (math.log(p, 2) element by element, as the reference computes it (rating.py:843): np.log2 -- and numpy's own log --
         #  can differ from libm in the last bit, and ties and the +2.5 / +15 margins are decided on exact values)
-        lg = np.fromiter((log(x, 2) for x in p_next.tolist()), dtype=np.float64, count=len(rows))
-        self.cum[rows] += -lg * self.lm_weight + self.conf_term[alt]
-        self.pos[rows] = pos + 1
-        for i, s in zip(rows, new_states):
-            self.state[i] = s
+        for i, p, s in zip(rows, p_next, new_states):
+            cum[i] += -log(p if p > 1e-99 else 1e-99, 2) * w + conf[alt[i]]
+            pos[i] += 1
+            state[i] = s
 
     def node(self, i):
         """the tree node of a finished track (only the survivors get one)"""
         alt = self.alternatives[self.alt[i]]
         parent = self.incoming[self.parent[i]]
         n = Node(parent=parent, state=self.state[i], value=alt.Unicode, cost=0.0, extras=(self.element, alt))
-        n.cum_cost = float(self.cum[i])      # the running sum itself, not parent + difference (last-bit identical)
+        n.cum_cost = self.cum[i]      # the running sum itself, not parent + difference (last-bit identical)
         return n
 
 
@@ -161,13 +165,14 @@ def decode_edge(tracks, finished, predict, batch_size, max_batches, close_states
     # the waiting list: track numbers + keys.  It starts in creation order (UNSORTED, as in the reference, whose first
     # batch is therefore cut off the end of the creation order) and is kept sorted from the first re-queueing on.
     waiting = list(range(len(tracks)))
-    wkeys = [float(k) for k in tracks.keys(np.arange(len(tracks)))] if waiting else []
+    wkeys = tracks.keys(waiting)
+    pos, length, alt, cum, state = tracks.pos, tracks.length, tracks.alt, tracks.cum, tracks.state
     for _ in range(max_batches):
         # ---- cut the next batch off the worst end; finished tracks found on the way move to the destination beam
         batch, taken = [], 0
         for i in reversed(waiting):
             taken += 1
-            if tracks.pos[i] == tracks.length[tracks.alt[i]]:
+            if pos[i] == length[alt[i]]:
                 _finish(tracks, finished, i, close_states)
             else:
                 batch.append(i)
@@ -178,24 +183,22 @@ def decode_edge(tracks, finished, predict, batch_size, max_batches, close_states
         if not batch:
             break
         batch.reverse()                                           # back to list order, then ordered by key:
-        bkeys = tracks.keys(np.asarray(batch))
-        order = np.argsort(bkeys, kind="stable")                  # insort_left of nodes popped from the end = a stable sort
-        batch = [batch[k] for k in order]
-        if len(finished) and tracks.cum[batch[0]] >= finished.best_cost(tracks) + FINISHED_MARGIN:
+        bkeys = tracks.keys(batch)
+        batch = [batch[k] for k in sorted(range(len(batch)), key=bkeys.__getitem__)]     # insort_left of nodes popped from the end = a stable sort
+        if len(finished) and cum[batch[0]] >= finished.best_cost(tracks) + FINISHED_MARGIN:
             break
         # ---- one character on every track of the batch
         target = tracks.targets(batch)
-        probs, new_states = predict(tracks.last_chars(batch), [tracks.state[i] for i in batch], target)
+        probs, new_states = predict(tracks.last_chars(batch), [state[i] for i in batch], target)
         tracks.advance(batch, probs, new_states, target)
         # ---- back into the waiting list, unless hopeless against its current head
-        nkeys = tracks.keys(np.asarray(batch))
-        for i, key in zip(batch, nkeys):
-            if waiting and tracks.cum[i] >= tracks.cum[waiting[0]] + WAITING_MARGIN:
-                tracks.state[i] = None
+        for i, key in zip(batch, tracks.keys(batch)):
+            if waiting and cum[i] >= cum[waiting[0]] + WAITING_MARGIN:
+                state[i] = None
                 continue
-            pos = bisect_left(wkeys, key)
-            wkeys.insert(pos, float(key))
-            waiting.insert(pos, i)
+            at = bisect_left(wkeys, key)
+            wkeys.insert(at, key)
+            waiting.insert(at, i)
         del waiting[max_batches * batch_size:]
         del wkeys[max_batches * batch_size:]
 
@@ -203,7 +206,7 @@ def decode_edge(tracks, finished, predict, batch_size, max_batches, close_states
 def _finish(tracks, finished, i, close_states):
     """a track has consumed its alternative: history clustering against the destination beam, then insertion"""
     if close_states is not None:
-        value, state, cost = tracks.text[tracks.alt[i]], tracks.state[i], float(tracks.cum[i])
+        value, state, cost = tracks.text[tracks.alt[i]], tracks.state[i], tracks.cum[i]
         for k in range(len(finished)):
             other_value, other_state, other_cost = finished.value_state_cost(k, tracks)
             if value == other_value and close_states(state, other_state):
@@ -211,7 +214,7 @@ def _finish(tracks, finished, i, close_states):
                     return                                     # redundant: the cheaper twin is already there
                 finished.remove_first_with_key(finished.keys[k])
                 break
-    finished.insert(float(tracks.cum[i]), ("track", i))
+    finished.insert(tracks.cum[i], ("track", i))
 
 
 def lattice_edges(graph, start):
@@ -219,8 +222,9 @@ def lattice_edges(graph, start):
     (rating.py:763-773)"""
     import networkx as nx
     reached = {start}
+    pred = graph.pred
     for node in nx.topological_sort(graph):
-        for source, _ in graph.in_edges([node]):
+        for source in pred[node]:      # (= graph.in_edges([node]) without a view object per node)
             if source in reached:
                 yield source, node
                 reached.add(node)

@@ -160,6 +160,7 @@ class Rater(object):
         self.batched_streams_max_chars = 1 << 30
         self._engine_factory = engine_factory
         self._pool = None
+        self._ctx_rows = None
         self._stop = False
 
     # ------------------------------------------------------------------ definition
@@ -846,8 +847,13 @@ class Rater(object):
         if hasattr(lm, "step_host"):
             new, slots = pool.refs(n)
             zero = pool.zero_slot
-            slot_in = np.array([s.slot if s is not None else zero for s in states], dtype=np.int32)
-            probs, hv = lm.step_host(self._ids(candidates), np.tile(ctx, (n, 1)), slot_in, np.array(slots, dtype=np.int32),
+            c_i = self.mapping[0]
+            packed = np.array([[c_i.get(c, 0) for c in candidates], [s.slot if s is not None else zero for s in states], slots],
+                              dtype=np.int32)
+            key = (n, tuple(ctx.tolist()))
+            if self._ctx_rows is None or self._ctx_rows[0] != key:      # (one context per page: the same rows edge after edge)
+                self._ctx_rows = (key, np.tile(ctx, (n, 1)))
+            probs, hv = lm.step_host(packed[0], self._ctx_rows[1], packed[1], packed[2],
                                      target=targets, head_k=self.depth if heads else 0)
             if heads:
                 for r, v in zip(new, hv):
