@@ -554,14 +554,21 @@ def main():
         for Wm in (128, 64):
             try:
                 entry = {}
-                for Bs, st in ((1024, 50), (1, 100)):
+                for Bs, st in ((1024, 50), (4096, 20), (1, 100)) if Wm == 128 else ((1024, 50), (1, 100)):
                     leg, lmm = training_leg(device, DEPTH, Wm, LENGTH, N_CTX, Bs, st, 5, corpus[:max(Bs, 64) * (CORPUS // 1024)])
                     del lmm
-                    entry["streams_%d" % Bs] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps")}
+                    e = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps", "mfma_frac")}
+                    # algorithmic HBM bytes of a training step per character and layer (time-major rows; bf16 unless noted): forward
+                    # P f32 written + read (32 W), G written (8 W), C f32 (4 W), H (2 W), masked H (2 W); backward G, C, dH f32 read
+                    # (8 + 4 + 4 W), dZ written (8 W); weight gradients read dZ twice and H / X once each (16 + 4 W); dX reads dZ (8 W)
+                    # and writes dH (4 W): ~104 W bytes per character and layer
+                    e["hbm_frac"] = leg["value"] * 104.0 * Wm * DEPTH / 1e9 / HBM_PEAK_GBS
+                    entry["streams_%d" % Bs] = e
                 ref_models["width_%d" % Wm] = entry
             except Exception as err:
                 ref_models["width_%d" % Wm] = {"error": repr(err)}
-        ref_models["note"] = "depth 2, length 256, V=256, 1 context; width 128 = the published model's topology (README.md:252-254)"
+        ref_models["note"] = ("depth 2, length 256, V=256, 1 context; width 128 = the published model's topology (README.md:252-254); from 512 "
+                              "streams on the one-workgroup-per-row-block scans of lstm_scan_w128.hip; hbm_frac: ~104 W bytes per character and layer")
         torch.cuda.empty_cache()
         # cfg2 at stream counts beside the default: 1000 and 4096 streams (the engine pads / regroups such batches around the
         # counts the persistent scans take, HipLM._stream_groups), 2 context variables at the default count

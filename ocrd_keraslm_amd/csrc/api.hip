@@ -152,6 +152,7 @@ struct kl_handle {
   bool logits_ws = true;        // KL_LOGITS_WS = 0: GEMM + softmax kernel for the training window's output layer instead of the fused kernel
   bool proj_ws = true;          // KL_PROJ_WS = 0: the ring GEMM for the gate inputs P of the second-generation scans too
   bool w128 = true;             // KL_W128 = 0: the thin fused scans also at width 128 (lstm_scan_w128.hip: a workgroup per 16-row block, all units)
+  bool w128_fuse = true;        // KL_W128_FUSE = 0: ... with the input side of the layers above the first from products over all steps
   int w128_min = 512;           // ... from this many streams on (KL_W128_MIN; measured: 512 streams 3.08 against 3.15 ms per step, 256: 2.77 / 2.43)
   bool fwd8 = true;             // KL_FWD8 = 0: the 16-wave forward scan also for the layers above the first (default: the eight-wave scan of
                                 // lstm_scan_fwd8.hip there -- 3.06 against 3.36 ms per launch at 3072 streams)
@@ -609,17 +610,21 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
   // it their gate inputs from one product over all steps.
   if (!scanned && training && h->scan_enabled && h->w128 && B >= h->w128_min && kl_scan_w128_applicable(B, T, W)) {
     for (int l = 0; l < L; ++l) {
-      if (l > 0) {
-        const bool masked_in = masks != nullptr && (l - 1) > 0;
-        const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
-        KL_TRY(kl_launch_gemm_tn(X, d.KT_hi[l], w.P1, P + h->off_b[l], B * T, 4 * W, W, W, W, 4 * W, 0, 1, 1.f, s));
-      }
       const bool masked = masks != nullptr && l > 0;
       KlScanFwdWide a;
       memset(&a, 0, sizeof(a));
       a.B = B; a.T = T; a.W = W;
       a.UT = d.UT_hi[l];
       a.P = w.P1;
+      if (l > 0) {
+        const bool masked_in = masks != nullptr && (l - 1) > 0;
+        const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
+        if (h->w128_fuse) {      // the input contraction inside the scan: no P rows, no product over all steps
+          a.P = nullptr; a.KT = d.KT_hi[l]; a.X = X; a.bias = P + h->off_b[l];
+        } else {
+          KL_TRY(kl_launch_gemm_tn(X, d.KT_hi[l], w.P1, P + h->off_b[l], B * T, 4 * W, W, W, W, 4 * W, 0, 1, 1.f, s));
+        }
+      }
       a.H = (bf16_t*)w.H[l]; a.C = w.C[l]; a.G = w.G[l];
       a.Hd = masked ? w.Hd[l] : nullptr;
       a.mask = masked ? masks + (size_t)l * BW : nullptr;
@@ -1049,6 +1054,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   if (env8h) h->proj_ws = atoi(env8h) != 0;
   const char* env8p = getenv("KL_W128");
   if (env8p) h->w128 = atoi(env8p) != 0;
+  const char* env8s = getenv("KL_W128_FUSE");
+  if (env8s) h->w128_fuse = atoi(env8s) != 0;
   const char* env8q = getenv("KL_W128_MIN");
   if (env8q) h->w128_min = atoi(env8q);
   const char* env8m = getenv("KL_FWD8");
@@ -1321,7 +1328,9 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
                           (thin_fits || wide_fits));
   if (sequential || w.scan2_bwd) {
     for (int l = L - 1; l >= 0; --l) {
-      if (l < L - 1)   // dX_l = dZ_{l+1} . K_{l+1}^T  -> w.dH (free once the layer above has been scanned)
+      // (width 128: the scan of lstm_scan_w128.hip contracts the layer above's dZ rows itself)
+      const bool fuse_dx = seq128 && h->w128_fuse && l < L - 1;
+      if (l < L - 1 && !fuse_dx)   // dX_l = dZ_{l+1} . K_{l+1}^T  -> w.dH (free once the layer above has been scanned)
         KL_TRY(kl_launch_gemm_tn(w.dZ[l + 1], d.Kn[l + 1], w.dH, nullptr, BT, W, 4 * W, 4 * W, 4 * W, W, dh_mode, 1, 1.f, s));
       KlScanBwd a;
       memset(&a, 0, sizeof(a));
@@ -1378,7 +1387,9 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
         KlScanBwd a1 = a;
         a1.dZT = nullptr;
         a1.sentinel = 0;
+        if (fuse_dx) { a1.Kn[1] = d.Kn[l + 1]; a1.dZ[1] = w.dZ[l + 1]; }
         e = kl_launch_scan_bwd_w128(a1, s);
+        if (e == KL_ERR_SHAPE && fuse_dx) return KL_ERR_SHAPE;      // (the dX product was skipped for it)
         w128k = e == 0;
         if (w128k) a.dZT = nullptr;
       }

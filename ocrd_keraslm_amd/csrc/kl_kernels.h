@@ -184,6 +184,7 @@ struct KlScanFwdWide {
   bf16_t* Cb;                          // second generation: cell states for the backward scan as bf16 [(T+1)B][W] (blocks 1..T written;
                                        // C then only receives block T, the carried-out state); null: every block goes to C in f32
   int p_bf16;                          // second generation: P is bf16 [T*B][W][4 gates] (8 bytes per cell) instead of f32
+  const bf16_t* KT; const bf16_t* X;   // width-128 scan only: input kernel [4W][W] + input rows [T*B][W] (with `bias`): the input side inside the scan
 };
 // width 128: a workgroup = a 16-row block of streams with ALL hidden units of one layer, no hand-off between workgroups
 // (lstm_scan_w128.hip); forward takes f32 P rows only; backward as the wide one-layer kernels (a.L == 1, db summed)

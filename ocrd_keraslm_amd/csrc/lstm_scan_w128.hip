@@ -41,10 +41,16 @@ constexpr int F_HT = 0, F_PB = F_HT + 2 * 16 * F_H_LD, F_GS = F_PB + 2 * 16 * F_
               F_HS = F_CS + 2 * 16 * F_C_LD, F_LDS = F_HS + 2 * 16 * F_H_LD;
 // backward LDS: dZ tiles [2][16][1040] | gates [2][16][1024] | c_{t-1} [2][16][512] | dH [2][16][512]
 constexpr int B_Z_LD = 1040;
-constexpr int B_ZT = 0, B_GB = B_ZT + 2 * 16 * B_Z_LD, B_CB = B_GB + 2 * 16 * 1024, B_DH = B_CB + 2 * 16 * 512, B_LDS = B_DH + 2 * 16 * 512;
+constexpr int B_ZT = 0, B_GB = B_ZT + 2 * 16 * B_Z_LD, B_CB = B_GB + 2 * 16 * 1024, B_DH = B_CB + 2 * 16 * 512, B_LDS = B_DH + 2 * 16 * 512,
+              B_LDS_XIN = B_DH + 2 * 16 * B_Z_LD;      // (XIN: the layer above's dZ tiles instead of the dH rows)
 
 __device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
 
+// KIN: the layer's input contraction happens HERE as well -- z = bias + X[t] . K^T + h[t-1] . U^T with K resident beside U (2 x 64
+// registers) and the 16 x 128 input rows X[t] (the layer below's -- masked -- outputs) staged like the state tile -- instead of
+// f32 gate-input rows P from a product over all steps: a step reads 4 KiB instead of 32, the P rows (2.1 GB written and read
+// per window at 4096 streams) and their GEMM disappear.
+template <bool KIN>
 __global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_kernel(const KlScanFwdWide a) {
   constexpr int W = W8;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -65,6 +71,18 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_kernel(const KlScan
       const long wrow = ((long)(col & 3) * W + 16 * wave + 4 * (col >> 2) + c) * W + (lane >> 4) * 8;
 #pragma unroll
       for (int j = 0; j < 4; ++j) bu[c][j] = *reinterpret_cast<const u32x4*>(a.UT + wrow + j * 32);
+    }
+  }
+  u32x4 bk[KIN ? 4 : 1][4];
+  float bias_c[4] = {0.f, 0.f, 0.f, 0.f};      // (KIN: the bias of this lane's column in each tile -- the accumulators start from it)
+  if (KIN) {
+    const int col = lane & 15;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const long wrow = ((long)(col & 3) * W + 16 * wave + 4 * (col >> 2) + c) * W + (lane >> 4) * 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bk[c][j] = *reinterpret_cast<const u32x4*>(a.KT + wrow + j * 32);
+      bias_c[c] = a.bias[(col & 3) * W + 16 * wave + 4 * (col >> 2) + c];
     }
   }
   // cell states and keep-masks of this lane's four cells
@@ -94,29 +112,47 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_kernel(const KlScan
     const int i = tid + NT8 * k, row = i >> 7, seg = i & 127;
     *reinterpret_cast<float4*>(smem + F_PB + (buf * 16 + row) * F_P_LD + seg * 16) = v;
   };
+  // (KIN: the input rows X[t] -- 16 x 256 bytes, threads 0 .. 255 -- take the place of the gate-input rows; tile [2][16][272] at F_PB)
+  auto x_load = [&](int t) __attribute__((always_inline)) {
+    uint4 v = uint4{0u, 0u, 0u, 0u};
+    if (tid < 256 && h_row < nrow) v = *reinterpret_cast<const uint4*>(a.X + ((long)t * B + row0 + h_row) * W + h_seg * 8);
+    return v;
+  };
+  auto x_put = [&](int buf, uint4 v) __attribute__((always_inline)) {
+    if (tid < 256) *reinterpret_cast<uint4*>(smem + F_PB + (buf * 16 + h_row) * F_H_LD + h_seg * 16) = v;
+  };
   // ---- prologue: the carried-in h rows, the gate inputs of step 0
   if (tid < 256) {
     uint4 v = uint4{0u, 0u, 0u, 0u};
     if (h_row < nrow) v = *reinterpret_cast<const uint4*>(a.H + ((long)row0 + h_row) * W + h_seg * 8);
     *reinterpret_cast<uint4*>(smem + F_HT + h_row * F_H_LD + h_seg * 16) = v;
   }
+  if (KIN) {
+    x_put(0, x_load(0));
+  } else {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) p_put(0, k, p_load(0, k));
+    for (int k = 0; k < 4; ++k) p_put(0, k, p_load(0, k));
+  }
   __syncthreads();
 
   for (int t = 0; t < T; ++t) {
     const int p = t & 1;
     // the gate inputs of the next step are on their way while this one computes (two steps ahead measured the same: the step
     // is bound by its ~350 vector instructions per wave -- 4 cells per lane, 10 transcendentals each --, not by the loads)
-    float4 pn[4];
+    float4 pn[KIN ? 1 : 4];
+    uint4 xn = uint4{0u, 0u, 0u, 0u};
     if (t + 1 < T) {
+      if (KIN) {
+        xn = x_load(t + 1);
+      } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) pn[k] = p_load(t + 1, k);
+        for (int k = 0; k < 4; ++k) pn[k] = p_load(t + 1, k);
+      }
     }
-    // ---- h[t-1] . U^T: 16 rows x this wave's 64 columns
+    // ---- h[t-1] . U^T (+ X[t] . K^T): 16 rows x this wave's 64 columns
     f32x4 acc[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4{bias_c[c], bias_c[c], bias_c[c], bias_c[c]};
     {
       const unsigned char* tb = smem + F_HT + (p * 16 + (lane & 15)) * F_H_LD + (lane >> 4) * 16;
 #pragma unroll
@@ -125,11 +161,23 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_kernel(const KlScan
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = mfma16(fa, __builtin_bit_cast(bf16x8, bu[c][j]), acc[c]);
       }
+      if (KIN) {
+        const unsigned char* xb = smem + F_PB + (p * 16 + (lane & 15)) * F_H_LD + (lane >> 4) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bf16x8 fx = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xb + j * 64));
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = mfma16(fx, __builtin_bit_cast(bf16x8, bk[c][j]), acc[c]);
+        }
+      }
     }
     // ---- the cell: after the quad transpose lane = (row, unit), registers = gates
     f32x4 pin[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) pin[g] = *reinterpret_cast<const f32x4*>(smem + F_PB + (p * 16 + crow) * F_P_LD + (g * W + cu) * 4);
+    for (int g = 0; g < 4; ++g) {
+      if (KIN) pin[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      else pin[g] = *reinterpret_cast<const f32x4*>(smem + F_PB + (p * 16 + crow) * F_P_LD + (g * W + cu) * 4);
+    }
     float hv[4], gi[4], gf[4], gg[4], go[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -154,8 +202,12 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_kernel(const KlScan
       *reinterpret_cast<uint2*>(gs + 768) = uint2{pack2(go[0], go[1]), pack2(go[2], go[3])};
     }
     if (t + 1 < T) {
+      if (KIN) {
+        x_put(p ^ 1, xn);
+      } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) p_put(p ^ 1, k, pn[k]);
+        for (int k = 0; k < 4; ++k) p_put(p ^ 1, k, pn[k]);
+      }
     }
     __syncthreads();
     // ---- this step's rows to memory, whole rows
@@ -181,6 +233,10 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_kernel(const KlScan
 
 // dh[t] = dH[t] (from above, all steps at once: the softmax side or the layer above's dX product) * mask + dZ[t+1] . U^T;
 // dZ[t] from the gate derivatives; db summed on the way
+// XIN: the gradient from above is contracted HERE -- dh[t] = mask * (dZ_above[t] . K_above^T) + dZ[t+1] . U^T with K_above
+// resident beside U and the 16 x 512 rows of the layer above's dZ[t] staged like this layer's own tile -- instead of f32 dH rows
+// from a product over all steps (a.Kn[1] / a.dZ[1] = the layer above's input kernel [W][4W] and dZ [T*B][4W]).
+template <bool XIN>
 __global__ __launch_bounds__(NT8, 1) void lstm_scan_bwd_w128_kernel(const KlScanBwd a) {
   constexpr int W = W8;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -196,6 +252,11 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_bwd_w128_kernel(const KlScan
   u32x4 bu[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) bu[j] = *reinterpret_cast<const u32x4*>(a.Un[0] + (long)u * 4 * W + j * 32 + q4 * 8);
+  u32x4 bk[XIN ? 16 : 1];
+  if (XIN) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bk[j] = *reinterpret_cast<const u32x4*>(a.Kn[1] + (long)u * 4 * W + j * 32 + q4 * 8);
+  }
   float ccur[4], dc[4], mk[4], dbacc[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -207,7 +268,7 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_bwd_w128_kernel(const KlScan
   }
   // rows between memory and LDS: gates (2 pieces of 16 bytes per thread and step), c_{t-1} (1), dH (1), dZ out (2)
   const int c_row = tid >> 5, c_seg = tid & 31;
-  struct In { uint4 g[2]; float4 c, d; };
+  struct In { uint4 g[2]; float4 c, d; uint4 za[2]; };
   auto in_load = [&](int t) __attribute__((always_inline)) {
     In v;
     const long trow = (long)t * B + row0;
@@ -215,24 +276,30 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_bwd_w128_kernel(const KlScan
     for (int k = 0; k < 2; ++k) {
       const int i = tid + NT8 * k, row = i >> 6, seg = i & 63;
       v.g[k] = uint4{0u, 0u, 0u, 0u};
-      if (row < nrow) v.g[k] = *reinterpret_cast<const uint4*>(a.G[0] + (trow + row) * 4 * W + seg * 8);
+      v.za[k] = uint4{0u, 0u, 0u, 0u};
+      if (row < nrow) {
+        v.g[k] = *reinterpret_cast<const uint4*>(a.G[0] + (trow + row) * 4 * W + seg * 8);
+        if (XIN) v.za[k] = *reinterpret_cast<const uint4*>(a.dZ[1] + (trow + row) * 4 * W + seg * 8);
+      }
     }
     v.c = float4{0.f, 0.f, 0.f, 0.f};
     v.d = float4{0.f, 0.f, 0.f, 0.f};
     if (c_row < nrow) {
       v.c = *reinterpret_cast<const float4*>(a.C[0] + (trow + c_row) * W + c_seg * 4);      // block t = c_{t-1}
-      v.d = *reinterpret_cast<const float4*>(a.dH + (trow + c_row) * W + c_seg * 4);
+      if (!XIN) v.d = *reinterpret_cast<const float4*>(a.dH + (trow + c_row) * W + c_seg * 4);
     }
     return v;
   };
+  // (XIN: the rows of the layer above's dZ -- tile [2][16][1040] -- take the place of the dH rows, from B_DH on)
   auto in_put = [&](int buf, const In& v) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int i = tid + NT8 * k, row = i >> 6, seg = i & 63;
       *reinterpret_cast<uint4*>(smem + B_GB + (buf * 16 + row) * 1024 + seg * 16) = v.g[k];
+      if (XIN) *reinterpret_cast<uint4*>(smem + B_DH + (buf * 16 + row) * B_Z_LD + seg * 16) = v.za[k];
     }
     *reinterpret_cast<float4*>(smem + B_CB + (buf * 16 + c_row) * 512 + c_seg * 16) = v.c;
-    *reinterpret_cast<float4*>(smem + B_DH + (buf * 16 + c_row) * 512 + c_seg * 16) = v.d;
+    if (!XIN) *reinterpret_cast<float4*>(smem + B_DH + (buf * 16 + c_row) * 512 + c_seg * 16) = v.d;
   };
   in_put((T - 1) & 1, in_load(T - 1));
   __syncthreads();
@@ -249,6 +316,13 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_bwd_w128_kernel(const KlScan
       for (int j = 0; j < 16; ++j)
         acc = mfma16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tb + j * 64)), __builtin_bit_cast(bf16x8, bu[j]), acc);
     }
+    f32x4 above = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (XIN) {
+      const unsigned char* tb = smem + B_DH + (p * 16 + (lane & 15)) * B_Z_LD + q4 * 16;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        above = mfma16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tb + j * 64)), __builtin_bit_cast(bf16x8, bk[j]), above);
+    }
     // ---- gate derivatives of this lane's four cells (rows 4 q4 + r, unit u)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -257,7 +331,7 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_bwd_w128_kernel(const KlScan
       const float gi = bf2f(*reinterpret_cast<const bf16_t*>(gb)), gf = bf2f(*reinterpret_cast<const bf16_t*>(gb + 256));
       const float gg = bf2f(*reinterpret_cast<const bf16_t*>(gb + 512)), go = bf2f(*reinterpret_cast<const bf16_t*>(gb + 768));
       const float cprev = *reinterpret_cast<const float*>(smem + B_CB + (p * 16 + row) * 512 + u * 4);
-      const float dh = acc[r] + mk[r] * *reinterpret_cast<const float*>(smem + B_DH + (p * 16 + row) * 512 + u * 4);
+      const float dh = acc[r] + mk[r] * (XIN ? above[r] : *reinterpret_cast<const float*>(smem + B_DH + (p * 16 + row) * 512 + u * 4));
       const float tc = fast_tanh(ccur[r]);
       const float d_o = dh * tc;
       dc[r] += dh * go * (1.f - tc * tc);
@@ -302,20 +376,31 @@ bool kl_scan_w128_applicable(int B, int T, int W) {
   return W == W8 && B >= 1 && T >= 1 && (long)(T + 1) * B * 4 * W * 4 < 0x7fffffffffffL;
 }
 
-// KL_ERR_SHAPE = not applicable.  Takes gate inputs as f32 rows P [T*B][4W] (gate-major, bias included) only.
+// KL_ERR_SHAPE = not applicable.  Gate inputs: f32 rows P [T*B][4W] (gate-major, bias included), or -- a.KT != null -- the input
+// rows a.X [T*B][W] bf16 with the input kernel a.KT [4W][W] and a.bias [4W] (the contraction then happens inside the scan).
 int kl_launch_scan_fwd_w128(KlScanFwdWide a, hipStream_t stream) {
-  if (!kl_scan_w128_applicable(a.B, a.T, a.W) || !a.P || a.p_bf16 || a.HT || a.HdT || !a.H || !a.C || !a.UT) return KL_ERR_SHAPE;
-  static KlLdsGrant grant;
-  if (kl_grant_lds(grant, reinterpret_cast<const void*>(&lstm_scan_fwd_w128_kernel), (size_t)F_LDS)) return KL_ERR_LAUNCH;
-  hipLaunchKernelGGL(lstm_scan_fwd_w128_kernel, dim3((a.B + 15) / 16), dim3(NT8), (size_t)F_LDS, stream, a);
+  if (!kl_scan_w128_applicable(a.B, a.T, a.W) || a.p_bf16 || a.HT || a.HdT || !a.H || !a.C || !a.UT) return KL_ERR_SHAPE;
+  const bool kin = a.KT != nullptr;
+  if (kin ? (!a.X || !a.bias) : !a.P) return KL_ERR_SHAPE;
+  static KlLdsGrant grant[2];
+  const void* fn = kin ? reinterpret_cast<const void*>(&lstm_scan_fwd_w128_kernel<true>) : reinterpret_cast<const void*>(&lstm_scan_fwd_w128_kernel<false>);
+  if (kl_grant_lds(grant[kin], fn, (size_t)F_LDS)) return KL_ERR_LAUNCH;
+  if (kin) hipLaunchKernelGGL(lstm_scan_fwd_w128_kernel<true>, dim3((a.B + 15) / 16), dim3(NT8), (size_t)F_LDS, stream, a);
+  else hipLaunchKernelGGL(lstm_scan_fwd_w128_kernel<false>, dim3((a.B + 15) / 16), dim3(NT8), (size_t)F_LDS, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 
-// one layer (a.L == 1; Un[0], G[0], C[0], dZ[0], mask[0], dH f32 [T*B][W], db)
+// one layer (a.L == 1; Un[0], G[0], C[0], dZ[0], mask[0], db); the gradient from above: dH f32 [T*B][W], or -- a.Kn[1] != null --
+// the layer above's dZ rows a.dZ[1] [T*B][4W] with its input kernel a.Kn[1] [W][4W] (contracted inside the scan)
 int kl_launch_scan_bwd_w128(KlScanBwd a, hipStream_t stream) {
-  if (!kl_scan_w128_applicable(a.B, a.T, a.W) || a.L != 1 || a.dZT || !a.dH || !a.Un[0] || !a.G[0] || !a.C[0] || !a.dZ[0]) return KL_ERR_SHAPE;
-  static KlLdsGrant grant;
-  if (kl_grant_lds(grant, reinterpret_cast<const void*>(&lstm_scan_bwd_w128_kernel), (size_t)B_LDS)) return KL_ERR_LAUNCH;
-  hipLaunchKernelGGL(lstm_scan_bwd_w128_kernel, dim3((a.B + 15) / 16), dim3(NT8), (size_t)B_LDS, stream, a);
+  if (!kl_scan_w128_applicable(a.B, a.T, a.W) || a.L != 1 || a.dZT || !a.Un[0] || !a.G[0] || !a.C[0] || !a.dZ[0]) return KL_ERR_SHAPE;
+  const bool xin = a.Kn[1] != nullptr;
+  if (xin ? !a.dZ[1] : !a.dH) return KL_ERR_SHAPE;
+  static KlLdsGrant grant[2];
+  const void* fn = xin ? reinterpret_cast<const void*>(&lstm_scan_bwd_w128_kernel<true>) : reinterpret_cast<const void*>(&lstm_scan_bwd_w128_kernel<false>);
+  const size_t lds = xin ? (size_t)B_LDS_XIN : (size_t)B_LDS;
+  if (kl_grant_lds(grant[xin], fn, lds)) return KL_ERR_LAUNCH;
+  if (xin) hipLaunchKernelGGL(lstm_scan_bwd_w128_kernel<true>, dim3((a.B + 15) / 16), dim3(NT8), lds, stream, a);
+  else hipLaunchKernelGGL(lstm_scan_bwd_w128_kernel<false>, dim3((a.B + 15) / 16), dim3(NT8), lds, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }

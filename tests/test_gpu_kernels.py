@@ -632,6 +632,24 @@ def test_train_window_width_1024_scans(monkeypatch, depth, width, voc, B, T, n_c
     check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks, want_kernel="lstm_scan_bwd_w32_kernel")
 
 
+@pytest.mark.parametrize("depth,width,voc,B,T,n_ctx,use_masks,env", [
+    (2, 128, 70, 40, 12, 1, True, {"KL_W128_MIN": "1"}),        # three row blocks, the last one half full; layer 1's input side inside the scan
+    (3, 128, 30, 20, 6, 2, True, {"KL_W128_MIN": "1"}),         # three layers, two context variables
+    (1, 128, 40, 24, 7, 1, False, {"KL_W128_MIN": "1"}),        # one layer, no dropout
+    (2, 100, 50, 24, 9, 1, True, {"KL_W128_MIN": "1"}),         # width 100 zero-padded to 128
+    (2, 128, 50, 600, 5, 1, True, {}),                          # the default path from 512 streams
+    (2, 128, 70, 40, 12, 1, True, {"KL_W128_MIN": "1", "KL_W128_FUSE": "0"}),      # input side / gradient from above by products over all steps
+    (4, 128, 30, 33, 5, 1, True, {"KL_W128_MIN": "1"})])        # four layers
+def test_train_window_width_128_scans(monkeypatch, depth, width, voc, B, T, n_ctx, use_masks, env):
+    """Width 128 (the reference's published model size): the scans of lstm_scan_w128.hip -- a workgroup per 16-row block of
+    streams with all hidden units of a layer, no hand-off between workgroups; the layers above the first contract their
+    inputs (forward) and the gradient from above (backward) inside the scan: gradients, loss and carried state against
+    the f64 oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks, want_kernel="lstm_scan_bwd_w128_kernel")
+
+
 @pytest.mark.parametrize("B,T", [(144, 4), (512, 3)])
 def test_width_1024_scans_consecutive_windows(monkeypatch, B, T):
     """the width-1024 scans over consecutive windows (sentinels re-armed per window, carried state, replayed graph),
