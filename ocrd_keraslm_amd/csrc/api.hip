@@ -152,6 +152,8 @@ struct kl_handle {
   bool logits_ws = true;        // KL_LOGITS_WS = 0: GEMM + softmax kernel for the training window's output layer instead of the fused kernel
   bool proj_ws = true;          // KL_PROJ_WS = 0: the ring GEMM for the gate inputs P of the second-generation scans too
   bool w128 = true;             // KL_W128 = 0: the thin fused scans also at width 128 (lstm_scan_w128.hip: a workgroup per 16-row block, all units)
+  bool w128_tables = true;      // KL_W128_TABLES = 0: layer 0's gate inputs gathered into f32 rows first instead of inside the scan
+  bool w128_multi = true;       // KL_W128_MULTI = 0: one launch per layer also where all layers' workgroups fit the CUs at once
   bool w128_fuse = true;        // KL_W128_FUSE = 0: ... with the input side of the layers above the first from products over all steps
   int w128_min = 512;           // ... from this many streams on (KL_W128_MIN; measured: 512 streams 3.08 against 3.15 ms per step, 256: 2.77 / 2.43)
   bool fwd8 = true;             // KL_FWD8 = 0: the 16-wave forward scan also for the layers above the first (default: the eight-wave scan of
@@ -378,20 +380,31 @@ int prepare_impl(kl_handle* h, int precision, hipStream_t s) {
       h->flags_zeroed = true;
     }
   }
-  for (int l = 0; l < c.depth; ++l) {
-    const float* K = P + h->off_K[l];   // layer 0: rows [0,W) are the char-embedding part
-    const float* U = P + h->off_U[l];
-    KL_TRY(kl_launch_f32_to_bf16_t(U, 4 * W, W, 4 * W, d.UT_hi[l], split ? d.UT_lo[l] : nullptr, W, 1, s));
-    KL_TRY(kl_launch_f32_to_bf16_t(K, 4 * W, W, 4 * W, d.KT_hi[l], split ? d.KT_lo[l] : nullptr, W, 1, s));
-    KL_TRY(kl_launch_f32_to_bf16_t(U, 4 * W, W, 4 * W, d.Un[l], nullptr, 4 * W, 0, s));
-    KL_TRY(kl_launch_f32_to_bf16_t(K, 4 * W, W, 4 * W, d.Kn[l], nullptr, 4 * W, 0, s));
-  }
+  // every bf16 operand derived from the parameters, in as few launches as the job list takes (a training step comes here after
+  // every Adam update): per layer U^T, K^T (hi [+ lo]) and U, K as they are; the embedding E (rows beyond the vocabulary: zeros)
+  // and E^T
   const float* E = P + h->off_E;
-  KL_TRY(kl_zero_async(d.E_hi, (size_t)Vp * W * sizeof(bf16_t), s));
-  KL_TRY(kl_zero_async(d.E_lo, (size_t)Vp * W * sizeof(bf16_t), s));
-  KL_TRY(kl_zero_async(d.ET, (size_t)W * Vp * sizeof(bf16_t), s));
-  KL_TRY(kl_launch_f32_to_bf16_t(E, W, V, W, d.E_hi, split ? d.E_lo : nullptr, W, 0, s));
-  KL_TRY(kl_launch_f32_to_bf16_t(E, W, V, W, d.ET, nullptr, Vp, 1, s));
+  {
+    KlConvJob jobs[KL_CONV_MAX_JOBS];
+    int nj = 0;
+    auto add = [&](const float* in, long ld_in, int rows, int cols, int rows_pad, bf16_t* hi, bf16_t* lo, long ld_out, int tr) -> int {
+      jobs[nj++] = KlConvJob{in, ld_in, rows, cols, rows_pad, tr, hi, lo, ld_out};
+      if (nj < KL_CONV_MAX_JOBS) return 0;
+      nj = 0;
+      return kl_launch_f32_to_bf16_jobs(jobs, KL_CONV_MAX_JOBS, s);
+    };
+    for (int l = 0; l < c.depth; ++l) {
+      const float* K = P + h->off_K[l];   // layer 0: rows [0,W) are the char-embedding part
+      const float* U = P + h->off_U[l];
+      KL_TRY(add(U, 4 * W, W, 4 * W, W, d.UT_hi[l], split ? d.UT_lo[l] : nullptr, W, 1));
+      KL_TRY(add(K, 4 * W, W, 4 * W, W, d.KT_hi[l], split ? d.KT_lo[l] : nullptr, W, 1));
+      KL_TRY(add(U, 4 * W, W, 4 * W, W, d.Un[l], nullptr, 4 * W, 0));
+      KL_TRY(add(K, 4 * W, W, 4 * W, W, d.Kn[l], nullptr, 4 * W, 0));
+    }
+    KL_TRY(add(E, W, V, W, Vp, d.E_hi, split ? d.E_lo : nullptr, W, 0));
+    KL_TRY(add(E, W, V, W, Vp, d.ET, nullptr, Vp, 1));
+    if (nj > 0) KL_TRY(kl_launch_f32_to_bf16_jobs(jobs, nj, s));
+  }
   // layer-0 look-up tables: EK = E . K0[:W] ; CtxK_n = Ctx_n . K0[W+10n ..]
   KlOperand op;
   memset(&op, 0, sizeof(op));
@@ -603,19 +616,27 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
     scanned = true;
     w.ht_ready = !w.km_plan;
   }
-  if (!scanned)
+  // Width 128 (the reference's own model sizes): a workgroup = a 16-row block of streams with ALL hidden units of a layer -- no
+  // hand-off of state between workgroups (lstm_scan_w128.hip).  Layer 0 takes its gate inputs straight from the look-up tables
+  // (up to two context variables; else the rows gathered here), the layers above it contract their inputs inside the scan.
+  const bool w128_path = !scanned && training && h->scan_enabled && h->w128 && B >= h->w128_min && kl_scan_w128_applicable(B, T, W);
+  const bool w128_tabs = w128_path && h->w128_tables && c.n_ctx <= kl_scan_w128_tables_max_ctx();
+  if (!scanned && !w128_tabs)
     KL_TRY(kl_launch_p1_gather(d.EK, ctxk.data(), c.n_ctx, P + h->off_b[0], idx, ctx, B, T, 4 * W, w.P1, s));
-  // Width 128 (the reference's own model sizes): one layer per launch, a workgroup = a 16-row block of streams with ALL hidden
-  // units -- no hand-off between workgroups (lstm_scan_w128.hip).  Layer 0 takes the table rows gathered above, the layers above
-  // it their gate inputs from one product over all steps.
-  if (!scanned && training && h->scan_enabled && h->w128 && B >= h->w128_min && kl_scan_w128_applicable(B, T, W)) {
+  if (w128_path) {
+    KlScanFwdWide layer_args[KL_SCAN_MAXL];
+    const bool try_multi = h->w128_multi && h->w128_fuse && L >= 2 && L <= KL_SCAN_MAXL;
     for (int l = 0; l < L; ++l) {
       const bool masked = masks != nullptr && l > 0;
-      KlScanFwdWide a;
+      KlScanFwdWide& a = layer_args[l < KL_SCAN_MAXL ? l : 0];
       memset(&a, 0, sizeof(a));
       a.B = B; a.T = T; a.W = W;
       a.UT = d.UT_hi[l];
       a.P = w.P1;
+      if (l == 0 && w128_tabs) {
+        a.P = nullptr; a.EK = d.EK; a.n_ctx = c.n_ctx; a.idx = idx; a.ctx = ctx; a.bias = P + h->off_b[0];
+        for (int n = 0; n < c.n_ctx; ++n) a.CtxK[n] = ctxk[n];
+      }
       if (l > 0) {
         const bool masked_in = masks != nullptr && (l - 1) > 0;
         const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
@@ -629,12 +650,40 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       a.Hd = masked ? w.Hd[l] : nullptr;
       a.mask = masked ? masks + (size_t)l * BW : nullptr;
       a.status = w.scan_status;
+      if (try_multi) continue;
       h->trace_begin(0, s);
       KL_TRY(kl_launch_scan_fwd_w128(a, s));
       h->trace_persistent[0] = true;
       h->trace_name[0] = "lstm_scan_fwd_w128_kernel";
       h->trace_flops[0] = (double)B * T * (2.0 * W * 4.0 * W);
       h->trace_end(0, s);
+    }
+    if (try_multi) {
+      // All layers in one launch where that fits the CUs (layers x 16-row blocks <= 256: up to 2048 streams at depth 2): a layer
+      // follows the one below it a step behind, polling the rows that one publishes -- which therefore start out as sentinels.
+      bool multi = kl_scan_w128_multi_fits(B, L);
+      if (multi) {
+        for (int l = 1; l < L; ++l) KL_TRY(kl_fill_u32_async(const_cast<bf16_t*>(layer_args[l].X), (size_t)T * BW * sizeof(bf16_t), 0xFFFFFFFFu, s));
+        h->trace_begin(0, s);
+        const int e = kl_launch_scan_fwd_w128_multi(layer_args, L, s);
+        if (e == KL_ERR_SHAPE) multi = false;
+        else KL_TRY(e);
+      }
+      if (multi) {
+        h->trace_persistent[0] = true;
+        h->trace_name[0] = "lstm_scan_fwd_w128_multi_kernel";
+        h->trace_flops[0] = (double)L * B * T * (2.0 * W * 4.0 * W) + (double)(L - 1) * B * T * (2.0 * W * 4.0 * W);
+        h->trace_end(0, s);
+      } else {
+        for (int l = 0; l < L; ++l) {
+          h->trace_begin(0, s);
+          KL_TRY(kl_launch_scan_fwd_w128(layer_args[l], s));
+          h->trace_persistent[0] = true;
+          h->trace_name[0] = "lstm_scan_fwd_w128_kernel";
+          h->trace_flops[0] = (double)B * T * (2.0 * W * 4.0 * W);
+          h->trace_end(0, s);
+        }
+      }
     }
     scanned = true;
   }
@@ -1056,6 +1105,10 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   if (env8p) h->w128 = atoi(env8p) != 0;
   const char* env8s = getenv("KL_W128_FUSE");
   if (env8s) h->w128_fuse = atoi(env8s) != 0;
+  const char* env8t = getenv("KL_W128_TABLES");
+  if (env8t) h->w128_tables = atoi(env8t) != 0;
+  const char* env8mm = getenv("KL_W128_MULTI");
+  if (env8mm) h->w128_multi = atoi(env8mm) != 0;
   const char* env8q = getenv("KL_W128_MIN");
   if (env8q) h->w128_min = atoi(env8q);
   const char* env8m = getenv("KL_FWD8");
@@ -1326,7 +1379,40 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
                           ((L > 1 && L <= KL_SCAN_MAXL && (W == 512 || W == 256 || W == 128) && n_rb_all > 512 / (L * nug)) ||
                            W == 1024 || (L > KL_SCAN_MAXL && (W == 512 || W == 256 || W == 128 || W == 64))) &&
                           (thin_fits || wide_fits));
-  if (sequential || w.scan2_bwd) {
+  // Width 128, all layers' workgroups fitting the CUs at once: ONE launch, a layer following the one above it a step behind (it
+  // polls the dZ rows that one publishes, which therefore start out as sentinels), then every layer's weight gradients.
+  if (seq128 && h->w128_fuse && h->w128_multi && kl_scan_w128_multi_fits(B, L)) {
+    KlScanBwd a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.T = T; a.W = W; a.L = L;
+    for (int l = 0; l < L; ++l) {
+      a.Un[l] = d.Un[l];
+      a.Kn[l] = d.Kn[l];
+      a.G[l] = w.G[l];
+      a.C[l] = w.C[l];
+      a.dZ[l] = w.dZ[l];
+      a.mask[l] = (masks != nullptr && l > 0) ? masks + (size_t)l * BW : nullptr;
+      a.db_l[l] = grads + h->off_b[l];
+    }
+    a.dH = w.dH;
+    a.status = w.scan_status + 1;
+    for (int l = 1; l < L; ++l) KL_TRY(kl_fill_u32_async(w.dZ[l], (size_t)T * BW * 4 * sizeof(bf16_t), 0xFFFFFFFFu, s));
+    h->trace_begin(1, s);
+    const int e = kl_launch_scan_bwd_w128_multi(a, s);
+    if (e != KL_ERR_SHAPE) {
+      KL_TRY(e);
+      h->trace_persistent[1] = true;
+      h->trace_name[1] = "lstm_scan_bwd_w128_multi_kernel";
+      h->trace_flops[1] = (double)(2 * L - 1) * B * T * (2.0 * W * 4.0 * W);      // (recurrent contractions + the from-above ones)
+      h->trace_end(1, s);
+      for (int l = L - 1; l >= 0; --l) {
+        KL_TRY(weight_grads(l, false, true, w.km_plan));
+        wg_done[l] = 1;
+      }
+      bscanned = true;
+    }
+  }
+  if (!bscanned && (sequential || w.scan2_bwd)) {
     for (int l = L - 1; l >= 0; --l) {
       // (width 128: the scan of lstm_scan_w128.hip contracts the layer above's dZ rows itself)
       const bool fuse_dx = seq128 && h->w128_fuse && l < L - 1;

@@ -3,6 +3,8 @@
 // cross-entropy + dlogits (F5/F6/B1), one-hot builders for the embedding
 // gradients (B7), embedding regularisers (F7), clip+Adam (O1).
 // All accesses are 16-byte vectors where the layout allows it.
+#include <string.h>
+
 #include "kl_common.h"
 #include "kl_kernels.h"
 
@@ -77,6 +79,42 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ in, long ld_in, int
     } else {
       orow = r0 + i; ocol = c0 + tx; v = tile[i][tx];
       if (orow >= rows || ocol >= cols) continue;
+    }
+    bf16_t hi, lo;
+    split_bf16(v, hi, lo);
+    out_hi[(long)orow * ld_out + ocol] = hi;
+    if (out_lo) out_lo[(long)orow * ld_out + ocol] = lo;
+  }
+}
+
+// ... a list of such conversions in one launch: blockIdx.z = the job (read through the kernel-argument segment: a by-value
+// array indexed at run time would be copied to scratch), blockIdx.x / y = its 64 x 64 tile (workgroups beyond a job's tiles leave)
+__global__ void f32_to_bf16_jobs_kernel(const KlConvJobs jobs) {
+  __shared__ float tile[64][65];
+  const KlConvJob __attribute__((address_space(4)))* jp =
+      (const KlConvJob __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.z;
+  const float* in = jp->in;
+  const long ld_in = jp->ld_in, ld_out = jp->ld_out;
+  const int rows = jp->rows, cols = jp->cols, rows_pad = jp->rows_pad, transpose = jp->transpose;
+  bf16_t* out_hi = jp->out_hi;
+  bf16_t* out_lo = jp->out_lo;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  if (r0 >= rows_pad || c0 >= cols) return;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? in[(long)r * ld_in + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    int orow, ocol;
+    float v;
+    if (transpose) {
+      orow = c0 + i; ocol = r0 + tx; v = tile[tx][i];
+      if (orow >= cols || ocol >= rows_pad) continue;
+    } else {
+      orow = r0 + i; ocol = c0 + tx; v = tile[i][tx];
+      if (orow >= rows_pad || ocol >= cols) continue;
     }
     bf16_t hi, lo;
     split_bf16(v, hi, lo);
@@ -459,6 +497,21 @@ int kl_launch_f32_to_bf16_t(const float* in, long ld_in, int rows, int cols, bf1
   dim3 grid((cols + 63) / 64, (rows + 63) / 64);
   hipLaunchKernelGGL(f32_to_bf16_kernel, grid, dim3(256), 0, stream, in, ld_in, rows, cols, out_hi, out_lo, ld_out,
                      transpose);
+  return ok();
+}
+
+int kl_launch_f32_to_bf16_jobs(const KlConvJob* jobs, int n, hipStream_t stream) {
+  if (n < 1 || n > KL_CONV_MAX_JOBS) return KL_ERR_SHAPE;
+  KlConvJobs all;
+  memset(&all, 0, sizeof(all));
+  int gx = 1, gy = 1;
+  for (int j = 0; j < n; ++j) {
+    all.job[j] = jobs[j];
+    if (all.job[j].rows_pad < all.job[j].rows) all.job[j].rows_pad = all.job[j].rows;
+    gx = max(gx, (jobs[j].cols + 63) / 64);
+    gy = max(gy, (all.job[j].rows_pad + 63) / 64);
+  }
+  hipLaunchKernelGGL(f32_to_bf16_jobs_kernel, dim3(gx, gy, n), dim3(256), 0, stream, all);
   return ok();
 }
 

@@ -190,6 +190,11 @@ struct KlScanFwdWide {
 // (lstm_scan_w128.hip); forward takes f32 P rows only; backward as the wide one-layer kernels (a.L == 1, db summed)
 bool kl_scan_w128_applicable(int B, int T, int W);
 int kl_launch_scan_fwd_w128(KlScanFwdWide args, hipStream_t stream);
+int kl_scan_w128_tables_max_ctx();      // layer 0 straight from the look-up tables (args.P == null) with up to this many context variables
+// ... all layers in one launch (layers x row blocks <= CUs, else KL_ERR_SHAPE), a layer polling the rows the one below publishes: the caller
+// pre-fills those rows (layers[l].X, l > 0) with 0xFFFF halfwords
+bool kl_scan_w128_multi_fits(int B, int L);      // 2 <= L <= 4 and L x 16-row blocks <= CUs
+int kl_launch_scan_fwd_w128_multi(const KlScanFwdWide* layers, int L, hipStream_t stream);
 bool kl_scan_fwd_wide_applicable(int B, int T, int W);
 int kl_launch_scan_fwd_wide(KlScanFwdWide args, hipStream_t stream);
 // second generation: every workgroup serves NP = 2..max_np phases of `rows` (16 or 32) rows per step; 0 = not applicable
@@ -221,6 +226,7 @@ struct KlScanBwd {
   unsigned* status;
   bf16_t* dZT; long ldt;               // wide one-layer kernel only: also write dZ transposed [4W][ldt] (null: no)
   float* db;                           // wide one-layer kernel only: += column sums of dZ (bias gradient; null: no)
+  float* db_l[KL_SCAN_MAXL];           // width-128 multi-layer launch only: the same per layer
   int sentinel;                        // wide one-layer kernel only: 1 = hand-off by data sentinels (dZ pre-filled with 0xFFFF halfwords)
   unsigned* xcc_slots; unsigned gen;   // as KlScanFwdWide (sentinel hand-off only)
   int pf_mode;                         // second generation: as KlScanFwdWide
@@ -239,6 +245,9 @@ int kl_launch_scan_bwd_wide2(KlScanBwd args, hipStream_t stream);
 int kl_launch_scan_bwd_regtile(KlScanBwd args, hipStream_t stream);
 int kl_launch_scan_bwd_w32(KlScanBwd args, hipStream_t stream);     // width 1024 (a.sentinel must be 1, a.L 1)
 int kl_launch_scan_bwd_w128(KlScanBwd args, hipStream_t stream);    // width 128 (a.L 1, a.dH f32)
+// ... all a.L layers in one launch (kl_scan_w128_multi_fits), a layer polling the dZ rows the one above publishes: the caller
+// pre-fills dZ[1 .. L - 1] with 0xFFFF halfwords; bias gradients to db_l
+int kl_launch_scan_bwd_w128_multi(KlScanBwd args, hipStream_t stream);
 int kl_scan_bwd_regtile_min_np();
 // output projection + softmax + CE + dlogits of a training window in one pass (V = 256, width 512); KL_ERR_SHAPE = not applicable
 int kl_launch_logits_ce_ws(const bf16_t* X, const bf16_t* E, const int* tgt, bf16_t* dlogits, float* rowstat, int B, int T, int W,
@@ -261,6 +270,16 @@ int kl_launch_embed_gather(const float* E, const float* const* ctx_tabs, int n_c
                            hipStream_t stream);
 int kl_launch_transpose_bf16(const bf16_t* in, long ld_in, bf16_t* out, long ld_out, int rows, int cols,
                              hipStream_t stream);
+// Several conversions in ONE launch (the operands a training step re-derives after every Adam update: ten small matrices
+// per two-layer model, each a launch of a few microseconds before).  rows_pad >= rows: source rows up to rows_pad count as
+// zeros and are written (the embedding's rows beyond the vocabulary).
+#define KL_CONV_MAX_JOBS 24
+struct KlConvJob {
+  const float* in; long ld_in; int rows, cols, rows_pad, transpose;
+  bf16_t* out_hi; bf16_t* out_lo; long ld_out;
+};
+struct KlConvJobs { KlConvJob job[KL_CONV_MAX_JOBS]; };
+int kl_launch_f32_to_bf16_jobs(const KlConvJob* jobs, int n, hipStream_t stream);
 int kl_launch_f32_to_bf16_t(const float* in, long ld_in, int rows, int cols, bf16_t* out_hi, bf16_t* out_lo,
                             long ld_out, int transpose, hipStream_t stream);
 int kl_launch_softmax_ce(float* logits, long ld, int rows, int V, const int* tgt, int B, int T, float inv_count,

@@ -50,13 +50,23 @@ __device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f
 // registers) and the 16 x 128 input rows X[t] (the layer below's -- masked -- outputs) staged like the state tile -- instead of
 // f32 gate-input rows P from a product over all steps: a step reads 4 KiB instead of 32, the P rows (2.1 GB written and read
 // per window at 4096 streams) and their GEMM disappear.
-template <bool KIN>
-__global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_kernel(const KlScanFwdWide a) {
+// POLL / PUB (the layers of a window in ONE launch, lstm_scan_fwd_w128_multi_kernel): PUB -- the rows the layer above reads (h,
+// or the masked h where it has a mask) leave as write-through stores, into an array the caller pre-filled with 0xFFFF halfwords;
+// POLL -- the input rows X[t] are taken with coherent loads a step ahead and asked for again until none of their halfwords is
+// that sentinel: a layer follows the one below it a step or more behind, on other CUs, nothing waits for a launch boundary.
+// NC >= 0 (layer 0, a.P == null): the gate inputs come straight from the look-up tables -- EK[idx[b, t]] + sum over NC context
+// variables of CtxK_n[ctx[b, t, n]] (f32 rows of 4W, L2-resident), the bias from the accumulators' start -- instead of f32 rows P
+// that a gather kernel wrote for every position first (537 MB written and read back per window at 1024 streams): a thread
+// serves ONE stream row (4 pieces of 16 bytes, 512 bytes apart), so that it holds one set of indices, fetched two steps ahead.
+template <bool KIN, bool POLL, bool PUB, int NC = -1>
+__device__ __forceinline__ void fwd_w128_body(const KlScanFwdWide& a, const int rb) {
+  constexpr bool GIN = NC >= 0;
+  constexpr int NCX = NC > 0 ? NC : 1;
   constexpr int W = W8;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int B = a.B, T = a.T;
-  const int row0 = blockIdx.x * 16;
+  const int row0 = rb * 16;
   const int nrow = min(16, B - row0);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int jr = lane & 3, a4 = (lane >> 2) & 3, q4 = lane >> 4;
@@ -74,14 +84,16 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_kernel(const KlScan
     }
   }
   u32x4 bk[KIN ? 4 : 1][4];
-  float bias_c[4] = {0.f, 0.f, 0.f, 0.f};      // (KIN: the bias of this lane's column in each tile -- the accumulators start from it)
-  if (KIN) {
+  float bias_c[4] = {0.f, 0.f, 0.f, 0.f};      // (KIN / GIN: the bias of this lane's column in each tile -- the accumulators start from it)
+  if (KIN || GIN) {
     const int col = lane & 15;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const long wrow = ((long)(col & 3) * W + 16 * wave + 4 * (col >> 2) + c) * W + (lane >> 4) * 8;
+      if (KIN) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bk[c][j] = *reinterpret_cast<const u32x4*>(a.KT + wrow + j * 32);
+        for (int j = 0; j < 4; ++j) bk[c][j] = *reinterpret_cast<const u32x4*>(a.KT + wrow + j * 32);
+      }
       bias_c[c] = a.bias[(col & 3) * W + 16 * wave + 4 * (col >> 2) + c];
     }
   }
@@ -109,13 +121,52 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_kernel(const KlScan
     return v;
   };
   auto p_put = [&](int buf, int k, float4 v) __attribute__((always_inline)) {
-    const int i = tid + NT8 * k, row = i >> 7, seg = i & 127;
+    const int i = tid + NT8 * k, row = GIN ? (tid >> 5) : (i >> 7), seg = GIN ? (tid & 31) + 32 * k : (i & 127);
     *reinterpret_cast<float4*>(smem + F_PB + (buf * 16 + row) * F_P_LD + seg * 16) = v;
   };
+  // GIN: this thread's stream row and its indices (rows beyond the batch: the last one's)
+  struct Ids { int id; int cx[NCX]; };
+  const long g_src = (long)(row0 + min(tid >> 5, nrow - 1)) * T;
+  auto ids_load = [&](int t) __attribute__((always_inline)) {
+    Ids v;
+    v.id = a.idx[g_src + t];
+#pragma unroll
+    for (int n = 0; n < NCX; ++n) v.cx[n] = NC > 0 ? a.ctx[(g_src + t) * NC + n] : 0;
+    return v;
+  };
+  auto g_load = [&](const Ids& ids, int k) __attribute__((always_inline)) {
+    const int seg = (tid & 31) + 32 * k;
+    float4 v = *reinterpret_cast<const float4*>(a.EK + (long)ids.id * 4 * W + seg * 4);
+#pragma unroll
+    for (int n = 0; n < NCX; ++n) {
+      if (n < NC) {
+        const float4 q = *reinterpret_cast<const float4*>(a.CtxK[n] + (long)ids.cx[n] * 4 * W + seg * 4);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+    }
+    return v;
+  };
   // (KIN: the input rows X[t] -- 16 x 256 bytes, threads 0 .. 255 -- take the place of the gate-input rows; tile [2][16][272] at F_PB)
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(KIN ? a.X : nullptr, KIN ? (long)T * B * W * 2 : 0);
   auto x_load = [&](int t) __attribute__((always_inline)) {
     uint4 v = uint4{0u, 0u, 0u, 0u};
-    if (tid < 256 && h_row < nrow) v = *reinterpret_cast<const uint4*>(a.X + ((long)t * B + row0 + h_row) * W + h_seg * 8);
+    if (tid < 256 && h_row < nrow) {
+      if (POLL) v = load16_sc1(rs_x, (unsigned)((((long)t * B + row0 + h_row) * W + h_seg * 8) * 2));
+      else v = *reinterpret_cast<const uint4*>(a.X + ((long)t * B + row0 + h_row) * W + h_seg * 8);
+    }
+    return v;
+  };
+  // POLL: the rows of step t as they are now, asked for again until the layer below has published all of them (bounded)
+  auto x_await = [&](int t, uint4 v) __attribute__((always_inline)) {
+    if (!POLL || tid >= 256) return v;
+    for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
+      const bool ok = h_row >= nrow || sentinel_free(sentinel_bits(v));
+      if (__all(ok)) return v;
+      if ((spin & 63) == 63 && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+      __builtin_amdgcn_s_sleep(2);
+      v = x_load(t);
+    }
+    __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return v;
   };
   auto x_put = [&](int buf, uint4 v) __attribute__((always_inline)) {
@@ -127,8 +178,14 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_kernel(const KlScan
     if (h_row < nrow) v = *reinterpret_cast<const uint4*>(a.H + ((long)row0 + h_row) * W + h_seg * 8);
     *reinterpret_cast<uint4*>(smem + F_HT + h_row * F_H_LD + h_seg * 16) = v;
   }
+  Ids ids_nx;      // GIN: the indices of the step after the one whose rows are on their way
   if (KIN) {
-    x_put(0, x_load(0));
+    x_put(0, x_await(0, x_load(0)));
+  } else if (GIN) {
+    const Ids i0 = ids_load(0);
+    ids_nx = ids_load(min(1, T - 1));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p_put(0, k, g_load(i0, k));
   } else {
 #pragma unroll
     for (int k = 0; k < 4; ++k) p_put(0, k, p_load(0, k));
@@ -144,6 +201,10 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_kernel(const KlScan
     if (t + 1 < T) {
       if (KIN) {
         xn = x_load(t + 1);
+      } else if (GIN) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pn[k] = g_load(ids_nx, k);
+        ids_nx = ids_load(min(t + 2, T - 1));
       } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) pn[k] = p_load(t + 1, k);
@@ -203,7 +264,7 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_kernel(const KlScan
     }
     if (t + 1 < T) {
       if (KIN) {
-        x_put(p ^ 1, xn);
+        x_put(p ^ 1, x_await(t + 1, xn));
       } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) p_put(p ^ 1, k, pn[k]);
@@ -223,11 +284,43 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_kernel(const KlScan
     if (c_row < nrow)
       *reinterpret_cast<float4*>(a.C + (trow + B + c_row) * W + c_seg * 4) = *reinterpret_cast<const float4*>(smem + F_CS + (p * 16 + c_row) * F_C_LD + c_seg * 16);
     if (h_row < nrow) {
-      if (tid < 256)
-        *reinterpret_cast<uint4*>(a.H + (trow + B + h_row) * W + h_seg * 8) = *reinterpret_cast<const uint4*>(smem + F_HT + ((p ^ 1) * 16 + h_row) * F_H_LD + h_seg * 16);
-      else if (a.Hd)
-        *reinterpret_cast<uint4*>(a.Hd + (trow + h_row) * W + h_seg * 8) = *reinterpret_cast<const uint4*>(smem + F_HS + (p * 16 + h_row) * F_H_LD + h_seg * 16);
+      if (tid < 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + F_HT + ((p ^ 1) * 16 + h_row) * F_H_LD + h_seg * 16);
+        if (PUB) store16_sc1(make_rsrc(a.H, (long)(T + 1) * B * W * 2), (unsigned)(((trow + B + h_row) * W + h_seg * 8) * 2), v);
+        else *reinterpret_cast<uint4*>(a.H + (trow + B + h_row) * W + h_seg * 8) = v;
+      } else if (a.Hd) {
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + F_HS + (p * 16 + h_row) * F_H_LD + h_seg * 16);
+        if (PUB) store16_sc1(make_rsrc(a.Hd, (long)T * B * W * 2), (unsigned)(((trow + h_row) * W + h_seg * 8) * 2), v);
+        else *reinterpret_cast<uint4*>(a.Hd + (trow + h_row) * W + h_seg * 8) = v;
+      }
     }
+  }
+}
+
+// MODE 0: gate inputs from f32 rows P; 1: KIN; 2 + n: from the look-up tables with n context variables
+template <int MODE>
+__global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_kernel(const KlScanFwdWide a) {
+  fwd_w128_body<MODE == 1, false, false, MODE >= 2 ? MODE - 2 : -1>(a, blockIdx.x);
+}
+
+// all layers of a window in one launch: workgroup = (layer = blockIdx / n_rb, row block = blockIdx % n_rb) -- the lowest layer's
+// workgroups first, every workgroup resident at once (the launcher checks layers x row blocks <= CUs)
+__global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_multi_kernel(const KlScanFwdWide a0, const KlScanFwdWide a1, const KlScanFwdWide a2,
+                                                                          const KlScanFwdWide a3, const int L, const int n_rb) {
+  const int layer = blockIdx.x / n_rb, rb = blockIdx.x - layer * n_rb;
+  if (layer == 0) {      // (L >= 2: always publishing)
+    if (a0.P) fwd_w128_body<false, false, true>(a0, rb);
+    else if (a0.n_ctx == 0) fwd_w128_body<false, false, true, 0>(a0, rb);
+    else if (a0.n_ctx == 1) fwd_w128_body<false, false, true, 1>(a0, rb);
+    else fwd_w128_body<false, false, true, 2>(a0, rb);
+  } else if (layer == 1) {
+    if (L > 2) fwd_w128_body<true, true, true>(a1, rb);
+    else fwd_w128_body<true, true, false>(a1, rb);
+  } else if (layer == 2) {
+    if (L > 3) fwd_w128_body<true, true, true>(a2, rb);
+    else fwd_w128_body<true, true, false>(a2, rb);
+  } else {
+    fwd_w128_body<true, true, false>(a3, rb);
   }
 }
 
@@ -236,13 +329,18 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_fwd_w128_kernel(const KlScan
 // XIN: the gradient from above is contracted HERE -- dh[t] = mask * (dZ_above[t] . K_above^T) + dZ[t+1] . U^T with K_above
 // resident beside U and the 16 x 512 rows of the layer above's dZ[t] staged like this layer's own tile -- instead of f32 dH rows
 // from a product over all steps (a.Kn[1] / a.dZ[1] = the layer above's input kernel [W][4W] and dZ [T*B][4W]).
-template <bool XIN>
-__global__ __launch_bounds__(NT8, 1) void lstm_scan_bwd_w128_kernel(const KlScanBwd a) {
+// LY: the layer's slot in the argument arrays (the one-layer launches: 0; a.Kn / a.dZ [LY + 1] = the layer above).
+// POLL / PUB (all layers of a window in ONE launch, lstm_scan_bwd_w128_multi_kernel): PUB -- the dZ rows leave as write-through
+// stores into an array the caller pre-filled with 0xFFFF halfwords; POLL -- the layer above's dZ rows are taken with coherent
+// loads a step ahead and asked for again until none of their halfwords is that sentinel.
+template <bool XIN, bool POLL, bool PUB, int LY>
+__device__ __forceinline__ void bwd_w128_body(const KlScanBwd& a, const int rb, float* const db) {
   constexpr int W = W8;
+  constexpr int LA = LY + 1 < KL_SCAN_MAXL ? LY + 1 : LY;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int B = a.B, T = a.T;
-  const int row0 = blockIdx.x * 16;
+  const int row0 = rb * 16;
   const int nrow = min(16, B - row0);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int col = lane & 15, q4 = lane >> 4;
@@ -251,24 +349,47 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_bwd_w128_kernel(const KlScan
   // resident weights: B fragments of this wave's 16 output units, K = 4W = 512 (U natural layout [W][4W]: row = unit)
   u32x4 bu[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) bu[j] = *reinterpret_cast<const u32x4*>(a.Un[0] + (long)u * 4 * W + j * 32 + q4 * 8);
+  for (int j = 0; j < 16; ++j) bu[j] = *reinterpret_cast<const u32x4*>(a.Un[LY] + (long)u * 4 * W + j * 32 + q4 * 8);
   u32x4 bk[XIN ? 16 : 1];
   if (XIN) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) bk[j] = *reinterpret_cast<const u32x4*>(a.Kn[1] + (long)u * 4 * W + j * 32 + q4 * 8);
+    for (int j = 0; j < 16; ++j) bk[j] = *reinterpret_cast<const u32x4*>(a.Kn[LA] + (long)u * 4 * W + j * 32 + q4 * 8);
   }
   float ccur[4], dc[4], mk[4], dbacc[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = min(4 * q4 + r, nrow - 1);
-    ccur[r] = a.C[0][((long)T * B + row0 + row) * W + u];       // c_{T-1} = block T
-    mk[r] = a.mask[0] ? a.mask[0][((long)row0 + row) * W + u] : 1.f;
+    ccur[r] = a.C[LY][((long)T * B + row0 + row) * W + u];       // c_{T-1} = block T
+    mk[r] = a.mask[LY] ? a.mask[LY][((long)row0 + row) * W + u] : 1.f;
     dc[r] = 0.f;
     dbacc[r] = 0.f;
   }
   // rows between memory and LDS: gates (2 pieces of 16 bytes per thread and step), c_{t-1} (1), dH (1), dZ out (2)
   const int c_row = tid >> 5, c_seg = tid & 31;
   struct In { uint4 g[2]; float4 c, d; uint4 za[2]; };
+  const __amdgpu_buffer_rsrc_t rs_za = make_rsrc(XIN ? a.dZ[LA] : nullptr, XIN ? (long)T * B * 4 * W * 2 : 0);
+  auto za_load = [&](int t, int k) __attribute__((always_inline)) {
+    const int i = tid + NT8 * k, row = i >> 6, seg = i & 63;
+    uint4 v = uint4{0u, 0u, 0u, 0u};
+    if (row < nrow) {
+      if (POLL) v = load16_sc1(rs_za, (unsigned)((((long)t * B + row0 + row) * 4 * W + seg * 8) * 2));
+      else v = *reinterpret_cast<const uint4*>(a.dZ[LA] + ((long)t * B + row0 + row) * 4 * W + seg * 8);
+    }
+    return v;
+  };
+  // POLL: the layer above's rows of step t as they are now, asked for again until all of them have been published (bounded)
+  auto za_await = [&](int t, In& v) __attribute__((always_inline)) {
+    if (!POLL) return;
+    for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
+      const bool ok = sentinel_free(sentinel_bits(v.za[0]) | sentinel_bits(v.za[1]));      // (rows beyond the batch: zeros)
+      if (__all(ok)) return;
+      if ((spin & 63) == 63 && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+      __builtin_amdgcn_s_sleep(2);
+      v.za[0] = za_load(t, 0);
+      v.za[1] = za_load(t, 1);
+    }
+    __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   auto in_load = [&](int t) __attribute__((always_inline)) {
     In v;
     const long trow = (long)t * B + row0;
@@ -276,16 +397,15 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_bwd_w128_kernel(const KlScan
     for (int k = 0; k < 2; ++k) {
       const int i = tid + NT8 * k, row = i >> 6, seg = i & 63;
       v.g[k] = uint4{0u, 0u, 0u, 0u};
-      v.za[k] = uint4{0u, 0u, 0u, 0u};
+      v.za[k] = XIN ? za_load(t, k) : uint4{0u, 0u, 0u, 0u};
       if (row < nrow) {
-        v.g[k] = *reinterpret_cast<const uint4*>(a.G[0] + (trow + row) * 4 * W + seg * 8);
-        if (XIN) v.za[k] = *reinterpret_cast<const uint4*>(a.dZ[1] + (trow + row) * 4 * W + seg * 8);
+        v.g[k] = *reinterpret_cast<const uint4*>(a.G[LY] + (trow + row) * 4 * W + seg * 8);
       }
     }
     v.c = float4{0.f, 0.f, 0.f, 0.f};
     v.d = float4{0.f, 0.f, 0.f, 0.f};
     if (c_row < nrow) {
-      v.c = *reinterpret_cast<const float4*>(a.C[0] + (trow + c_row) * W + c_seg * 4);      // block t = c_{t-1}
+      v.c = *reinterpret_cast<const float4*>(a.C[LY] + (trow + c_row) * W + c_seg * 4);      // block t = c_{t-1}
       if (!XIN) v.d = *reinterpret_cast<const float4*>(a.dH + (trow + c_row) * W + c_seg * 4);
     }
     return v;
@@ -301,7 +421,11 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_bwd_w128_kernel(const KlScan
     *reinterpret_cast<float4*>(smem + B_CB + (buf * 16 + c_row) * 512 + c_seg * 16) = v.c;
     if (!XIN) *reinterpret_cast<float4*>(smem + B_DH + (buf * 16 + c_row) * 512 + c_seg * 16) = v.d;
   };
-  in_put((T - 1) & 1, in_load(T - 1));
+  {
+    In first = in_load(T - 1);
+    za_await(T - 1, first);
+    in_put((T - 1) & 1, first);
+  }
   __syncthreads();
 
   for (int t = T - 1; t >= 0; --t) {
@@ -347,46 +471,146 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_bwd_w128_kernel(const KlScan
       *reinterpret_cast<bf16_t*>(zt + 768) = bo;
       dbacc[0] += bf2f(bi); dbacc[1] += bf2f(bff); dbacc[2] += bf2f(bg); dbacc[3] += bf2f(bo);      // (what the weight gradients see: the rounded values)
     }
-    if (t > 0) in_put(p ^ 1, nxt);
+    if (t > 0) {
+      za_await(t - 1, nxt);
+      in_put(p ^ 1, nxt);
+    }
     __syncthreads();
     // ---- dZ[t] to memory, whole rows
     const long trow = (long)t * B + row0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int i = tid + NT8 * k, row = i >> 6, seg = i & 63;
-      if (row < nrow)
-        *reinterpret_cast<uint4*>(a.dZ[0] + (trow + row) * 4 * W + seg * 8) = *reinterpret_cast<const uint4*>(smem + B_ZT + (p * 16 + row) * B_Z_LD + seg * 16);
+      if (row < nrow) {
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + B_ZT + (p * 16 + row) * B_Z_LD + seg * 16);
+        if (PUB) store16_sc1(make_rsrc(a.dZ[LY], (long)T * B * 4 * W * 2), (unsigned)(((trow + row) * 4 * W + seg * 8) * 2), v);
+        else *reinterpret_cast<uint4*>(a.dZ[LY] + (trow + row) * 4 * W + seg * 8) = v;
+      }
     }
   }
   // bias gradient: column sums of what was written (the four row groups of a wave, then one atomic per column and workgroup)
-  if (a.db) {
+  if (db) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float v = dbacc[g];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
-      if (q4 == 0) atomicAdd(a.db + g * W + u, v);
+      if (q4 == 0) atomicAdd(db + g * W + u, v);
     }
+  }
+}
+
+template <bool XIN>
+__global__ __launch_bounds__(NT8, 1) void lstm_scan_bwd_w128_kernel(const KlScanBwd a) {
+  bwd_w128_body<XIN, false, false, 0>(a, blockIdx.x, a.db);
+}
+
+// all layers of a window in one launch: workgroup = (layer = L - 1 - blockIdx / n_rb, row block = blockIdx % n_rb) -- the top
+// layer's workgroups first, every workgroup resident at once (the launcher checks layers x row blocks <= CUs)
+__global__ __launch_bounds__(NT8, 1) void lstm_scan_bwd_w128_multi_kernel(const KlScanBwd a) {
+  const int L = a.L, n_rb = a.n_rb;
+  const int layer = L - 1 - blockIdx.x / n_rb, rb = blockIdx.x % n_rb;
+  if (layer == L - 1) {       // (takes the softmax side's dH rows, all steps there before the launch)
+    if (layer == 1) bwd_w128_body<false, false, true, 1>(a, rb, a.db_l[1]);
+    else if (layer == 2) bwd_w128_body<false, false, true, 2>(a, rb, a.db_l[2]);
+    else bwd_w128_body<false, false, true, 3>(a, rb, a.db_l[3]);
+  } else if (layer == 0) {
+    bwd_w128_body<true, true, false, 0>(a, rb, a.db_l[0]);
+  } else if (layer == 1) {
+    bwd_w128_body<true, true, true, 1>(a, rb, a.db_l[1]);
+  } else {
+    bwd_w128_body<true, true, true, 2>(a, rb, a.db_l[2]);
   }
 }
 
 }  // namespace
 
+namespace {
+int w128_cus() {
+  static int v = 0;
+  if (!v) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    v = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 1;
+  }
+  return v;
+}
+}  // namespace
+
+// the gate inputs of layer 0 straight from the look-up tables: up to two context variables (kl_scan_w128_tables_max_ctx)
+namespace {
+bool w128_tables_ok(const KlScanFwdWide& a) {
+  if (!a.EK || !a.idx || !a.bias || a.n_ctx < 0 || a.n_ctx > 2 || (a.n_ctx > 0 && !a.ctx)) return false;
+  for (int n = 0; n < a.n_ctx; ++n)
+    if (!a.CtxK[n]) return false;
+  return true;
+}
+}  // namespace
+int kl_scan_w128_tables_max_ctx() { return 2; }
+
 bool kl_scan_w128_applicable(int B, int T, int W) {
   return W == W8 && B >= 1 && T >= 1 && (long)(T + 1) * B * 4 * W * 4 < 0x7fffffffffffL;
 }
 
-// KL_ERR_SHAPE = not applicable.  Gate inputs: f32 rows P [T*B][4W] (gate-major, bias included), or -- a.KT != null -- the input
+// KL_ERR_SHAPE = not applicable.  Gate inputs: f32 rows P [T*B][4W] (gate-major, bias included); or -- a.P == null, layer 0 -- the
+// look-up tables a.EK / a.CtxK[0 .. n_ctx) (f32 rows of 4W) with a.idx [B][T] / a.ctx [B][T][n_ctx] and a.bias; or -- a.KT != null -- the input
 // rows a.X [T*B][W] bf16 with the input kernel a.KT [4W][W] and a.bias [4W] (the contraction then happens inside the scan).
 int kl_launch_scan_fwd_w128(KlScanFwdWide a, hipStream_t stream) {
   if (!kl_scan_w128_applicable(a.B, a.T, a.W) || a.p_bf16 || a.HT || a.HdT || !a.H || !a.C || !a.UT) return KL_ERR_SHAPE;
   const bool kin = a.KT != nullptr;
-  if (kin ? (!a.X || !a.bias) : !a.P) return KL_ERR_SHAPE;
-  static KlLdsGrant grant[2];
-  const void* fn = kin ? reinterpret_cast<const void*>(&lstm_scan_fwd_w128_kernel<true>) : reinterpret_cast<const void*>(&lstm_scan_fwd_w128_kernel<false>);
-  if (kl_grant_lds(grant[kin], fn, (size_t)F_LDS)) return KL_ERR_LAUNCH;
-  if (kin) hipLaunchKernelGGL(lstm_scan_fwd_w128_kernel<true>, dim3((a.B + 15) / 16), dim3(NT8), (size_t)F_LDS, stream, a);
-  else hipLaunchKernelGGL(lstm_scan_fwd_w128_kernel<false>, dim3((a.B + 15) / 16), dim3(NT8), (size_t)F_LDS, stream, a);
+  const int mode = kin ? 1 : (a.P ? 0 : 2 + a.n_ctx);
+  if (kin ? (!a.X || !a.bias) : (!a.P && !w128_tables_ok(a))) return KL_ERR_SHAPE;
+  static KlLdsGrant grant[5];
+  const void* fn = mode == 0   ? reinterpret_cast<const void*>(&lstm_scan_fwd_w128_kernel<0>)
+                   : mode == 1 ? reinterpret_cast<const void*>(&lstm_scan_fwd_w128_kernel<1>)
+                   : mode == 2 ? reinterpret_cast<const void*>(&lstm_scan_fwd_w128_kernel<2>)
+                   : mode == 3 ? reinterpret_cast<const void*>(&lstm_scan_fwd_w128_kernel<3>)
+                               : reinterpret_cast<const void*>(&lstm_scan_fwd_w128_kernel<4>);
+  if (kl_grant_lds(grant[mode], fn, (size_t)F_LDS)) return KL_ERR_LAUNCH;
+  const dim3 grid((a.B + 15) / 16), block(NT8);
+  switch (mode) {
+    case 0: hipLaunchKernelGGL(lstm_scan_fwd_w128_kernel<0>, grid, block, (size_t)F_LDS, stream, a); break;
+    case 1: hipLaunchKernelGGL(lstm_scan_fwd_w128_kernel<1>, grid, block, (size_t)F_LDS, stream, a); break;
+    case 2: hipLaunchKernelGGL(lstm_scan_fwd_w128_kernel<2>, grid, block, (size_t)F_LDS, stream, a); break;
+    case 3: hipLaunchKernelGGL(lstm_scan_fwd_w128_kernel<3>, grid, block, (size_t)F_LDS, stream, a); break;
+    default: hipLaunchKernelGGL(lstm_scan_fwd_w128_kernel<4>, grid, block, (size_t)F_LDS, stream, a); break;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+bool kl_scan_w128_multi_fits(int B, int L) { return L >= 2 && L <= 4 && B >= 1 && (long)L * ((B + 15) / 16) <= w128_cus(); }
+
+// Backward, all layers in one launch: a.L layers in the slots 0 .. L - 1 (Un, Kn, G, C, dZ, mask, db_l), a.dH = the gradient from
+// the softmax side (f32, for the top layer); the CALLER pre-fills dZ[1 .. L - 1] with 0xFFFF halfwords.  KL_ERR_SHAPE = not applicable.
+int kl_launch_scan_bwd_w128_multi(KlScanBwd a, hipStream_t stream) {
+  if (!kl_scan_w128_applicable(a.B, a.T, a.W) || !kl_scan_w128_multi_fits(a.B, a.L) || a.dZT || !a.dH || !a.status) return KL_ERR_SHAPE;
+  for (int l = 0; l < a.L; ++l)
+    if (!a.Un[l] || !a.G[l] || !a.C[l] || !a.dZ[l] || (l > 0 && !a.Kn[l])) return KL_ERR_SHAPE;
+  a.n_rb = (a.B + 15) / 16;
+  static KlLdsGrant grant;
+  if (kl_grant_lds(grant, reinterpret_cast<const void*>(&lstm_scan_bwd_w128_multi_kernel), (size_t)B_LDS_XIN)) return KL_ERR_LAUNCH;
+  hipLaunchKernelGGL(lstm_scan_bwd_w128_multi_kernel, dim3(a.L * a.n_rb), dim3(NT8), (size_t)B_LDS_XIN, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+// The layers of a window in one launch (layers[0]: gate inputs P; layers[l > 0]: KT / X / bias with X = the rows layer l - 1
+// publishes -- the CALLER pre-fills those rows with 0xFFFF halfwords).  Only where every workgroup finds a CU at once
+// (layers x row blocks <= CUs): the point is to use CUs a single layer leaves idle.  KL_ERR_SHAPE = not applicable.
+int kl_launch_scan_fwd_w128_multi(const KlScanFwdWide* layers, int L, hipStream_t stream) {
+  if (!kl_scan_w128_multi_fits(layers[0].B, L)) return KL_ERR_SHAPE;
+  const int n_rb = (layers[0].B + 15) / 16;
+  for (int l = 0; l < L; ++l) {
+    const KlScanFwdWide& a = layers[l];
+    if (!kl_scan_w128_applicable(a.B, a.T, a.W) || a.B != layers[0].B || a.T != layers[0].T || a.p_bf16 || a.HT || a.HdT || !a.H || !a.C || !a.UT || !a.status)
+      return KL_ERR_SHAPE;
+    if (l == 0 ? (a.KT || (!a.P && !w128_tables_ok(a))) : (!a.KT || !a.X || !a.bias)) return KL_ERR_SHAPE;
+    if (l > 0 && a.X != (layers[l - 1].Hd ? layers[l - 1].Hd : layers[l - 1].H + (size_t)a.B * a.W)) return KL_ERR_SHAPE;
+  }
+  static KlLdsGrant grant;
+  if (kl_grant_lds(grant, reinterpret_cast<const void*>(&lstm_scan_fwd_w128_multi_kernel), (size_t)F_LDS)) return KL_ERR_LAUNCH;
+  const KlScanFwdWide& z = layers[L - 1];
+  hipLaunchKernelGGL(lstm_scan_fwd_w128_multi_kernel, dim3(L * n_rb), dim3(NT8), (size_t)F_LDS, stream, layers[0], layers[1], L > 2 ? layers[2] : z,
+                     L > 3 ? layers[3] : z, L, n_rb);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 

@@ -632,22 +632,30 @@ def test_train_window_width_1024_scans(monkeypatch, depth, width, voc, B, T, n_c
     check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks, want_kernel="lstm_scan_bwd_w32_kernel")
 
 
-@pytest.mark.parametrize("depth,width,voc,B,T,n_ctx,use_masks,env", [
-    (2, 128, 70, 40, 12, 1, True, {"KL_W128_MIN": "1"}),        # three row blocks, the last one half full; layer 1's input side inside the scan
-    (3, 128, 30, 20, 6, 2, True, {"KL_W128_MIN": "1"}),         # three layers, two context variables
-    (1, 128, 40, 24, 7, 1, False, {"KL_W128_MIN": "1"}),        # one layer, no dropout
-    (2, 100, 50, 24, 9, 1, True, {"KL_W128_MIN": "1"}),         # width 100 zero-padded to 128
-    (2, 128, 50, 600, 5, 1, True, {}),                          # the default path from 512 streams
-    (2, 128, 70, 40, 12, 1, True, {"KL_W128_MIN": "1", "KL_W128_FUSE": "0"}),      # input side / gradient from above by products over all steps
-    (4, 128, 30, 33, 5, 1, True, {"KL_W128_MIN": "1"})])        # four layers
-def test_train_window_width_128_scans(monkeypatch, depth, width, voc, B, T, n_ctx, use_masks, env):
+@pytest.mark.parametrize("depth,width,voc,B,T,n_ctx,use_masks,env,want", [
+    (2, 128, 70, 40, 12, 1, True, {"KL_W128_MIN": "1"}, "multi"),      # three row blocks, the last one half full; both layers in one launch
+    (3, 128, 30, 20, 6, 2, True, {"KL_W128_MIN": "1"}, "multi"),       # three layers, two context variables
+    (1, 128, 40, 24, 7, 1, False, {"KL_W128_MIN": "1"}, "single"),     # one layer, no dropout
+    (2, 100, 50, 24, 9, 1, True, {"KL_W128_MIN": "1"}, "multi"),       # width 100 zero-padded to 128
+    (2, 128, 50, 600, 5, 1, True, {}, "multi"),                        # the default path from 512 streams
+    (2, 128, 70, 40, 12, 1, True, {"KL_W128_MIN": "1", "KL_W128_FUSE": "0"}, "single"),     # input side / gradient from above by products over all steps
+    (4, 128, 30, 33, 5, 1, True, {"KL_W128_MIN": "1"}, "multi"),       # four layers, each polling the rows of its neighbour
+    (2, 128, 70, 40, 12, 1, True, {"KL_W128_MIN": "1", "KL_W128_MULTI": "0"}, "single"),    # one launch per layer, contractions inside the scans
+    (2, 128, 50, 1024, 24, 1, True, {}, "multi"),                      # 2 x 64 workgroups in one launch
+    (2, 128, 50, 2064, 3, 1, True, {}, "single"),                      # 2 x 129 row blocks do not fit 256 CUs: one launch per layer
+    (2, 128, 40, 40, 6, 0, True, {"KL_W128_MIN": "1"}, "multi"),       # no context variable: layer 0 from the embedding table alone
+    (2, 128, 40, 24, 5, 3, True, {"KL_W128_MIN": "1"}, "multi"),       # three context variables: layer 0's gate inputs gathered into rows first
+    (1, 128, 40, 24, 7, 1, False, {"KL_W128_MIN": "1", "KL_W128_TABLES": "0"}, "single")])   # ... also with one
+def test_train_window_width_128_scans(monkeypatch, depth, width, voc, B, T, n_ctx, use_masks, env, want):
     """Width 128 (the reference's published model size): the scans of lstm_scan_w128.hip -- a workgroup per 16-row block of
-    streams with all hidden units of a layer, no hand-off between workgroups; the layers above the first contract their
-    inputs (forward) and the gradient from above (backward) inside the scan: gradients, loss and carried state against
-    the f64 oracle."""
+    streams with all hidden units of a layer, no hand-off of state between workgroups; the layers above the first contract
+    their inputs (forward) and the gradient from above (backward) inside the scan, and where all layers' workgroups fit the
+    CUs at once they run in ONE launch, a layer polling the rows its neighbour publishes: gradients, loss and carried state
+    against the f64 oracle."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks, want_kernel="lstm_scan_bwd_w128_kernel")
+    check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks,
+                                 want_kernel="lstm_scan_bwd_w128_multi_kernel" if want == "multi" else "lstm_scan_bwd_w128_kernel")
 
 
 @pytest.mark.parametrize("B,T", [(144, 4), (512, 3)])
@@ -656,6 +664,13 @@ def test_width_1024_scans_consecutive_windows(monkeypatch, B, T):
     forced on from one row block: uneven visits with prefetched tiles / four row blocks per workgroup"""
     monkeypatch.setenv("KL_W32_MIN_RB", "1")
     test_train_consecutive_windows_reuse_buffers(2, 1024, 40, B, T)
+
+
+def test_width_128_scans_consecutive_windows(monkeypatch):
+    """the width-128 scans, all layers in one launch, over consecutive windows: the rows a layer polls are sentinels again
+    before every window (carried state, replayed graph)"""
+    monkeypatch.setenv("KL_W128_MIN", "1")
+    test_train_consecutive_windows_reuse_buffers(3, 128, 40, 72, 6)
 
 
 def test_flag_handoff_survives_changing_shapes():
