@@ -663,7 +663,11 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       // follows the one below it a step behind, polling the rows that one publishes -- which therefore start out as sentinels.
       bool multi = kl_scan_w128_multi_fits(B, L);
       if (multi) {
-        for (int l = 1; l < L; ++l) KL_TRY(kl_fill_u32_async(const_cast<bf16_t*>(layer_args[l].X), (size_t)T * BW * sizeof(bf16_t), 0xFFFFFFFFu, s));
+        const bool roll = h->sentinel_roll && T >= 3;      // (rolling sentinels: only the first two steps start out armed)
+        for (int l = 1; l < L; ++l) {
+          layer_args[l - 1].sentinel = roll ? 2 : 1;
+          KL_TRY(kl_fill_u32_async(const_cast<bf16_t*>(layer_args[l].X), (size_t)(roll ? 2 : T) * BW * sizeof(bf16_t), 0xFFFFFFFFu, s));
+        }
         h->trace_begin(0, s);
         const int e = kl_launch_scan_fwd_w128_multi(layer_args, L, s);
         if (e == KL_ERR_SHAPE) multi = false;
@@ -1230,6 +1234,12 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   int fe = KL_ERR_SHAPE;
   if (h->logits_ws && loss_acc != nullptr && w.rowstat != nullptr && V == Vp)
     fe = kl_launch_logits_ce_ws(Htop, d.E_hi, tgt, w.dlogits, w.rowstat, B, T, W, V, Vp, inv_count, h->last_only, s);
+  // (width 128: ... and dH = dlogits . E in the same pass -- lstm_scan_w128.hip; the scans there take dH as f32 rows)
+  bool dh_done = false;
+  if (fe == KL_ERR_SHAPE && h->logits_ws && W == 128 && loss_acc != nullptr && w.rowstat != nullptr && !w.scan2_bwd) {
+    fe = kl_launch_logits_ce_w128(Htop, d.E_hi, d.ET, tgt, w.dlogits, w.dH, w.rowstat, B, T, W, V, Vp, inv_count, h->last_only, s);
+    dh_done = fe == 0;
+  }
   if (fe == 0) {
     KL_TRY(kl_launch_rowstat_reduce(w.rowstat, BT, loss_acc, s));
   } else if (fe == KL_ERR_SHAPE) {
@@ -1243,6 +1253,7 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
   const int dh_mode = w.scan2_bwd ? 1 : 0;
   int de = KL_ERR_SHAPE;
   if (dh_mode == 1 && h->logits_ws) de = kl_launch_dh_ws(w.dlogits, d.ET, reinterpret_cast<bf16_t*>(w.dH), BT, W, Vp, s);
+  if (dh_done) de = 0;
   if (de == KL_ERR_SHAPE) de = kl_launch_gemm_tn(w.dlogits, d.ET, w.dH, nullptr, BT, W, Vp, Vp, Vp, W, dh_mode, 1, 1.f, s);
   KL_TRY(de);
   if (BTp != BT) {
@@ -1396,7 +1407,10 @@ static int train_window_body(kl_handle* h, int B, int T, const int32_t* idx, con
     }
     a.dH = w.dH;
     a.status = w.scan_status + 1;
-    for (int l = 1; l < L; ++l) KL_TRY(kl_fill_u32_async(w.dZ[l], (size_t)T * BW * 4 * sizeof(bf16_t), 0xFFFFFFFFu, s));
+    const bool roll = h->sentinel_roll && T >= 3;      // (rolling sentinels: only the last two steps start out armed)
+    a.sentinel = roll ? 2 : 1;
+    for (int l = 1; l < L; ++l)
+      KL_TRY(kl_fill_u32_async(w.dZ[l] + (roll ? (size_t)(T - 2) * BW * 4 : 0), (size_t)(roll ? 2 : T) * BW * 4 * sizeof(bf16_t), 0xFFFFFFFFu, s));
     h->trace_begin(1, s);
     const int e = kl_launch_scan_bwd_w128_multi(a, s);
     if (e != KL_ERR_SHAPE) {

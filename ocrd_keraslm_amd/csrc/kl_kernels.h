@@ -254,6 +254,9 @@ int kl_launch_logits_ce_ws(const bf16_t* X, const bf16_t* E, const int* tgt, bf1
                            int V, long ld_dl, float inv_count, int last_only, hipStream_t stream);
 // dH = dlogits . E (bf16) of a training window, weight-stationary (V padded to 256, width 512); KL_ERR_SHAPE = not applicable
 int kl_launch_dh_ws(const bf16_t* dlogits, const bf16_t* ET, bf16_t* dH, long M, int W, int Vp, hipStream_t stream);
+// ... at width 128 (V <= Vp <= 256): also dH = dlogits . E as f32 rows, in the same pass (lstm_scan_w128.hip)
+int kl_launch_logits_ce_w128(const bf16_t* X, const bf16_t* E, const bf16_t* ET, const int* tgt, bf16_t* dlogits, float* dH, float* rowstat, int B,
+                             int T, int W, int V, int Vp, float inv_count, int last_only, hipStream_t stream);
 int kl_launch_rowstat_reduce(const float* rowstat, int rows, float* loss_acc, hipStream_t stream);
 // weight-stationary P = X . KTp^T + bp for width 512 (lstm_scan2.hip: proj_ws_kernel); KL_ERR_SHAPE = not applicable
 int kl_launch_proj_ws(const bf16_t* X, const bf16_t* KTp, const float* bp, bf16_t* P, long M, int W, unsigned* status,

@@ -133,3 +133,40 @@ __device__ __forceinline__ void glds4_sc1_s(__amdgpu_buffer_rsrc_t rsrc, unsigne
       : "memory");
 }
 
+// wave-wide reductions by DPP (no LDS crossbar: `__shfl_xor` is a ds_bpermute of ~100 cycles each, eighteen of them in a
+// dependent chain per softmax row).  Every step combines with a lane pattern inside the 16-lane rows, the last two carry the
+// row results across (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3); the result is lane 63's, broadcast
+// through a scalar.  Lanes a step does not write see the operation's identity.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float identity, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  const float ninf = -INFINITY;
+  v = fmaxf(v, dpp_f<0xB1, 0xF>(ninf, v));
+  v = fmaxf(v, dpp_f<0x4E, 0xF>(ninf, v));
+  v = fmaxf(v, dpp_f<0x141, 0xF>(ninf, v));
+  v = fmaxf(v, dpp_f<0x140, 0xF>(ninf, v));
+  v = fmaxf(v, dpp_f<0x142, 0xA>(ninf, v));
+  v = fmaxf(v, dpp_f<0x143, 0xC>(ninf, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_f<0xB1, 0xF>(0.f, v);
+  v += dpp_f<0x4E, 0xF>(0.f, v);
+  v += dpp_f<0x141, 0xF>(0.f, v);
+  v += dpp_f<0x140, 0xF>(0.f, v);
+  v += dpp_f<0x142, 0xA>(0.f, v);
+  v += dpp_f<0x143, 0xC>(0.f, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int wave_min_i(int v) {      // (non-negative values: compared as floats' bit patterns would be, done on ints)
+  const int big = 0x7fffffff;
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0xB1, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x4E, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x141, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x140, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x142, 0xA, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x143, 0xC, 0xF, false));
+  return __builtin_amdgcn_readlane(v, 63);
+}

@@ -284,14 +284,28 @@ __device__ __forceinline__ void fwd_w128_body(const KlScanFwdWide& a, const int 
     if (c_row < nrow)
       *reinterpret_cast<float4*>(a.C + (trow + B + c_row) * W + c_seg * 4) = *reinterpret_cast<const float4*>(smem + F_CS + (p * 16 + c_row) * F_C_LD + c_seg * 16);
     if (h_row < nrow) {
+      // (PUB, a.sentinel == 2 -- rolling sentinels: the rows of step t + 2 become sentinels again while those of step t are
+      //  published, by the thread that is going to publish them; only the first two steps start out armed)
+      const bool arm = PUB && a.sentinel == 2 && t + 2 < T;
+      const uint4 ones = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
       if (tid < 256) {
         const uint4 v = *reinterpret_cast<const uint4*>(smem + F_HT + ((p ^ 1) * 16 + h_row) * F_H_LD + h_seg * 16);
-        if (PUB) store16_sc1(make_rsrc(a.H, (long)(T + 1) * B * W * 2), (unsigned)(((trow + B + h_row) * W + h_seg * 8) * 2), v);
-        else *reinterpret_cast<uint4*>(a.H + (trow + B + h_row) * W + h_seg * 8) = v;
+        if (PUB) {
+          const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.H, (long)(T + 1) * B * W * 2);
+          if (arm && !a.Hd) store16_sc1(rs, (unsigned)(((trow + 3L * B + h_row) * W + h_seg * 8) * 2), ones);
+          store16_sc1(rs, (unsigned)(((trow + B + h_row) * W + h_seg * 8) * 2), v);
+        } else {
+          *reinterpret_cast<uint4*>(a.H + (trow + B + h_row) * W + h_seg * 8) = v;
+        }
       } else if (a.Hd) {
         const uint4 v = *reinterpret_cast<const uint4*>(smem + F_HS + (p * 16 + h_row) * F_H_LD + h_seg * 16);
-        if (PUB) store16_sc1(make_rsrc(a.Hd, (long)T * B * W * 2), (unsigned)(((trow + h_row) * W + h_seg * 8) * 2), v);
-        else *reinterpret_cast<uint4*>(a.Hd + (trow + h_row) * W + h_seg * 8) = v;
+        if (PUB) {
+          const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.Hd, (long)T * B * W * 2);
+          if (arm) store16_sc1(rs, (unsigned)(((trow + 2L * B + h_row) * W + h_seg * 8) * 2), ones);
+          store16_sc1(rs, (unsigned)(((trow + h_row) * W + h_seg * 8) * 2), v);
+        } else {
+          *reinterpret_cast<uint4*>(a.Hd + (trow + h_row) * W + h_seg * 8) = v;
+        }
       }
     }
   }
@@ -483,8 +497,15 @@ __device__ __forceinline__ void bwd_w128_body(const KlScanBwd& a, const int rb, 
       const int i = tid + NT8 * k, row = i >> 6, seg = i & 63;
       if (row < nrow) {
         const uint4 v = *reinterpret_cast<const uint4*>(smem + B_ZT + (p * 16 + row) * B_Z_LD + seg * 16);
-        if (PUB) store16_sc1(make_rsrc(a.dZ[LY], (long)T * B * 4 * W * 2), (unsigned)(((trow + row) * 4 * W + seg * 8) * 2), v);
-        else *reinterpret_cast<uint4*>(a.dZ[LY] + (trow + row) * 4 * W + seg * 8) = v;
+        if (PUB) {
+          // (a.sentinel == 2 -- rolling sentinels: step t - 2 becomes sentinels again while step t is published; the first two start out armed)
+          const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.dZ[LY], (long)T * B * 4 * W * 2);
+          if (a.sentinel == 2 && t >= 2)
+            store16_sc1(rs, (unsigned)(((trow - 2L * B + row) * 4 * W + seg * 8) * 2), uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu});
+          store16_sc1(rs, (unsigned)(((trow + row) * 4 * W + seg * 8) * 2), v);
+        } else {
+          *reinterpret_cast<uint4*>(a.dZ[LY] + (trow + row) * 4 * W + seg * 8) = v;
+        }
       }
     }
   }
@@ -520,6 +541,176 @@ __global__ __launch_bounds__(NT8, 1) void lstm_scan_bwd_w128_multi_kernel(const 
     bwd_w128_body<true, true, true, 1>(a, rb, a.db_l[1]);
   } else {
     bwd_w128_body<true, true, true, 2>(a, rb, a.db_l[2]);
+  }
+}
+
+
+// ---------------------------------------------------------------- output layer of a training window at width 128
+// logits = X . E^T, softmax, cross-entropy, its gradient AND the gradient into the top layer, dH = dlogits . E, in one pass over
+// the rows: the embedding (<= 256 characters x 128 bf16 = 64 KiB) is stationary in registers in both orientations, 32 rows at
+// a time go through LDS, and out go the bf16 gradient rows dlogits (the embedding's gradient reads them), the f32 rows dH and
+// the per-row (loss, hit) pair.  The GEMM + softmax + GEMM this replaces wrote the logits as f32 (268 MB at 1024 streams), read
+// them back and read dlogits once more.  Same rules as softmax_ce_v256_kernel / logits_ce_ws_kernel (rating.py:255-258 through
+// Keras: probabilities clipped to [1e-7, 1 - 1e-7] -- no gradient outside --, padded positions count in the mean but carry no
+// target, accuracy = first maximum equals the target; targets < -1 = a dummy stream of the caller's padding: counts for nothing).
+struct KlCeW128 {
+  const bf16_t* X;       // [M][128] (masked) outputs of the top layer, time-major rows r = t B + b
+  const bf16_t* E;       // [Vp][128], rows beyond V zero
+  const bf16_t* ET;      // [128][Vp]
+  const int* tgt;        // [B][T]
+  bf16_t* dlogits;       // [M][Vp]
+  float* dH;             // [M][128]
+  float* rowstat;        // [M][2]
+  int M, B, T, V, Vp, n_wg, last_only;
+  float inv_count;
+};
+constexpr int CE_X_LD = 272, CE_Z_LD = 260, CE_G_LD = 528, CE_D_LD = 132;      // bytes / floats / bytes / floats
+constexpr int CE_XT = 0, CE_ZL = CE_XT + 2 * 32 * CE_X_LD, CE_GL = CE_ZL + 32 * CE_Z_LD * 4, CE_LDS = CE_GL + 32 * CE_G_LD;
+
+__global__ __launch_bounds__(1024, 1) void logits_ce_w128_kernel(const KlCeW128 a) {
+  constexpr int W = W8, ROWS = 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = blockIdx.x;
+  const int n_tiles_all = (a.M + ROWS - 1) / ROWS;
+  const int my_tiles = wg < n_tiles_all ? (n_tiles_all - wg + a.n_wg - 1) / a.n_wg : 0;
+  if (my_tiles == 0) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* zl = reinterpret_cast<float*>(smem + CE_ZL);
+  const int V = a.V, Vp = a.Vp, nk = Vp >> 5;      // (k-steps of the dH contraction)
+
+  // E for the logits: this wave's 16 characters, K = 128; E^T for dH: the 16 units of column tile wave & 7, K = Vp
+  u32x4 bu[4], be[8];
+  {
+    const int ch = 16 * wave + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      bu[j] = ch < Vp ? *reinterpret_cast<const u32x4*>(a.E + (long)ch * W + (lane >> 4) * 8 + j * 32) : u32x4{0u, 0u, 0u, 0u};
+    const int un = 16 * (wave & 7) + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      be[j] = j < nk ? *reinterpret_cast<const u32x4*>(a.ET + (long)un * Vp + (lane >> 4) * 8 + j * 32) : u32x4{0u, 0u, 0u, 0u};
+  }
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.X, (long)a.M * W * 2);
+  const __amdgpu_buffer_rsrc_t rs_dl = make_rsrc(a.dlogits, (long)a.M * Vp * 2);
+  const __amdgpu_buffer_rsrc_t rs_dh = make_rsrc(a.dH, (long)a.M * W * 4);
+  const __amdgpu_buffer_rsrc_t rs_rs = make_rsrc(a.rowstat, (long)a.M * 8);
+  // a tile's rows: 32 x 256 bytes = one 16-byte piece for each of the first 512 threads (rows beyond M read as zeros)
+  const int x_row = tid >> 4, x_seg = tid & 15;
+  auto fetch = [&](int i) __attribute__((always_inline)) {
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (tid < 512) {
+      const long row = (long)(wg + (long)i * a.n_wg) * ROWS + x_row;
+      v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, x_seg * 16, (int)(unsigned)(row * W * 2), 0));
+    }
+    return v;
+  };
+  auto put = [&](int buf, u32x4 v) __attribute__((always_inline)) {
+    if (tid < 512) *reinterpret_cast<u32x4*>(smem + CE_XT + (buf * ROWS + x_row) * CE_X_LD + x_seg * 16) = v;
+  };
+  u32x4 ra = fetch(0);
+  put(0, ra);
+  if (my_tiles > 1) ra = fetch(1);
+#pragma unroll 1
+  for (int i = 0; i < my_tiles; ++i) {
+    const int buf = i & 1;
+    const long row0 = (long)(wg + (long)i * a.n_wg) * ROWS;
+    __syncthreads();                       // tile i is complete in LDS; every wave has left tile i - 1, its logits and its gradient rows
+    if (i + 1 < my_tiles) put(buf ^ 1, ra);
+    if (i + 2 < my_tiles) ra = fetch(i + 2);
+    // ---- logits of 32 rows x this wave's 16 characters
+    {
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      const unsigned char* tb = smem + CE_XT + (buf * ROWS + (lane & 15)) * CE_X_LD + (lane >> 4) * 16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          acc[h] = mfma16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tb + h * 16 * CE_X_LD + j * 64)), __builtin_bit_cast(bf16x8, bu[j]), acc[h]);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zl[(h * 16 + 4 * (lane >> 4) + r) * CE_Z_LD + 16 * wave + (lane & 15)] = acc[h][r];
+    }
+    __syncthreads();
+    // ---- rows 2 wave, 2 wave + 1: one row per pass, lane = characters 4 lane .. 4 lane + 3
+#pragma unroll 1
+    for (int k2 = 0; k2 < 2; ++k2) {
+      const int lr = 2 * wave + k2;
+      const long row = row0 + lr;
+      const bool there = row < a.M;
+      const f32x4 z = *reinterpret_cast<const f32x4*>(zl + lr * CE_Z_LD + lane * 4);
+      const int v0 = lane * 4;
+      float e[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] = v0 + k < V ? z[k] : -INFINITY;      // (characters beyond the vocabulary do not exist)
+      const float mx = wave_max(fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3])));
+      const int first = e[0] == mx ? v0 : e[1] == mx ? v0 + 1 : e[2] == mx ? v0 + 2 : e[3] == mx ? v0 + 3 : 0x7fffffff;
+      const int amax = wave_min_i(first);
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        e[k] = __expf(e[k] - mx);
+        sum += e[k];
+      }
+      const float inv = 1.f / wave_sum(sum);
+      const long rr = there ? row : 0;
+      const int b = (int)(rr % a.B), tt = (int)(rr / a.B);
+      int t = a.tgt[(long)b * a.T + tt];
+      bool counts = true;
+      if (a.last_only && tt != a.T - 1) { t = -1; counts = false; }
+      if (t < -1) { t = -1; counts = false; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] *= inv;
+      float pt = 0.f;
+      if (t >= 0) {
+        const int tl = t >> 2, tk = t & 3;
+        const float cand = tk == 0 ? e[0] : tk == 1 ? e[1] : tk == 2 ? e[2] : e[3];
+        pt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand), tl));
+      }
+      const bool valid = t >= 0;
+      const bool active = there && valid && pt >= 1e-7f && pt <= 1.f - 1e-7f;
+      unsigned short g[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float gk = active ? e[k] : 0.f;
+        if (active && v0 + k == t) gk -= 1.f;
+        g[k] = f2bf(gk * a.inv_count);
+      }
+      const u32x2 gp = u32x2{(unsigned)g[0] | ((unsigned)g[1] << 16), (unsigned)g[2] | ((unsigned)g[3] << 16)};
+      *reinterpret_cast<u32x2*>(smem + CE_GL + lr * CE_G_LD + lane * 8) = gp;
+      if (v0 < Vp) __builtin_amdgcn_raw_buffer_store_b64(gp, rs_dl, lane * 8, (int)(unsigned)(row * Vp * 2), 0);      // (rows beyond M: out of the buffer's range, dropped)
+      if (lane == 0) {
+        float l = 0.f;
+        if (valid) {
+          const float pc = fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f);
+          l = -__logf(pc) * a.inv_count;
+        }
+        const int tsafe = valid ? t : 0;
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, l), __builtin_bit_cast(unsigned, (counts && amax == tsafe) ? a.inv_count : 0.f)},
+                                              rs_rs, 0, (int)(unsigned)(row * 8), 0);
+      }
+    }
+    __syncthreads();
+    // ---- dH of the tile: wave = (row half wave >> 3, 16 units of column tile wave & 7), K = Vp characters
+    {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int h = wave >> 3;
+      const unsigned char* gb = smem + CE_GL + (h * 16 + (lane & 15)) * CE_G_LD + (lane >> 4) * 16;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < nk) acc = mfma16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(gb + j * 64)), __builtin_bit_cast(bf16x8, be[j]), acc);
+      // (out as whole rows: through the logits' LDS, free since the barrier above)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zl[(h * 16 + 4 * (lane >> 4) + r) * CE_D_LD + 16 * (wave & 7) + (lane & 15)] = acc[r];
+    }
+    __syncthreads();
+    {
+      const int d_row = tid >> 5, d_seg = tid & 31;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(zl + d_row * CE_D_LD + d_seg * 4);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_dh, (int)(unsigned)(((row0 + d_row) * W + d_seg * 4) * 4), 0, 0);
+    }
   }
 }
 
@@ -581,7 +772,8 @@ int kl_launch_scan_fwd_w128(KlScanFwdWide a, hipStream_t stream) {
 bool kl_scan_w128_multi_fits(int B, int L) { return L >= 2 && L <= 4 && B >= 1 && (long)L * ((B + 15) / 16) <= w128_cus(); }
 
 // Backward, all layers in one launch: a.L layers in the slots 0 .. L - 1 (Un, Kn, G, C, dZ, mask, db_l), a.dH = the gradient from
-// the softmax side (f32, for the top layer); the CALLER pre-fills dZ[1 .. L - 1] with 0xFFFF halfwords.  KL_ERR_SHAPE = not applicable.
+// the softmax side (f32, for the top layer); the CALLER pre-fills dZ[1 .. L - 1] with 0xFFFF halfwords (all steps; a.sentinel == 2:
+// only steps T - 1 and T - 2, the publishing layer arms step t - 2 while it publishes step t).  KL_ERR_SHAPE = not applicable.
 int kl_launch_scan_bwd_w128_multi(KlScanBwd a, hipStream_t stream) {
   if (!kl_scan_w128_applicable(a.B, a.T, a.W) || !kl_scan_w128_multi_fits(a.B, a.L) || a.dZT || !a.dH || !a.status) return KL_ERR_SHAPE;
   for (int l = 0; l < a.L; ++l)
@@ -594,7 +786,8 @@ int kl_launch_scan_bwd_w128_multi(KlScanBwd a, hipStream_t stream) {
 }
 
 // The layers of a window in one launch (layers[0]: gate inputs P; layers[l > 0]: KT / X / bias with X = the rows layer l - 1
-// publishes -- the CALLER pre-fills those rows with 0xFFFF halfwords).  Only where every workgroup finds a CU at once
+// publishes -- the CALLER pre-fills those rows with 0xFFFF halfwords: all T steps, or with layers[l - 1].sentinel == 2 only the
+// first two, the publishing layer then arms step t + 2 while it publishes step t).  Only where every workgroup finds a CU at once
 // (layers x row blocks <= CUs): the point is to use CUs a single layer leaves idle.  KL_ERR_SHAPE = not applicable.
 int kl_launch_scan_fwd_w128_multi(const KlScanFwdWide* layers, int L, hipStream_t stream) {
   if (!kl_scan_w128_multi_fits(layers[0].B, L)) return KL_ERR_SHAPE;
@@ -626,5 +819,23 @@ int kl_launch_scan_bwd_w128(KlScanBwd a, hipStream_t stream) {
   if (kl_grant_lds(grant[xin], fn, lds)) return KL_ERR_LAUNCH;
   if (xin) hipLaunchKernelGGL(lstm_scan_bwd_w128_kernel<true>, dim3((a.B + 15) / 16), dim3(NT8), lds, stream, a);
   else hipLaunchKernelGGL(lstm_scan_bwd_w128_kernel<false>, dim3((a.B + 15) / 16), dim3(NT8), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+
+// Output layer of a training window at width 128 in one pass (logits_ce_w128_kernel): dlogits [M][Vp] bf16, dH [M][128] f32,
+// rowstat [M][2]; E [Vp][128] / ET [128][Vp] bf16 with zeros beyond V; the caller still reduces rowstat (kl_launch_rowstat_reduce).
+// KL_ERR_SHAPE = not applicable.
+int kl_launch_logits_ce_w128(const bf16_t* X, const bf16_t* E, const bf16_t* ET, const int* tgt, bf16_t* dlogits, float* dH, float* rowstat, int B,
+                             int T, int W, int V, int Vp, float inv_count, int last_only, hipStream_t stream) {
+  const long M = (long)B * T;
+  if (W != W8 || V < 1 || V > Vp || Vp > 256 || (Vp & 31) || M < 1 || M * 256L * 2 > 0xfffffff0L) return KL_ERR_SHAPE;
+  KlCeW128 a;
+  a.X = X; a.E = E; a.ET = ET; a.tgt = tgt; a.dlogits = dlogits; a.dH = dH; a.rowstat = rowstat;
+  a.M = (int)M; a.B = B; a.T = T; a.V = V; a.Vp = Vp; a.last_only = last_only; a.inv_count = inv_count;
+  const long n_tiles = (M + 31) / 32;
+  a.n_wg = (int)(n_tiles < w128_cus() ? n_tiles : w128_cus());
+  static KlLdsGrant grant;
+  if (kl_grant_lds(grant, reinterpret_cast<const void*>(&logits_ce_w128_kernel), (size_t)CE_LDS)) return KL_ERR_LAUNCH;
+  hipLaunchKernelGGL(logits_ce_w128_kernel, dim3(a.n_wg), dim3(1024), (size_t)CE_LDS, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
