@@ -162,6 +162,19 @@ __device__ __forceinline__ unsigned sentinel_bits(uint4 v) {
 }
 __device__ __forceinline__ bool sentinel_free(unsigned bits) { return (bits & 0x80008000u) == 0; }
 
+// ... for waves that check many granules: ONE packed instruction per dword -- the running maximum of the two halfword columns
+// (v_pk_max_u16) has a 0xFFFF halfword iff some dword had one in that column; three where sentinel_bits needs thirteen per granule
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned sentinel_acc(unsigned m, uint4 v) {
+  u16x2_t a = __builtin_bit_cast(u16x2_t, m);
+  a = __builtin_elementwise_max(a, __builtin_bit_cast(u16x2_t, v.x));
+  a = __builtin_elementwise_max(a, __builtin_bit_cast(u16x2_t, v.y));
+  a = __builtin_elementwise_max(a, __builtin_bit_cast(u16x2_t, v.z));
+  a = __builtin_elementwise_max(a, __builtin_bit_cast(u16x2_t, v.w));
+  return __builtin_bit_cast(unsigned, a);
+}
+__device__ __forceinline__ bool sentinel_acc_free(unsigned m) { return (m & 0xFFFFu) != 0xFFFFu && (m >> 16) != 0xFFFFu; }
+
 // v_exp_f32 / v_rcp_f32 forms (1 ulp each): the scans are latency chains, and the
 // training path computes in bf16 anyway
 __device__ __forceinline__ float fast_sigmoid(float x) {

@@ -618,6 +618,14 @@ __global__ __launch_bounds__(1024, 1) void logits_ce_w128_kernel(const KlCeW128 
     __syncthreads();                       // tile i is complete in LDS; every wave has left tile i - 1, its logits and its gradient rows
     if (i + 1 < my_tiles) put(buf ^ 1, ra);
     if (i + 2 < my_tiles) ra = fetch(i + 2);
+    // (the targets of this wave's two rows, asked for before the contraction: the softmax pass would wait a memory round trip for each)
+    int tg[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      const long row = row0 + 2 * wave + k2;
+      const long rr = row < a.M ? row : 0;
+      tg[k2] = a.tgt[(rr % a.B) * a.T + rr / a.B];
+    }
     // ---- logits of 32 rows x this wave's 16 characters
     {
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -655,9 +663,8 @@ __global__ __launch_bounds__(1024, 1) void logits_ce_w128_kernel(const KlCeW128 
         sum += e[k];
       }
       const float inv = 1.f / wave_sum(sum);
-      const long rr = there ? row : 0;
-      const int b = (int)(rr % a.B), tt = (int)(rr / a.B);
-      int t = a.tgt[(long)b * a.T + tt];
+      const int tt = (int)((there ? row : 0) / a.B);
+      int t = k2 == 0 ? tg[0] : tg[1];
       bool counts = true;
       if (a.last_only && tt != a.T - 1) { t = -1; counts = false; }
       if (t < -1) { t = -1; counts = false; }

@@ -24,6 +24,8 @@ namespace {
 
 #include "kl_scan_common.h"
 
+#include "kl_scan2_helpers.h"
+
 // wait_vm for counts up to 31 (vmcnt has six bits on gfx9; an under-estimate only waits longer)
 __device__ __forceinline__ void wait_vm_wide(int k) {
   if (k <= 15) {
@@ -38,6 +40,40 @@ __device__ __forceinline__ void wait_vm_wide(int k) {
   }
 #undef KL_WAIT_CASE
 }
+
+#ifdef KL_STAMP
+// diagnostic build: cycles per block of workgroup 0, thread 0 (a computing wave: slots 0..15) and thread 256 (a DMA wave: 16..31)
+__device__ unsigned long long kl_w32_stamps[32];
+#define WSTAMP(i)                                                                            \
+  do {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256)) {                       \
+      const unsigned long long now_ = clock64();                                             \
+      wstamp_lds[(threadIdx.x ? 16 : 0) + (i)] += now_ - wlast_;                             \
+      wlast_ = now_;                                                                         \
+    }                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+  } while (0)
+#define WCOUNT(i)                                                                            \
+  do {                                                                                       \
+    if (blockIdx.x == 0 && threadIdx.x == 256) wstamp_lds[16 + (i)] += 1;                    \
+  } while (0)
+#define WSTAMP_INIT()                                  \
+  __shared__ unsigned long long wstamp_lds[32];        \
+  if (threadIdx.x < 32) wstamp_lds[threadIdx.x] = 0;   \
+  __syncthreads();                                     \
+  unsigned long long wlast_ = clock64();
+#define WSTAMP_FLUSH()                                                                        \
+  do {                                                                                        \
+    __syncthreads();                                                                          \
+    if (blockIdx.x == 0 && threadIdx.x < 32 && wstamp_lds[threadIdx.x]) atomicAdd(&kl_w32_stamps[threadIdx.x], wstamp_lds[threadIdx.x]); \
+  } while (0)
+#else
+#define WSTAMP(i)
+#define WCOUNT(i)
+#define WSTAMP_INIT()
+#define WSTAMP_FLUSH()
+#endif
 
 constexpr int UN = 32;         // hidden units per workgroup
 constexpr int NT = 512;        // threads per workgroup
@@ -85,12 +121,16 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_bwd_w32_kernel(const KlScanBw
 #pragma unroll
     for (int j = 0; j < KSTEPS; ++j) bu[j] = *reinterpret_cast<const uint4*>(a.Un[0] + wrow + j * 32 + kq);
   }
-  const int er = tid >> 5, eu = tid & 31;          // epilogue thread = (row of 16, unit of 32)
-  float dc_one = 0.f;
+  // Roles (round 4): waves 4-7 bring the tiles in and check them -- nothing else but the contraction --, waves 0-3 run the
+  // epilogue (two cells per lane: row 4 wave + (lane >> 4), units 2 (lane & 15) and the next) and publish what they computed
+  // themselves, staged through 1 KiB of LDS per wave: no workgroup barrier between the epilogue and the publish.
+  const bool e_wave = wave < 4;
+  const int er = 4 * (wave & 3) + (lane >> 4), eu = 2 * (lane & 15);
+  float dc_one[2] = {0.f, 0.f};
   if (MAXRB > 1) {
-    for (int i = 0; i < MAXRB; ++i) dc_slot[i * NT] = 0.f;
+    for (int i = 0; i < MAXRB; ++i) dc_slot[i * NT] = 0.f;      // (an epilogue lane's two cells: slots tid and tid + 256)
   }
-  float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+  float dbacc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   const long BW = (long)B * W;
   const bf16_t* Gl = a.G[0];
   const float* Cl = a.C[0];
@@ -98,74 +138,117 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_bwd_w32_kernel(const KlScanBw
   const float* maskl = a.mask[0];
   unsigned* status = a.status;
   const __amdgpu_buffer_rsrc_t rs_own = make_rsrc(a.dZ[0], (long)T * BW * 4 * 2);
+  const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(Gl, (long)T * BW * 4 * 2);
+  const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(Cl, (long)(T + 1) * BW * 4);
+  const __amdgpu_buffer_rsrc_t rs_dh = make_rsrc(dH, (long)T * BW * 4);
   bool alive = true;
   constexpr bool PREF = MAXRB > 1;
   const bool pref_ok = (B & 15) == 0;
-  const int n_raw = maskl ? 8 : 7;                 // epilogue inputs loaded at the top of a block, behind the DMA
   const unsigned lds_a = (unsigned)(size_t)(lds_void_t*)a_tile;
   if (tid == 0) ok_flag = 1;
   __syncthreads();
   bool local = false;
   if (a.xcc_slots)
     local = xcd_local_group(a.xcc_slots, a.gen, NWG_RB, [&](int j) { return xcd + 8 * (rq * NWG_RB + j); }, flags + 1, status);
+  // fragment of k-step j of a half (lane = row l & 15, k-piece q = l >> 4): piece (4 (j & 15) + q) ^ row of the row's KiB
+  // = row * 1024 + 256 ((j & 15) >> 2) + 16 ((4 (j & 3) + q) ^ row): one offset per j & 3, the rest is an immediate
+  unsigned frag_off[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) frag_off[m] = (unsigned)((lane & 15) * 1024 + (((4 * m + (lane >> 4)) ^ (lane & 15)) * 16));
   const bool dma_wave = wave >= 4;
   const int dq = wave - 4;                         // the quarter a DMA wave brings in
-  // The tile comes in two halves -- k-steps [0, KH) and [KH, KSTEPS) of every quarter -- that are requested, checked and
-  // multiplied one after the other: half A of the NEXT block is requested as soon as this block's half A has been
-  // multiplied (it travels under half B's MFMAs and the epilogue), half B behind this block's last MFMA.  With the
-  // whole tile requested only behind the MFMA phase, two thirds of its travel time was exposed (timing experiments of
-  // round 3: 6.8 of 15.5 ms per launch at 512 streams).
+  // The tile of the NEXT block is requested as soon as every wave has multiplied this block's (the barrier behind the
+  // contraction): it lands within a few hundred cycles of its last request (stamps) and is checked by the requesting wave
+  // right away, under the epilogue of waves 0-3.
+  int pf = 0;                                      // this block's tile was requested (and checked) during the block before
+  WSTAMP_INIT();
   constexpr int KH = KSTEPS / 2;
-  int pf_a = 0, pf_b = 0;                          // this block's halves are in flight (requested during the block before)
+  static_assert(KH == 16, "a tile half of a quarter = 16 rows x 1 KiB");
 
-  // requests for half hf of the tile of block (nt, nr0): dZ[nt + 1]
-  auto request_half = [&](int hf, int nt, int nr0) {
-    const unsigned nbase = (unsigned)((((long)(nt + 1) * B + min(nr0 + (lane & 15), B - 1)) * 4 * W + (long)dq * W + kq) * 2);
+  // A half of a quarter is 16 rows x 1 KiB (512 k-values), and ONE REQUEST = ONE ROW'S KiB: 64 lanes on 1024 consecutive bytes.
+  // (The first cut requested MFMA fragments -- lane (row, k-piece): consecutive lanes 8 KiB apart, 64 addresses for the
+  //  address unit to handle one by one -- and a DMA wave spent ~2 700 cycles issuing the 16 requests of a half, with the
+  //  computing waves waiting behind it at the next barrier: stamps, tools/probe_w32_stamps.py.)  The LDS image is lane-linear
+  // (lane l lands at 16 l), so row r's 16-byte piece p lies at r * 1024 + 16 (p ^ r): the swizzle is applied at the SOURCE
+  // (lane l asks for piece l ^ r) and again where the fragments are read -- lane (row, q) of k-step j reads piece (4 j + q) ^ row,
+  // which puts the 16 lanes the LDS serves together on 16 different 16-byte slots.
+  // (the swizzled lane offsets of the 16 rows, once; the row's own offset is wave-uniform and travels in a scalar register)
+  unsigned swz[16];
 #pragma unroll
-    for (int j = 0; j < KH; ++j) {
-      const int jj = hf * KH + j;
-      if (local) glds16_nt(rs_own, nbase + jj * 64, lds_a + (dq * KSTEPS + jj) * 1024);
-      else glds16_sc1(rs_own, nbase + jj * 64, lds_a + (dq * KSTEPS + jj) * 1024);
+  for (int j = 0; j < 16; ++j) swz[j] = (unsigned)((lane ^ j) * 16);
+  auto request_row = [&](int hf, int j, int bt, int br0) __attribute__((always_inline)) {
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((((long)(bt + 1) * B + min(br0 + j, B - 1)) * 4 * W + (long)dq * W + hf * (KH * 32)) * 2));
+    if (local) glds16_nt_s(rs_own, (unsigned)((lane ^ j) * 16), so, __builtin_amdgcn_readfirstlane(lds_a + (dq * KSTEPS + hf * KH + j) * 1024));
+    else glds16_sc1_s(rs_own, (unsigned)((lane ^ j) * 16), so, __builtin_amdgcn_readfirstlane(lds_a + (dq * KSTEPS + hf * KH + j) * 1024));
+  };
+  // requests for half hf of the tile of block (nt, nr0): dZ[nt + 1].  Whole row blocks (the prefetched path: B % 16 == 0): the 16
+  // rows lie 8 KiB apart, ONE asm block walks M0 and the scalar offset through them -- three instructions per request.
+  auto request_half = [&](int hf, int nt, int nr0) __attribute__((always_inline)) {
+    if (pref_ok) {
+      unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((((long)(nt + 1) * B + nr0) * 4 * W + (long)dq * W + hf * (KH * 32)) * 2));
+      const unsigned l0 = __builtin_amdgcn_readfirstlane(lds_a + (dq * KSTEPS + hf * KH) * 1024);
+      unsigned keep;
+#define KL_W32_REQ16(MOD)                                                                                                          \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                                        \
+                   "buffer_load_dwordx4 %4, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_add_u32 %1, %1, 0x2000\n\t"   \
+                   "buffer_load_dwordx4 %5, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_add_u32 %1, %1, 0x2000\n\t"   \
+                   "buffer_load_dwordx4 %6, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_add_u32 %1, %1, 0x2000\n\t"   \
+                   "buffer_load_dwordx4 %7, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_add_u32 %1, %1, 0x2000\n\t"   \
+                   "buffer_load_dwordx4 %8, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_add_u32 %1, %1, 0x2000\n\t"   \
+                   "buffer_load_dwordx4 %9, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_add_u32 %1, %1, 0x2000\n\t"   \
+                   "buffer_load_dwordx4 %10, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_add_u32 %1, %1, 0x2000\n\t"  \
+                   "buffer_load_dwordx4 %11, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_add_u32 %1, %1, 0x2000\n\t"  \
+                   "buffer_load_dwordx4 %12, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_add_u32 %1, %1, 0x2000\n\t"  \
+                   "buffer_load_dwordx4 %13, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_add_u32 %1, %1, 0x2000\n\t"  \
+                   "buffer_load_dwordx4 %14, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_add_u32 %1, %1, 0x2000\n\t"  \
+                   "buffer_load_dwordx4 %15, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_add_u32 %1, %1, 0x2000\n\t"  \
+                   "buffer_load_dwordx4 %16, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_add_u32 %1, %1, 0x2000\n\t"  \
+                   "buffer_load_dwordx4 %17, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_add_u32 %1, %1, 0x2000\n\t"  \
+                   "buffer_load_dwordx4 %18, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_add_u32 %1, %1, 0x2000\n\t"  \
+                   "buffer_load_dwordx4 %19, %2, %1 offen " MOD " lds\n\ts_mov_b32 m0, %0"                                         \
+                   : "=&s"(keep), "+s"(so)                                                                                          \
+                   : "s"(rs_own), "s"(l0), "v"(swz[0]), "v"(swz[1]), "v"(swz[2]), "v"(swz[3]), "v"(swz[4]), "v"(swz[5]), "v"(swz[6]),    \
+                     "v"(swz[7]), "v"(swz[8]), "v"(swz[9]), "v"(swz[10]), "v"(swz[11]), "v"(swz[12]), "v"(swz[13]), "v"(swz[14]),        \
+                     "v"(swz[15])                                                                                                   \
+                   : "memory", "scc")
+      static_assert(W * 4 * 2 == 0x2000, "row stride of dZ");
+      if (local) KL_W32_REQ16("nt");
+      else KL_W32_REQ16("sc1");
+#undef KL_W32_REQ16
+    } else {
+#pragma unroll
+      for (int j = 0; j < KH; ++j) request_row(hf, j, nt, nr0);
     }
   };
-  // DMA waves: half hf of this block's tile is complete and free of sentinels (else re-fetched until it is).
-  // in_flight: it was requested ahead; then at most `younger` later requests of this wave may still be outstanding.
-  auto await_half = [&](int hf, int t, int r0, bool in_flight, int younger) {
-    unsigned char* frag = a_tile + (dq * KSTEPS + hf * KH) * 1024 + lane * 16;
-    const unsigned base = (unsigned)((((long)(t + 1) * B + min(r0 + (lane & 15), B - 1)) * 4 * W + (long)dq * W + kq) * 2);
+  // DMA waves: is what landed of half hf free of sentinels?  (16 KiB per wave: the running halfword maximum, two chains)
+  auto look_half = [&](int hf, bool one_row) __attribute__((always_inline)) {
+    const unsigned char* frag = a_tile + (dq * KSTEPS + hf * KH) * 1024 + lane * 16;
+    unsigned m0 = 0, m1 = 0;
+    if (one_row) {
+      m0 = sentinel_acc(0u, *reinterpret_cast<const uint4*>(frag + (KH - 1) * 1024));
+    } else {
+#pragma unroll
+      for (int j = 0; j < KH; j += 2) {
+        m0 = sentinel_acc(m0, *reinterpret_cast<const uint4*>(frag + j * 1024));
+        m1 = sentinel_acc(m1, *reinterpret_cast<const uint4*>(frag + (j + 1) * 1024));
+      }
+    }
+    return __all(sentinel_acc_free(m0) && sentinel_acc_free(m1));
+  };
+  // ... the slow path (nothing requested ahead, or the look found sentinels): fetched again until it is complete.  The wave first
+  // probes ONE row (256 workgroups spinning on whole tiles slow the publishes down) and fetches the rest once that one is there.
+  auto fetch_half = [&](int hf, int t, int r0) __attribute__((always_inline)) {
     bool ok = false;
     if (alive) {
-      // Without a request in flight the wave first probes ONE fragment (256 workgroups spinning on whole tiles slow
-      // the publishes down) and fetches the rest once that one is there.
-      bool probe = !in_flight;
+      bool probe = true;
       for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
-        if (in_flight) {
-          wait_vm_wide(younger);                 // (this wave's queue holds loads only, in order)
-        } else if (probe) {
-          const int jj = hf * KH + KH - 1;
-          if (local) glds16_nt(rs_own, base + jj * 64, lds_a + (dq * KSTEPS + jj) * 1024);
-          else glds16_sc1(rs_own, base + jj * 64, lds_a + (dq * KSTEPS + jj) * 1024);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-          request_half(hf, t, r0);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        unsigned bits = 0;
-        if (probe) {
-          bits = sentinel_bits(*reinterpret_cast<const uint4*>(frag + (KH - 1) * 1024));
-        } else {
-          uint4 v[8];
-#pragma unroll
-          for (int hh = 0; hh < KH / 8; ++hh) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const uint4*>(frag + (hh * 8 + j) * 1024);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) bits |= sentinel_bits(v[j]);
-          }
-        }
-        const bool good = __all(sentinel_free(bits));
+        if (probe) request_row(hf, KH - 1, t, r0);
+        else
+#pragma unroll 1
+          for (int j = 0; j < KH; ++j) request_row(hf, j, t, r0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool good = look_half(hf, probe);
         if (good && !probe) { ok = true; break; }
-        in_flight = false;
         probe = !good;                             // the probe passed: now the whole half; a bad half: back to probing
         if (!good) {
           if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
@@ -178,7 +261,8 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_bwd_w32_kernel(const KlScanBw
       }
     }
     if (!ok) {
-#pragma unroll
+      unsigned char* frag = a_tile + (dq * KSTEPS + hf * KH) * 1024 + lane * 16;
+#pragma unroll 1
       for (int j = 0; j < KH; ++j) *reinterpret_cast<uint4*>(frag + j * 1024) = uint4{0, 0, 0, 0};
     }
   };
@@ -186,104 +270,131 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_bwd_w32_kernel(const KlScanBw
   for (int t = T - 1; t >= 0; --t) {
 #pragma unroll 1
     for (int i = 0; i < MAXRB; ++i) {
+      WSTAMP(0);
       const int rb = rg + i * n_rg;
       if (rb >= n_rb) continue;
       const int r0 = rb * 16;
       const int erow = min(r0 + er, B - 1);
-      // (raw loads only; they are consumed in the epilogue behind a compiler fence)
-      const bf16_t* gp = Gl + ((long)t * B + erow) * 4 * W + u0 + eu;
-      unsigned g0 = gp[0], g1 = gp[W], g2 = gp[2 * W], g3 = gp[3 * W];
-      float c = Cl[((long)(t + 1) * B + erow) * W + u0 + eu];
-      float cp = Cl[((long)t * B + erow) * W + u0 + eu];
-      float dh = dH[((long)t * B + erow) * W + u0 + eu];
-      float mkv = maskl ? maskl[(long)erow * W + u0 + eu] : 1.f;
+      // epilogue inputs of waves 0-3 (raw loads, consumed behind the contraction): the gates as the aligned dwords that hold
+      // the lane's two units -- a 16-bit load is zero-extended by an instruction of its own RIGHT BEHIND the load, i.e. a wait
+      // at the top of every block (3 000 cycles per block in the first cut, stamps)
+      unsigned g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+      float2 c = float2{0.f, 0.f}, cp = c, dh = c, mkv = float2{1.f, 1.f};
+      if (e_wave) {
+        // (buffer loads: the block's offset is wave-uniform and travels in a scalar register, the lane's part is two
+        //  instructions -- eight 64-bit address computations per block were 1 300 cycles of the epilogue waves' block)
+        const unsigned vrow = (unsigned)((erow - r0) * W + u0 + eu);                 // elements inside the block's 16 rows
+        const unsigned sg = (unsigned)(((long)t * B + r0) * 4 * W * 2), sc = (unsigned)(((long)t * B + r0) * W * 4);
+        const unsigned vg = (unsigned)(((erow - r0) * 4 * W + u0 + eu) * 2);
+        g0 = __builtin_amdgcn_raw_buffer_load_b32(rs_g, (int)vg, (int)sg, 0);
+        g1 = __builtin_amdgcn_raw_buffer_load_b32(rs_g, (int)(vg + W * 2), (int)sg, 0);
+        g2 = __builtin_amdgcn_raw_buffer_load_b32(rs_g, (int)(vg + 2 * W * 2), (int)sg, 0);
+        g3 = __builtin_amdgcn_raw_buffer_load_b32(rs_g, (int)(vg + 3 * W * 2), (int)sg, 0);
+        // (dword loads: this toolchain's __builtin_amdgcn_raw_buffer_load_b64 comes out as ONE 32-bit load, both elements the same)
+        auto ld = [&](__amdgpu_buffer_rsrc_t r, unsigned so, int k) __attribute__((always_inline)) {
+          return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(vrow * 4 + k * 4), (int)so, 0));
+        };
+        c = float2{ld(rs_c, sc + (unsigned)B * W * 4, 0), ld(rs_c, sc + (unsigned)B * W * 4, 1)};
+        cp = float2{ld(rs_c, sc, 0), ld(rs_c, sc, 1)};
+        dh = float2{ld(rs_dh, sc, 0), ld(rs_dh, sc, 1)};
+        if (maskl) mkv = *reinterpret_cast<const float2*>(maskl + (long)erow * W + u0 + eu);
+      }
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       // the block this workgroup visits next, and whether its tile may be asked for ahead
       int ni = i + 1, nt = t;
       if (ni >= MAXRB || rg + ni * n_rg >= n_rb) { ni = 0; nt = t - 1; }
       const int nr0 = (rg + ni * n_rg) * 16;
-      const bool ahead = PREF && dma_wave && pref_ok && nt >= 0 && nt < T - 1;
-      int nx_a = 0, nx_b = 0;
+      const bool ahead = PREF && pref_ok && nt >= 0 && nt < T - 1;
+      WSTAMP(1);
       if (t < T - 1) {
-        if (dma_wave) await_half(0, t, r0, pf_a != 0, (pf_b ? KH : 0) + n_raw);
-        __syncthreads();
+        if (dma_wave && !pf) {      // nothing was requested ahead (one block per workgroup, a ragged batch, the first visit)
+          fetch_half(0, t, r0);
+          fetch_half(1, t, r0);
+        }
+        WSTAMP(2);
+        __syncthreads();            // the tile is there and checked; the partial sums and the staging of the block before are free
         alive = ok_flag != 0;
+        WSTAMP(3);
 #pragma unroll
-        for (int j = 0; j < KH; ++j) {
+        for (int j = 0; j < KSTEPS; ++j) {
           frag16 fa, fb;
-          fa.u = *reinterpret_cast<const uint4*>(a_tile + (kq4 * KSTEPS + j) * 1024 + lane * 16);
+          fa.u = *reinterpret_cast<const uint4*>(a_tile + (kq4 * KSTEPS + (j >= KH ? KH : 0)) * 1024 + frag_off[j & 3] + ((j & (KH - 1)) >> 2) * 256);
           fb.u = bu[j];
           acc = mfma16(fa.v, fb.v, acc);
         }
-        __syncthreads();      // half A of the buffer is free
-        // (the epilogue inputs have long arrived; waiting for them HERE keeps the compiler's wait in front of the requests below)
-        asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(c), "+v"(cp), "+v"(dh), "+v"(mkv));
-        if (ahead && alive) {
-          request_half(0, nt, nr0);
-          nx_a = 1;
-        }
-        if (dma_wave) await_half(1, t, r0, pf_b != 0, nx_a ? KH : 0);
-        __syncthreads();
-        alive = ok_flag != 0;
-#pragma unroll
-        for (int j = KH; j < KSTEPS; ++j) {
-          frag16 fa, fb;
-          fa.u = *reinterpret_cast<const uint4*>(a_tile + (kq4 * KSTEPS + j) * 1024 + lane * 16);
-          fb.u = bu[j];
-          acc = mfma16(fa.v, fb.v, acc);
-        }
+        WSTAMP(4);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) zt[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
-      __syncthreads();
-      asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(c), "+v"(cp), "+v"(dh), "+v"(mkv));
-      if (ahead && alive) {      // the whole buffer is free: the rest of the next block's tile
-        if (!nx_a) {
+      WSTAMP(5);
+      __syncthreads();              // the partial sums are there; the tile buffer is free
+      WSTAMP(6);
+      pf = 0;
+      if (dma_wave) {
+        if (ahead && alive) {       // the next block's tile: requested, landed, checked -- this wave's queue holds nothing else
           request_half(0, nt, nr0);
-          nx_a = 1;
+          request_half(1, nt, nr0);
+          WSTAMP(7);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          WSTAMP(8);
+          const bool there = look_half(0, false) && look_half(1, false);
+          if (!there) {
+            fetch_half(0, nt, nr0);
+            fetch_half(1, nt, nr0);
+          }
+          pf = 1;
+          WSTAMP(9);
         }
-        request_half(1, nt, nr0);
-        nx_b = 1;
-      }
-      pf_a = nx_a;
-      pf_b = nx_b;
-      const int wz = (eu >> 4) * 4;                // the four K-quarter waves of this unit group
-      dh = dh * mkv + (zt[wz][er][eu & 15] + zt[wz + 1][er][eu & 15] + zt[wz + 2][er][eu & 15] + zt[wz + 3][er][eu & 15]);
-      const float gi = bf2f((bf16_t)g0), gf = bf2f((bf16_t)g1), gg = bf2f((bf16_t)g2), go = bf2f((bf16_t)g3);
-      const float tc = fast_tanh(c);
-      const float dc = dh * go * (1.f - tc * tc) + (MAXRB > 1 ? dc_slot[i * NT] : dc_one);
-      if (MAXRB > 1) dc_slot[i * NT] = dc * gf;
-      else dc_one = dc * gf;
-      const float d_o = dh * tc, d_i = dc * gg, d_g = dc * gi, d_f = dc * cp;
-      const unsigned z0 = f2bf(d_i * gi * (1.f - gi)), z1 = f2bf(d_f * gf * (1.f - gf));
-      const unsigned z2 = f2bf(d_g * (1.f - gg * gg)), z3 = f2bf(d_o * go * (1.f - go));
-      const bool row_ok = (r0 + er) < B;
-      if (row_ok && alive) {
-        dbacc[0] += bf2f((bf16_t)z0); dbacc[1] += bf2f((bf16_t)z1); dbacc[2] += bf2f((bf16_t)z2); dbacc[3] += bf2f((bf16_t)z3);
-      }
-      pub[(0 * 16 + er) * UN + eu] = (bf16_t)z0;
-      pub[(1 * 16 + er) * UN + eu] = (bf16_t)z1;
-      pub[(2 * 16 + er) * UN + eu] = (bf16_t)z2;
-      pub[(3 * 16 + er) * UN + eu] = (bf16_t)z3;
-      __syncthreads();
-      // publish dZ[t]: waves 0-3, one 16-byte store per lane (the data is its own signal)
-      if (wave < 4) {
-        const int g = tid >> 6, prow = (tid >> 2) & 15, seg = tid & 3;
+      } else {
+        asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3));
+        const float cc[2] = {c.x, c.y}, cpp[2] = {cp.x, cp.y}, dhh[2] = {dh.x, dh.y}, mk[2] = {mkv.x, mkv.y};
+        unsigned zz[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int u = eu + k, wz = (u >> 4) * 4, uc = u & 15;      // the four K-quarter waves of this unit's group
+          const float dhv = dhh[k] * mk[k] + (zt[wz][er][uc] + zt[wz + 1][er][uc] + zt[wz + 2][er][uc] + zt[wz + 3][er][uc]);
+          const int gsh = k * 16;
+          const float gi = bf2f((bf16_t)(g0 >> gsh)), gf = bf2f((bf16_t)(g1 >> gsh)), gg = bf2f((bf16_t)(g2 >> gsh)), go = bf2f((bf16_t)(g3 >> gsh));
+          const float tc = fast_tanh(cc[k]);
+          const float dc = dhv * go * (1.f - tc * tc) + (MAXRB > 1 ? dc_slot[i * NT + k * 256] : dc_one[k]);
+          if (MAXRB > 1) dc_slot[i * NT + k * 256] = dc * gf;
+          else dc_one[k] = dc * gf;
+          const float d_o = dhv * tc, d_i = dc * gg, d_g = dc * gi, d_f = dc * cpp[k];
+          const unsigned z0 = f2bf(d_i * gi * (1.f - gi)), z1 = f2bf(d_f * gf * (1.f - gf));
+          const unsigned z2 = f2bf(d_g * (1.f - gg * gg)), z3 = f2bf(d_o * go * (1.f - go));
+          if ((r0 + er) < B && alive) {
+            dbacc[k][0] += bf2f((bf16_t)z0); dbacc[k][1] += bf2f((bf16_t)z1); dbacc[k][2] += bf2f((bf16_t)z2); dbacc[k][3] += bf2f((bf16_t)z3);
+          }
+          zz[0] |= z0 << gsh; zz[1] |= z1 << gsh; zz[2] |= z2 << gsh; zz[3] |= z3 << gsh;
+        }
+        // this wave's 4 rows x 4 gates x 64 bytes through its own KiB of staging: segment = (row of 4, gate), the lane's dword
+        unsigned char* stage = reinterpret_cast<unsigned char*>(pub) + wave * 1024;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<unsigned*>(stage + ((lane >> 4) * 4 + g) * 64 + (lane & 15) * 4) = zz[g];
+        WSTAMP(7);
+        // publish dZ[t]: one 16-byte store per lane (the data is its own signal)
+        const int seg = lane >> 2, prow = 4 * wave + (seg >> 2), pg = seg & 3;
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + lane * 16);      // (same wave: ordered by the LDS counter)
         if (alive && r0 + prow < B) {
-          const uint4 v = *reinterpret_cast<const uint4*>(pub + (g * 16 + prow) * UN + seg * 8);
-          const unsigned off = (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2);
+          const unsigned off = (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)pg * W + u0 + (lane & 3) * 8) * 2);
           if (local) store16(rs_own, off, 0u, v);      // stays in this XCD's L2, where all its readers are
           else store16_sc1(rs_own, off, v);
         }
+        WSTAMP(8);
       }
     }
   }
+  WSTAMP_FLUSH();
   // db[g*W + u] += sum over this workgroup's rows and all steps
   if (a.db) {
     __syncthreads();
     float* red = reinterpret_cast<float*>(a_tile);     // [4 gates][16 rows][32 units]
+    if (e_wave) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) red[(g * 16 + er) * UN + eu] = dbacc[g];
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[(g * 16 + er) * UN + eu + k] = dbacc[k][g];
+    }
     __syncthreads();
     if (tid < 4 * UN) {
       const int g = tid >> 5, u = tid & 31;
@@ -350,7 +461,6 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
   bool alive = true;
   constexpr bool PREF = MAXRB > 1;
   const bool pref_ok = (B & 15) == 0;
-  const int n_raw = maskl ? 5 : 4;
   const unsigned lds_a = (unsigned)(size_t)(lds_void_t*)a_tile;
   if (tid == 0) ok_flag = 1;
   __syncthreads();
@@ -365,12 +475,50 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
   // (at most n_raw younger loads outstanding) is exact -- the compiler's own wait for the inputs, one block later,
   // finds them long arrived.
   int cur = 0, pf_issued = 0;
-  auto request_tile = [&](int buf, int nt, int nr0) {
-    const unsigned nbase = (unsigned)((((long)nt * B + min(nr0 + (lane & 15), B - 1)) * W + (dq * KQ) * 32 + kq) * 2);
+  // (whole row blocks: the lane's part of the eight requests' addresses -- rows 2 j + (l >> 5), 2 KiB apart, piece (l & 31) ^ row)
+  unsigned swz[8];
 #pragma unroll
-    for (int j = 0; j < KQ; ++j) {
-      if (local) glds16_nt(rs_h, nbase + j * 64, lds_a + buf * (KSTEPS * 1024) + (dq * KQ + j) * 1024);
-      else glds16_sc1(rs_h, nbase + j * 64, lds_a + buf * (KSTEPS * 1024) + (dq * KQ + j) * 1024);
+  for (int j = 0; j < 8; ++j) swz[j] = (unsigned)((2 * j + (lane >> 5)) * (W * 2) + ((((lane & 31) ^ (2 * j + (lane >> 5))) & 31) * 16));
+  // fragment of k-step j of a quarter (lane = row l & 15, k-piece q = l >> 4): piece (4 j + q) ^ row of the row's 512 bytes
+  unsigned frag_off[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) frag_off[m] = (unsigned)((lane & 15) * 512 + (((4 * m + (lane >> 4)) ^ (lane & 15)) * 16));
+  // A DMA wave's share of a tile is 16 rows x 512 bytes (its K-quarter), and ONE REQUEST = TWO ROWS' 512 bytes: 32 lanes on 512
+  // consecutive bytes.  (The first cut requested MFMA fragments -- consecutive lanes in different rows, 64 addresses for the
+  // address unit to handle one by one: see the backward scan above.)  The LDS image is lane-linear, i.e. row-major
+  // [16 rows][512 bytes] per quarter; row r's 16-byte piece p lies at r * 512 + 16 (p ^ r) -- swizzled at the SOURCE (the lane
+  // that lands at piece position l & 31 of row r asks for piece (l & 31) ^ r) and again where the fragments are read.
+  static_assert(KQ == 8, "a DMA wave's share of a tile = 16 rows x 512 bytes");
+  auto request_tile = [&](int buf, int nt, int nr0) __attribute__((always_inline)) {
+    const unsigned l0 = __builtin_amdgcn_readfirstlane(lds_a + buf * (KSTEPS * 1024) + (dq * KQ) * 1024);
+    if (pref_ok) {      // whole row blocks: one scalar offset, M0 walks through the eight requests
+      const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((((long)nt * B + nr0) * W + (dq * KQ) * 32) * 2));
+      unsigned keep;
+#define KL_W32_REQ8(MOD)                                                                                              \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                           \
+                   "buffer_load_dwordx4 %4, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"     \
+                   "buffer_load_dwordx4 %5, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"     \
+                   "buffer_load_dwordx4 %6, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"     \
+                   "buffer_load_dwordx4 %7, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"     \
+                   "buffer_load_dwordx4 %8, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"     \
+                   "buffer_load_dwordx4 %9, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"     \
+                   "buffer_load_dwordx4 %10, %2, %1 offen " MOD " lds\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"    \
+                   "buffer_load_dwordx4 %11, %2, %1 offen " MOD " lds\n\ts_mov_b32 m0, %0"                            \
+                   : "=&s"(keep)                                                                                       \
+                   : "s"(so), "s"(rs_h), "s"(l0), "v"(swz[0]), "v"(swz[1]), "v"(swz[2]), "v"(swz[3]), "v"(swz[4]), "v"(swz[5]),   \
+                     "v"(swz[6]), "v"(swz[7])                                                                          \
+                   : "memory", "scc")
+      if (local) KL_W32_REQ8("nt");
+      else KL_W32_REQ8("sc1");
+#undef KL_W32_REQ8
+    } else {
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) {
+        const int row = 2 * j + (lane >> 5);
+        const unsigned src = (unsigned)((((long)nt * B + min(nr0 + row, B - 1)) * W + (dq * KQ) * 32) * 2) + (unsigned)((((lane & 31) ^ row) & 31) * 16);
+        if (local) glds16_nt(rs_h, src, l0 + j * 1024);
+        else glds16_sc1(rs_h, src, l0 + j * 1024);
+      }
     }
   };
   // the first block's inputs
@@ -397,16 +545,17 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
         if (alive) {
           bool issued = PREF && pf_issued;
           for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
-            if (issued) {
-              wait_vm(n_raw);
+            if (issued) {      // (at most the epilogue inputs are younger; the count as a constant)
+              if (maskl) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+              else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             } else {
               request_tile(cur, t, r0);
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             unsigned bits = 0;
 #pragma unroll
-            for (int j = 0; j < KQ; ++j) bits |= sentinel_bits(*reinterpret_cast<const uint4*>(frag + j * 1024));
-            if (__all(t == 0 || sentinel_free(bits))) { ok = true; break; }
+            for (int j = 0; j < KQ; ++j) bits = sentinel_acc(bits, *reinterpret_cast<const uint4*>(frag + j * 1024));
+            if (__all(t == 0 || sentinel_acc_free(bits))) { ok = true; break; }
             issued = false;
             if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
             __builtin_amdgcn_s_sleep(2);
@@ -450,7 +599,7 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
 #pragma unroll
       for (int j = 0; j < KQ; ++j) {
         frag16 fa;
-        fa.u = *reinterpret_cast<const uint4*>(tile + (kq4 * KQ + j) * 1024 + lane * 16);
+        fa.u = *reinterpret_cast<const uint4*>(tile + (kq4 * KQ) * 1024 + frag_off[j & 3] + (j >> 2) * 256);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           frag16 fb;
@@ -580,3 +729,13 @@ int kl_launch_scan_fwd_w32(KlScanFwd a, hipStream_t stream) {
   else KL_W32_LAUNCH(lstm_scan_fwd_w32_kernel, 8, KL_W32_FWD_LDS(32));
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
+
+#ifdef KL_STAMP
+extern "C" int kl_test_w32_stamps(unsigned long long* out, int reset) {
+  if (reset) {
+    unsigned long long zeros[32] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(kl_w32_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : KL_ERR_LAUNCH;
+  }
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(kl_w32_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
+#endif
