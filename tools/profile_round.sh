@@ -26,3 +26,12 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$
 cp $OUT/${TAG}_rate_stats/*/*_kernel_stats.csv $OUT/${TAG}_rating_window_B1_kernel_stats.csv
 grep "us/step" $OUT/${TAG}_inc1024.log $OUT/${TAG}_inc128.log
 grep "rating window" $OUT/${TAG}_rate1.log
+# cfg5 (depth 4, width 1024, length 512) at 512 streams and the reference's own model size (depth 2, width 128, length 256): per-kernel times
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cfg5_stats -- python3 tools/probe_cfg5.py 512 > $OUT/${TAG}_cfg5.log 2>&1
+cp $OUT/${TAG}_cfg5_stats/*/*_kernel_stats.csv $OUT/${TAG}_cfg5_B512_kernel_stats.csv
+for WB in 1024 4096; do
+  KL_SHAPE="2,128,256,$WB,20" timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_w128_${WB}_stats -- python3 tools/probe_shapes.py shape > $OUT/${TAG}_w128_${WB}.log 2>&1
+  cp $OUT/${TAG}_w128_${WB}_stats/*/*_kernel_stats.csv $OUT/${TAG}_w128_B${WB}_kernel_stats.csv
+done
+grep "cfg5 train" $OUT/${TAG}_cfg5.log
+grep -h "^shape" $OUT/${TAG}_w128_1024.log $OUT/${TAG}_w128_4096.log
