@@ -165,6 +165,9 @@ __device__ __forceinline__ bool sentinel_free(unsigned bits) { return (bits & 0x
 // ... for waves that check many granules: ONE packed instruction per dword -- the running maximum of the two halfword columns
 // (v_pk_max_u16) has a 0xFFFF halfword iff some dword had one in that column; three where sentinel_bits needs thirteen per granule
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
+}
 __device__ __forceinline__ unsigned sentinel_acc(unsigned m, uint4 v) {
   u16x2_t a = __builtin_bit_cast(u16x2_t, m);
   a = __builtin_elementwise_max(a, __builtin_bit_cast(u16x2_t, v.x));

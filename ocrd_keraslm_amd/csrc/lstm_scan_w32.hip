@@ -141,6 +141,7 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_bwd_w32_kernel(const KlScanBw
   const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(Gl, (long)T * BW * 4 * 2);
   const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(Cl, (long)(T + 1) * BW * 4);
   const __amdgpu_buffer_rsrc_t rs_dh = make_rsrc(dH, (long)T * BW * 4);
+  const __amdgpu_buffer_rsrc_t rs_mk = make_rsrc(maskl, maskl ? BW * 4 : 0);
   bool alive = true;
   constexpr bool PREF = MAXRB > 1;
   const bool pref_ok = (B & 15) == 0;
@@ -223,17 +224,25 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_bwd_w32_kernel(const KlScanBw
   // DMA waves: is what landed of half hf free of sentinels?  (16 KiB per wave: the running halfword maximum, two chains)
   auto look_half = [&](int hf, bool one_row) __attribute__((always_inline)) {
     const unsigned char* frag = a_tile + (dq * KSTEPS + hf * KH) * 1024 + lane * 16;
-    unsigned m0 = 0, m1 = 0;
-    if (one_row) {
-      m0 = sentinel_acc(0u, *reinterpret_cast<const uint4*>(frag + (KH - 1) * 1024));
-    } else {
+    if (one_row) return __all(sentinel_acc_free(sentinel_acc(0u, *reinterpret_cast<const uint4*>(frag + (KH - 1) * 1024))));
+    // (eight independent chains: one dependent chain of 64 packed maxima waits out the vector unit's latency 64 times)
+    unsigned m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int j = 0; j < KH; j += 2) {
-        m0 = sentinel_acc(m0, *reinterpret_cast<const uint4*>(frag + j * 1024));
-        m1 = sentinel_acc(m1, *reinterpret_cast<const uint4*>(frag + (j + 1) * 1024));
-      }
+    for (int j = 0; j < KH; j += 8) {
+      uint4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(frag + (j + k) * 1024);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m[k] = pk_max(m[k], v[k].x);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m[k] = pk_max(m[k], v[k].y);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m[k] = pk_max(m[k], v[k].z);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m[k] = pk_max(m[k], v[k].w);
     }
-    return __all(sentinel_acc_free(m0) && sentinel_acc_free(m1));
+    const unsigned all = pk_max(pk_max(pk_max(m[0], m[1]), pk_max(m[2], m[3])), pk_max(pk_max(m[4], m[5]), pk_max(m[6], m[7])));
+    return __all(sentinel_acc_free(all));
   };
   // ... the slow path (nothing requested ahead, or the look found sentinels): fetched again until it is complete.  The wave first
   // probes ONE row (256 workgroups spinning on whole tiles slow the publishes down) and fetches the rest once that one is there.
@@ -278,9 +287,11 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_bwd_w32_kernel(const KlScanBw
       // epilogue inputs of waves 0-3 (raw loads, consumed behind the contraction): the gates as the aligned dwords that hold
       // the lane's two units -- a 16-bit load is zero-extended by an instruction of its own RIGHT BEHIND the load, i.e. a wait
       // at the top of every block (3 000 cycles per block in the first cut, stamps)
-      unsigned g0 = 0, g1 = 0, g2 = 0, g3 = 0;
-      float2 c = float2{0.f, 0.f}, cp = c, dh = c, mkv = float2{1.f, 1.f};
-      if (e_wave) {
+      // (EVERY wave issues them -- the transport waves' copies are never used: loads inside `if (epilogue wave)` are merged with
+      //  the other branch's defaults right behind the loads, i.e. waited for at the top of the block)
+      unsigned g0, g1, g2, g3;
+      float2 c, cp, dh, mkv;
+      {
         // (buffer loads: the block's offset is wave-uniform and travels in a scalar register, the lane's part is two
         //  instructions -- eight 64-bit address computations per block were 1 300 cycles of the epilogue waves' block)
         const unsigned vrow = (unsigned)((erow - r0) * W + u0 + eu);                 // elements inside the block's 16 rows
@@ -292,12 +303,17 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_bwd_w32_kernel(const KlScanBw
         g3 = __builtin_amdgcn_raw_buffer_load_b32(rs_g, (int)(vg + 3 * W * 2), (int)sg, 0);
         // (dword loads: this toolchain's __builtin_amdgcn_raw_buffer_load_b64 comes out as ONE 32-bit load, both elements the same)
         auto ld = [&](__amdgpu_buffer_rsrc_t r, unsigned so, int k) __attribute__((always_inline)) {
-          return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(vrow * 4 + k * 4), (int)so, 0));
+          // (the second unit's dword as a streaming load: two plain neighbours are merged into one 64-bit load whose halves the
+          //  register allocator then copies apart right behind the load -- another wait at the top of the block)
+          return k == 0 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(vrow * 4), (int)so, 0))
+                        : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(vrow * 4 + 4), (int)so, 2));
         };
         c = float2{ld(rs_c, sc + (unsigned)B * W * 4, 0), ld(rs_c, sc + (unsigned)B * W * 4, 1)};
         cp = float2{ld(rs_c, sc, 0), ld(rs_c, sc, 1)};
         dh = float2{ld(rs_dh, sc, 0), ld(rs_dh, sc, 1)};
-        if (maskl) mkv = *reinterpret_cast<const float2*>(maskl + (long)erow * W + u0 + eu);
+        // (the mask unconditionally, from a resource of zero records where there is none: a conditional load is merged with its
+        //  default right behind the load -- a wait for all of the above at the top of every block)
+        mkv = float2{ld(rs_mk, (unsigned)((long)r0 * W * 4), 0), ld(rs_mk, (unsigned)((long)r0 * W * 4), 1)};
       }
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       // the block this workgroup visits next, and whether its tile may be asked for ahead
@@ -335,9 +351,11 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_bwd_w32_kernel(const KlScanBw
           request_half(0, nt, nr0);
           request_half(1, nt, nr0);
           WSTAMP(7);
+          asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // (the first half has landed: looked at while the second lands)
+          const bool there_a = look_half(0, false);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           WSTAMP(8);
-          const bool there = look_half(0, false) && look_half(1, false);
+          const bool there = look_half(1, false) && there_a;
           if (!there) {
             fetch_half(0, nt, nr0);
             fetch_half(1, nt, nr0);
@@ -347,7 +365,7 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_bwd_w32_kernel(const KlScanBw
         }
       } else {
         asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3));
-        const float cc[2] = {c.x, c.y}, cpp[2] = {cp.x, cp.y}, dhh[2] = {dh.x, dh.y}, mk[2] = {mkv.x, mkv.y};
+        const float cc[2] = {c.x, c.y}, cpp[2] = {cp.x, cp.y}, dhh[2] = {dh.x, dh.y}, mk[2] = {maskl ? mkv.x : 1.f, maskl ? mkv.y : 1.f};
         unsigned zz[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
