@@ -170,3 +170,29 @@ __device__ __forceinline__ int wave_min_i(int v) {      // (non-negative values:
   v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x143, 0xC, 0xF, false));
   return __builtin_amdgcn_readlane(v, 63);
 }
+
+// ... the same inside every 16-lane row of the wave (four rows reduced at once): two quad permutations, then the mirrors of the
+// half row and of the row -- after each step the partial result is uniform over twice as many lanes, the last leaves it in all 16
+__device__ __forceinline__ float row16_max(float v) {
+  const float ninf = -INFINITY;
+  v = fmaxf(v, dpp_f<0xB1, 0xF>(ninf, v));
+  v = fmaxf(v, dpp_f<0x4E, 0xF>(ninf, v));
+  v = fmaxf(v, dpp_f<0x141, 0xF>(ninf, v));
+  v = fmaxf(v, dpp_f<0x140, 0xF>(ninf, v));
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0xB1, 0xF>(0.f, v);
+  v += dpp_f<0x4E, 0xF>(0.f, v);
+  v += dpp_f<0x141, 0xF>(0.f, v);
+  v += dpp_f<0x140, 0xF>(0.f, v);
+  return v;
+}
+__device__ __forceinline__ int row16_min_i(int v) {
+  const int big = 0x7fffffff;
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0xB1, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x4E, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x141, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x140, 0xF, 0xF, false));
+  return v;
+}

@@ -564,11 +564,16 @@ struct KlCeW128 {
   int M, B, T, V, Vp, n_wg, last_only;
   float inv_count;
 };
+constexpr int CE_ROWS = 64;
 constexpr int CE_X_LD = 272, CE_Z_LD = 260, CE_G_LD = 528, CE_D_LD = 132;      // bytes / floats / bytes / floats
-constexpr int CE_XT = 0, CE_ZL = CE_XT + 2 * 32 * CE_X_LD, CE_GL = CE_ZL + 32 * CE_Z_LD * 4, CE_LDS = CE_GL + 32 * CE_G_LD;
+constexpr int CE_XT = 0, CE_ZL = CE_XT + 2 * CE_ROWS * CE_X_LD, CE_GL = CE_ZL + CE_ROWS * CE_Z_LD * 4, CE_LDS = CE_GL + CE_ROWS * CE_G_LD;
 
+// 64 rows per tile.  Softmax pass: a wave takes FOUR rows at once, 16 lanes per row and 16 characters per lane (characters
+// 64 k + 4 (l & 15) .. + 3, k = 0 .. 3): the reductions are four DPP steps inside the 16-lane rows and serve four rows each --
+// with a row per pass and wave-wide reductions (the first cut, as logits_ce_ws_kernel) the pass was 150 vector instructions per
+// row, 0.66 ms per window at 4096 streams against 0.17 ms of memory traffic.
 __global__ __launch_bounds__(1024, 1) void logits_ce_w128_kernel(const KlCeW128 a) {
-  constexpr int W = W8, ROWS = 32;
+  constexpr int W = W8, ROWS = CE_ROWS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x;
@@ -595,19 +600,16 @@ __global__ __launch_bounds__(1024, 1) void logits_ce_w128_kernel(const KlCeW128 
   const __amdgpu_buffer_rsrc_t rs_dl = make_rsrc(a.dlogits, (long)a.M * Vp * 2);
   const __amdgpu_buffer_rsrc_t rs_dh = make_rsrc(a.dH, (long)a.M * W * 4);
   const __amdgpu_buffer_rsrc_t rs_rs = make_rsrc(a.rowstat, (long)a.M * 8);
-  // a tile's rows: 32 x 256 bytes = one 16-byte piece for each of the first 512 threads (rows beyond M read as zeros)
+  // a tile's rows: 64 x 256 bytes = one 16-byte piece per thread (rows beyond M read as zeros)
   const int x_row = tid >> 4, x_seg = tid & 15;
   auto fetch = [&](int i) __attribute__((always_inline)) {
-    u32x4 v = u32x4{0u, 0u, 0u, 0u};
-    if (tid < 512) {
-      const long row = (long)(wg + (long)i * a.n_wg) * ROWS + x_row;
-      v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, x_seg * 16, (int)(unsigned)(row * W * 2), 0));
-    }
-    return v;
+    const long row = (long)(wg + (long)i * a.n_wg) * ROWS + x_row;
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, x_seg * 16, (int)(unsigned)(row * W * 2), 0));
   };
   auto put = [&](int buf, u32x4 v) __attribute__((always_inline)) {
-    if (tid < 512) *reinterpret_cast<u32x4*>(smem + CE_XT + (buf * ROWS + x_row) * CE_X_LD + x_seg * 16) = v;
+    *reinterpret_cast<u32x4*>(smem + CE_XT + (buf * ROWS + x_row) * CE_X_LD + x_seg * 16) = v;
   };
+  const int rs4 = lane >> 4, cl = lane & 15;       // softmax pass: row 4 wave + rs4, characters 64 k + 4 cl ..
   u32x4 ra = fetch(0);
   put(0, ra);
   if (my_tiles > 1) ra = fetch(1);
@@ -618,77 +620,83 @@ __global__ __launch_bounds__(1024, 1) void logits_ce_w128_kernel(const KlCeW128 
     __syncthreads();                       // tile i is complete in LDS; every wave has left tile i - 1, its logits and its gradient rows
     if (i + 1 < my_tiles) put(buf ^ 1, ra);
     if (i + 2 < my_tiles) ra = fetch(i + 2);
-    // (the targets of this wave's two rows, asked for before the contraction: the softmax pass would wait a memory round trip for each)
-    int tg[2];
-#pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
-      const long row = row0 + 2 * wave + k2;
-      const long rr = row < a.M ? row : 0;
-      tg[k2] = a.tgt[(rr % a.B) * a.T + rr / a.B];
-    }
-    // ---- logits of 32 rows x this wave's 16 characters
+    // (the target of this lane's row, asked for before the contraction)
+    const int lr = 4 * wave + rs4;
+    const long row = row0 + lr;
+    const bool there = row < a.M;
+    const long rr = there ? row : 0;
+    const int tt = (int)(rr / a.B);
+    int t = a.tgt[(rr - (long)tt * a.B) * a.T + tt];
+    // ---- logits of 64 rows x this wave's 16 characters
     {
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 acc[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
       const unsigned char* tb = smem + CE_XT + (buf * ROWS + (lane & 15)) * CE_X_LD + (lane >> 4) * 16;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 4; ++h)
           acc[h] = mfma16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tb + h * 16 * CE_X_LD + j * 64)), __builtin_bit_cast(bf16x8, bu[j]), acc[h]);
       }
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 4; ++h)
 #pragma unroll
         for (int r = 0; r < 4; ++r) zl[(h * 16 + 4 * (lane >> 4) + r) * CE_Z_LD + 16 * wave + (lane & 15)] = acc[h][r];
     }
     __syncthreads();
-    // ---- rows 2 wave, 2 wave + 1: one row per pass, lane = characters 4 lane .. 4 lane + 3
-#pragma unroll 1
-    for (int k2 = 0; k2 < 2; ++k2) {
-      const int lr = 2 * wave + k2;
-      const long row = row0 + lr;
-      const bool there = row < a.M;
-      const f32x4 z = *reinterpret_cast<const f32x4*>(zl + lr * CE_Z_LD + lane * 4);
-      const int v0 = lane * 4;
-      float e[4];
+    // ---- softmax, cross-entropy and its gradient of rows 4 wave .. 4 wave + 3
+    {
+      float e[16];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) e[k] = v0 + k < V ? z[k] : -INFINITY;      // (characters beyond the vocabulary do not exist)
-      const float mx = wave_max(fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3])));
-      const int first = e[0] == mx ? v0 : e[1] == mx ? v0 + 1 : e[2] == mx ? v0 + 2 : e[3] == mx ? v0 + 3 : 0x7fffffff;
-      const int amax = wave_min_i(first);
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 z = *reinterpret_cast<const f32x4*>(zl + lr * CE_Z_LD + 64 * k + 4 * cl);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[4 * k + j] = 64 * k + 4 * cl + j < V ? z[j] : -INFINITY;      // (characters beyond the vocabulary do not exist)
+      }
+      float mloc = e[0];
+#pragma unroll
+      for (int j = 1; j < 16; ++j) mloc = fmaxf(mloc, e[j]);
+      const float mx = row16_max(mloc);
+      // the first character that reaches the maximum (Keras' argmax)
+      int first = 0x7fffffff;
+#pragma unroll
+      for (int j = 15; j >= 0; --j) first = e[j] == mx ? 64 * (j >> 2) + 4 * cl + (j & 3) : first;
+      const int amax = row16_min_i(first);      // (a lane's characters ascend with j: `first` is its smallest hit)
       float sum = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        e[k] = __expf(e[k] - mx);
-        sum += e[k];
+      for (int j = 0; j < 16; ++j) {
+        e[j] = __expf(e[j] - mx);      // (exp2-based: the arguments are <= 0)
+        sum += e[j];
       }
-      const float inv = 1.f / wave_sum(sum);
-      const int tt = (int)((there ? row : 0) / a.B);
-      int t = k2 == 0 ? tg[0] : tg[1];
+      const float inv = 1.f / row16_sum(sum);
       bool counts = true;
       if (a.last_only && tt != a.T - 1) { t = -1; counts = false; }
-      if (t < -1) { t = -1; counts = false; }
+      if (t < -1) { t = -1; counts = false; }      // (a dummy stream added by the caller's padding: no accuracy either)
+      float ploc = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) e[k] *= inv;
-      float pt = 0.f;
-      if (t >= 0) {
-        const int tl = t >> 2, tk = t & 3;
-        const float cand = tk == 0 ? e[0] : tk == 1 ? e[1] : tk == 2 ? e[2] : e[3];
-        pt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand), tl));
+      for (int j = 0; j < 16; ++j) {
+        e[j] *= inv;
+        ploc = (64 * (j >> 2) + 4 * cl + (j & 3)) == t ? e[j] : ploc;
       }
+      const float pt = row16_sum(ploc);              // (one lane of the row holds the target's probability)
       const bool valid = t >= 0;
       const bool active = there && valid && pt >= 1e-7f && pt <= 1.f - 1e-7f;
-      unsigned short g[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float gk = active ? e[k] : 0.f;
-        if (active && v0 + k == t) gk -= 1.f;
-        g[k] = f2bf(gk * a.inv_count);
+        unsigned short g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float gk = active ? e[4 * k + j] : 0.f;
+          if (active && 64 * k + 4 * cl + j == t) gk -= 1.f;
+          g[j] = f2bf(gk * a.inv_count);
+        }
+        const u32x2 gp = u32x2{(unsigned)g[0] | ((unsigned)g[1] << 16), (unsigned)g[2] | ((unsigned)g[3] << 16)};
+        *reinterpret_cast<u32x2*>(smem + CE_GL + lr * CE_G_LD + (64 * k + 4 * cl) * 2) = gp;
+        // (rows beyond M: out of the buffer's range, dropped; the row differs from lane to lane: all of the address in the vector offset)
+        if (64 * k + 4 * cl < Vp) __builtin_amdgcn_raw_buffer_store_b64(gp, rs_dl, (int)(unsigned)(row * Vp * 2 + (64 * k + 4 * cl) * 2), 0, 0);
       }
-      const u32x2 gp = u32x2{(unsigned)g[0] | ((unsigned)g[1] << 16), (unsigned)g[2] | ((unsigned)g[3] << 16)};
-      *reinterpret_cast<u32x2*>(smem + CE_GL + lr * CE_G_LD + lane * 8) = gp;
-      if (v0 < Vp) __builtin_amdgcn_raw_buffer_store_b64(gp, rs_dl, lane * 8, (int)(unsigned)(row * Vp * 2), 0);      // (rows beyond M: out of the buffer's range, dropped)
-      if (lane == 0) {
+      if (cl == 0) {
         float l = 0.f;
         if (valid) {
           const float pc = fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f);
@@ -696,27 +704,36 @@ __global__ __launch_bounds__(1024, 1) void logits_ce_w128_kernel(const KlCeW128 
         }
         const int tsafe = valid ? t : 0;
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, l), __builtin_bit_cast(unsigned, (counts && amax == tsafe) ? a.inv_count : 0.f)},
-                                              rs_rs, 0, (int)(unsigned)(row * 8), 0);
+                                              rs_rs, (int)(unsigned)(row * 8), 0, 0);
       }
     }
     __syncthreads();
-    // ---- dH of the tile: wave = (row half wave >> 3, 16 units of column tile wave & 7), K = Vp characters
+    // ---- dH of the tile: wave = (16 units of column tile wave & 7, row tiles 2 (wave >> 3) and the next), K = Vp characters
     {
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int h = wave >> 3;
-      const unsigned char* gb = smem + CE_GL + (h * 16 + (lane & 15)) * CE_G_LD + (lane >> 4) * 16;
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      const int h0 = 2 * (wave >> 3);
+      const unsigned char* gb = smem + CE_GL + (h0 * 16 + (lane & 15)) * CE_G_LD + (lane >> 4) * 16;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        if (j < nk) acc = mfma16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(gb + j * 64)), __builtin_bit_cast(bf16x8, be[j]), acc);
+        if (j < nk) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            acc[h] = mfma16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(gb + h * 16 * CE_G_LD + j * 64)), __builtin_bit_cast(bf16x8, be[j]), acc[h]);
+        }
       // (out as whole rows: through the logits' LDS, free since the barrier above)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) zl[(h * 16 + 4 * (lane >> 4) + r) * CE_D_LD + 16 * (wave & 7) + (lane & 15)] = acc[r];
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zl[((h0 + h) * 16 + 4 * (lane >> 4) + r) * CE_D_LD + 16 * (wave & 7) + (lane & 15)] = acc[h][r];
     }
     __syncthreads();
     {
-      const int d_row = tid >> 5, d_seg = tid & 31;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(zl + d_row * CE_D_LD + d_seg * 4);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_dh, (int)(unsigned)(((row0 + d_row) * W + d_seg * 4) * 4), 0, 0);
+      const int d_row = tid >> 4, d_seg = tid & 15;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(zl + d_row * CE_D_LD + (d_seg + 16 * k) * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_dh, (int)(unsigned)(((row0 + d_row) * W + (d_seg + 16 * k) * 4) * 4), 0, 0);
+      }
     }
   }
 }
@@ -839,7 +856,7 @@ int kl_launch_logits_ce_w128(const bf16_t* X, const bf16_t* E, const bf16_t* ET,
   KlCeW128 a;
   a.X = X; a.E = E; a.ET = ET; a.tgt = tgt; a.dlogits = dlogits; a.dH = dH; a.rowstat = rowstat;
   a.M = (int)M; a.B = B; a.T = T; a.V = V; a.Vp = Vp; a.last_only = last_only; a.inv_count = inv_count;
-  const long n_tiles = (M + 31) / 32;
+  const long n_tiles = (M + CE_ROWS - 1) / CE_ROWS;
   a.n_wg = (int)(n_tiles < w128_cus() ? n_tiles : w128_cus());
   static KlLdsGrant grant;
   if (kl_grant_lds(grant, reinterpret_cast<const void*>(&logits_ce_w128_kernel), (size_t)CE_LDS)) return KL_ERR_LAUNCH;
