@@ -638,6 +638,127 @@ __global__ __launch_bounds__(1024, 1) void proj_ws_kernel(const KlProjWs a) {
   }
 }
 
+// The same with EIGHT waves of 32 output columns each (round 4): every A fragment read from LDS feeds TWO MFMAs (column tiles c = 0, 1),
+// so the tile's fragments cross the LDS eight times per tile instead of sixteen -- the 16-wave form above spends 5 000 cycles on a
+// 32-row tile whose MFMAs take 2 048 (16 waves x 32 KiB of ds_read_b128 per tile: LDS-read-bound, as the 16-wave forward scan).
+// Column tile c's column j is output column 32 w + 8 (j >> 2) + 4 c + (j & 3): after the quad transpose a lane holds eight
+// CONSECUTIVE columns of one row over the two tiles -- one 16-byte store, 64 bytes per row and wave.
+// STAGE: the tile's 32 x 512 bytes of output leave through 16 KiB of LDS as whole 512-byte row segments (32 consecutive lanes on one
+// row) instead of 64 bytes per row and wave.
+template <bool STAGE>
+__global__ __launch_bounds__(512, 1) void proj_ws8_kernel(const KlProjWs a) {
+  constexpr int KSTEPS = 16, W = 512, N = 4 * W, NCG = N / 256, ROWS = 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, yy = blockIdx.x >> 3;
+  const int cg = yy % NCG, rq = yy / NCG, rg = xcd * ((a.n_rg + 7) >> 3) + rq;
+  if (rg >= a.n_rg) return;
+  const int c0 = cg * 256;                                  // first output column of this workgroup
+  const int n_tiles_all = a.M / ROWS;
+  const int my_tiles = rg < n_tiles_all ? (n_tiles_all - rg + a.n_rg - 1) / a.n_rg : 0;
+  if (my_tiles == 0) return;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // tile [2][32 rows][1024]
+
+  u32x4 bu[2][KSTEPS];
+  float bias[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int col = c0 + 32 * wave + 8 * ((lane & 15) >> 2) + 4 * c + (lane & 3);
+    const long wrow = (long)col * W + (lane >> 4) * 8;
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j) bu[c][j] = *reinterpret_cast<const u32x4*>(a.KTp + wrow + j * 32);
+    bias[c] = a.bp[col];                                    // (accumulator layout: one column per lane)
+  }
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.X, (long)a.M * W * 2);
+  const __amdgpu_buffer_rsrc_t rs_p = make_rsrc(a.P, (long)a.M * N * 2);
+  // X rows through registers two tiles ahead, laid into the LDS tile by the wave that fetched them: rows w, w + 8, w + 16, w + 24,
+  // chunk c of row r at position c ^ (r & 15) -- the layout the 16-wave form reads
+  const unsigned frag_lane = (unsigned)((lane & 15) * 1024 + (((lane >> 4) ^ (lane & 3)) * 16) + 64 * ((lane >> 2) & 3));
+  unsigned put_lane[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) put_lane[h] = (unsigned)((wave + 8 * h) * 1024 + ((lane ^ ((wave + 8 * h) & 15)) & 63) * 16);
+  const int jr = lane & 3, a4 = (lane >> 2) & 3, q4 = lane >> 4;
+  auto fetch = [&](int i, u32x4 (&r)[4]) __attribute__((always_inline)) {
+    const long row0 = (long)(rg + (long)i * a.n_rg) * ROWS;
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+      r[h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, lane * 16, (int)(unsigned)((row0 + 8 * h + wave) * W * 2), 0));
+  };
+  auto put = [&](int buf, const u32x4 (&r)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) *reinterpret_cast<u32x4*>(smem + buf * ROWS * 1024 + put_lane[h]) = r[h];
+  };
+  u32x4 ra[4], rb[4];      // tile i + 1 and tile i + 2 on their way
+  fetch(0, ra);
+  put(0, ra);
+  if (my_tiles > 1) fetch(1, ra);
+  if (my_tiles > 2) fetch(2, rb);
+  auto one_tile = [&](int i, u32x4 (&r1)[4]) __attribute__((always_inline)) {
+    const int buf = i & 1;
+    __syncthreads();                       // tile i is complete in LDS, and every wave has left tile i - 1
+    if (i + 1 < my_tiles) put(buf ^ 1, r1);
+    if (i + 3 < my_tiles) fetch(i + 3, r1);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) acc[c][h] = f32x4{bias[c], bias[c], bias[c], bias[c]};
+    {
+      const unsigned char* tb = smem + buf * ROWS * 1024;
+      u32x4 fr[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) fr[0][h] = *reinterpret_cast<const u32x4*>(tb + frag_lane + h * 16 * 1024);
+#pragma unroll
+      for (int q = 0; q < KSTEPS; ++q) {
+        if (q + 1 < KSTEPS) {
+          const int q1 = q + 1;
+          const unsigned char* ap = tb + (frag_lane ^ (unsigned)(64 * (q1 >> 2))) + 256 * (q1 & 3);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) fr[q1 & 1][h] = *reinterpret_cast<const u32x4*>(ap + h * 16 * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const bf16x8 fb = __builtin_bit_cast(bf16x8, bu[c][4 * (q & 3) + (q >> 2)]);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) acc[c][h] = mfma16(__builtin_bit_cast(bf16x8, fr[q & 1][h]), fb, acc[c][h]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // out: after the quad transposes lane = (row 4 q4 + jr, columns 32 w + 8 a4 .. + 7): 16 bytes per lane
+    const long row0 = (long)(rg + (long)i * a.n_rg) * ROWS;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 v0 = acc[0][h], v1 = acc[1][h];
+      quad_transpose(v0, jr);
+      quad_transpose(v1, jr);
+      const u32x4 pk = u32x4{(unsigned)f2bf(v0[0]) | ((unsigned)f2bf(v0[1]) << 16), (unsigned)f2bf(v0[2]) | ((unsigned)f2bf(v0[3]) << 16),
+                             (unsigned)f2bf(v1[0]) | ((unsigned)f2bf(v1[1]) << 16), (unsigned)f2bf(v1[2]) | ((unsigned)f2bf(v1[3]) << 16)};
+      if (STAGE) {
+        *reinterpret_cast<u32x4*>(smem + 2 * ROWS * 1024 + (h * 16 + 4 * q4 + jr) * 528 + (32 * wave + 8 * a4) * 2) = pk;
+      } else {
+        const unsigned off = (unsigned)(((h * 16 + 4 * q4 + jr) * N + c0 + 32 * wave + 8 * a4) * 2);
+        __builtin_amdgcn_raw_buffer_store_b128(pk, rs_p, (int)off, (int)(unsigned)(row0 * N * 2), 0);
+      }
+    }
+    if (STAGE) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int row = (tid >> 5) + 16 * k, seg = tid & 31;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + 2 * ROWS * 1024 + row * 528 + seg * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs_p, (int)(unsigned)((row * N + c0 + seg * 8) * 2), (int)(unsigned)(row0 * N * 2), 0);
+      }
+    }
+  };
+  for (int i = 0; i < my_tiles; i += 2) {
+    one_tile(i, ra);
+    if (i + 1 < my_tiles) one_tile(i + 1, rb);
+  }
+}
+
 // (wave_max / wave_sum / wave_min_i: kl_scan2_helpers.h)
 
 // ---------------------------------------------------------------- gradient into the top layer: dH = dlogits . E
@@ -1795,6 +1916,21 @@ int kl_launch_proj_ws(const bf16_t* X, const bf16_t* KTp, const float* bp, bf16_
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return KL_ERR_LAUNCH;
     attr_set = true;
+  }
+  // (eight waves of 32 columns: half the LDS reads per MFMA; KL_PROJ_WS8 = 0: the 16-wave form)
+  static const int eight = [] { const char* e = getenv("KL_PROJ_WS8"); return e ? atoi(e) : 1; }();      // (0: the 16-wave form; 2: with staged stores -- measured equal, 23.73 ms per step both, 23.91 with 16 waves)
+  if (eight == 2) {
+    static KlLdsGrant grant;
+    const size_t lds8 = lds + 32 * 528;
+    if (kl_grant_lds(grant, reinterpret_cast<const void*>(&proj_ws8_kernel<true>), lds8)) return KL_ERR_LAUNCH;
+    hipLaunchKernelGGL(proj_ws8_kernel<true>, dim3(8 * 8 * ((a.n_rg + 7) / 8)), dim3(512), lds8, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
+  }
+  if (eight == 1) {
+    static KlLdsGrant grant;
+    if (kl_grant_lds(grant, reinterpret_cast<const void*>(&proj_ws8_kernel<false>), lds)) return KL_ERR_LAUNCH;
+    hipLaunchKernelGGL(proj_ws8_kernel<false>, dim3(8 * 8 * ((a.n_rg + 7) / 8)), dim3(512), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(proj_ws_kernel, dim3(8 * 8 * ((a.n_rg + 7) / 8)), dim3(1024), lds, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
