@@ -567,8 +567,8 @@ def main():
                 ref_models["width_%d" % Wm] = entry
             except Exception as err:
                 ref_models["width_%d" % Wm] = {"error": repr(err)}
-        ref_models["note"] = ("depth 2, length 256, V=256, 1 context; width 128 = the published model's topology (README.md:252-254); from 512 "
-                              "streams on the one-workgroup-per-row-block scans of lstm_scan_w128.hip; hbm_frac: ~104 W bytes per character and layer")
+        ref_models["note"] = ("depth 2, length 256, V=256, 1 context; width 128 = the published model's topology (README.md:252-254), on the "
+                              "one-workgroup-per-row-block scans of lstm_scan_w128.hip (all layers in one launch up to 2048 streams); hbm_frac: ~104 W bytes per character and layer")
         torch.cuda.empty_cache()
         # cfg2 at stream counts beside the default: 1000 and 4096 streams (the engine pads / regroups such batches around the
         # counts the persistent scans take, HipLM._stream_groups), 2 context variables at the default count

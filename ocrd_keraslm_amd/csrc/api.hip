@@ -155,7 +155,8 @@ struct kl_handle {
   bool w128_tables = true;      // KL_W128_TABLES = 0: layer 0's gate inputs gathered into f32 rows first instead of inside the scan
   bool w128_multi = true;       // KL_W128_MULTI = 0: one launch per layer also where all layers' workgroups fit the CUs at once
   bool w128_fuse = true;        // KL_W128_FUSE = 0: ... with the input side of the layers above the first from products over all steps
-  int w128_min = 512;           // ... from this many streams on (KL_W128_MIN; measured: 512 streams 3.08 against 3.15 ms per step, 256: 2.77 / 2.43)
+  int w128_min = 1;             // ... from this many streams on (KL_W128_MIN; measured against the thin fused scans, ms per step at 1 / 16 / 64 / 128 / 256 streams:
+                                // 1.54 / 1.68 / 1.69 / 1.74 / 1.87 against 1.57 / 1.80 / 1.79 / 1.96 / 2.29)
   bool fwd8 = true;             // KL_FWD8 = 0: the 16-wave forward scan also for the layers above the first (default: the eight-wave scan of
                                 // lstm_scan_fwd8.hip there -- 3.06 against 3.36 ms per launch at 3072 streams)
   bool fwd8_all = false;        // KL_FWD8 = 2: ... also for layer 0 (its gate inputs gathered into P rows first)

@@ -647,7 +647,9 @@ def test_train_window_width_1024_scans(monkeypatch, depth, width, voc, B, T, n_c
     (2, 128, 30, 20, 2, 1, True, {"KL_W128_MIN": "1"}, "multi"),       # two steps: nothing to roll
     (2, 128, 40, 40, 6, 0, True, {"KL_W128_MIN": "1"}, "multi"),       # no context variable: layer 0 from the embedding table alone
     (2, 128, 40, 24, 5, 3, True, {"KL_W128_MIN": "1"}, "multi"),       # three context variables: layer 0's gate inputs gathered into rows first
-    (1, 128, 40, 24, 7, 1, False, {"KL_W128_MIN": "1", "KL_W128_TABLES": "0"}, "single")])   # ... also with one
+    (1, 128, 40, 24, 7, 1, False, {"KL_W128_MIN": "1", "KL_W128_TABLES": "0"}, "single"),    # ... also with one
+    (2, 128, 70, 8, 32, 1, True, {}, "multi"),                         # the default at any stream count since round 4
+    (2, 128, 70, 40, 12, 1, True, {"KL_W128": "0"}, "thin")])          # the thin fused scans (16-unit workgroups exchanging state) stay reachable
 def test_train_window_width_128_scans(monkeypatch, depth, width, voc, B, T, n_ctx, use_masks, env, want):
     """Width 128 (the reference's published model size): the scans of lstm_scan_w128.hip -- a workgroup per 16-row block of
     streams with all hidden units of a layer, no hand-off of state between workgroups; the layers above the first contract
@@ -657,7 +659,8 @@ def test_train_window_width_128_scans(monkeypatch, depth, width, voc, B, T, n_ct
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks,
-                                 want_kernel="lstm_scan_bwd_w128_multi_kernel" if want == "multi" else "lstm_scan_bwd_w128_kernel")
+                                 want_kernel={"multi": "lstm_scan_bwd_w128_multi_kernel", "single": "lstm_scan_bwd_w128_kernel",
+                                              "thin": "lstm_scan_bwd_kernel"}[want])
 
 
 @pytest.mark.parametrize("B,T", [(144, 4), (512, 3)])
