@@ -60,6 +60,8 @@ struct Derived {
   std::vector<bf16_t*> KTp;      // [4W][W], l >= 1
   std::vector<float*> bp;        // [4W], l >= 1 (layer 0's bias is folded into EKp)
   float* EKp = nullptr;          // [V][4W] = EK + b_0
+  bf16_t* comb = nullptr;        // width 512, one context variable: [V * ctx_vocab][W][4] bf16 = EKp[v] + CtxKp_0[c], every gate-input row layer 0 can
+                                 // ask for (200 MiB at V = 256) -- the eight-wave forward scan gathers its rows from it (lstm_scan_fwd8.hip, table mode)
   std::vector<float*> CtxKp;     // [ctx_vocab][W][4] per context variable (the scan's table mode reads that of variable 0)
   unsigned* scan_flags = nullptr;   // lstm_scan_bwd_wide2_kernel's flags + epoch (zeroed once per bind: the numbers only grow)
 };
@@ -160,6 +162,10 @@ struct kl_handle {
   bool fwd8 = true;             // KL_FWD8 = 0: the 16-wave forward scan also for the layers above the first (default: the eight-wave scan of
                                 // lstm_scan_fwd8.hip there -- 3.06 against 3.36 ms per launch at 3072 streams)
   bool fwd8_all = false;        // KL_FWD8 = 2: ... also for layer 0 (its gate inputs gathered into P rows first)
+  bool fwd8_tab = false;        // KL_FWD8_TAB = 1: layer 0 (one context variable) on the eight-wave scan too, its gate-input rows gathered from the
+                                // table of all (character, context value) sums (200 MiB more of derived operands).  Off: measured 3.43 ms per launch
+                                // against 3.53 on the 16-wave scan's table mode, minus 0.06 ms for the table -- with 200 context values in a batch the
+                                // gathers leave the L2 that the two small tables stay in
   bool fwd8_ls = true;          // KL_FWD8_LS = 0: the counter form of the eight-wave forward scan instead of the two-barrier form
   bool fwd8_local = true;       // KL_FWD8_LOCAL = 0: write-through publishes in the eight-wave forward scan even where its partners share an XCD
   int fwd8_pf = -1;             // KL_FWD8_PF = 0..3: where it requests its tiles (default by phases per step)
@@ -288,6 +294,9 @@ size_t carve_derived(const kl_handle* h, void* base, Derived* d) {
   o.CtxKp.assign(c.n_ctx, nullptr);
   for (int n = 0; n < c.n_ctx; ++n) o.CtxKp[n] = cv.take<float>((size_t)c.ctx_vocab * 4 * W);
   o.scan_flags = cv.take<unsigned>(KL_SCAN_FLAGS + 64);      // hand-off flags of the backward scan [256 row blocks][64] + the epoch word
+  o.comb = nullptr;
+  if (h->fwd8_tab && W == 512 && c.n_ctx == 1 && V * (size_t)c.ctx_vocab * 4 * W * sizeof(bf16_t) <= ((size_t)512 << 20))
+    o.comb = cv.take<bf16_t>(V * (size_t)c.ctx_vocab * 4 * W);
   return align_up(cv.off, 256);
 }
 
@@ -424,6 +433,8 @@ int prepare_impl(kl_handle* h, int precision, hipStream_t s) {
     }
     KL_TRY(kl_launch_permute_gate_cols_f32(d.EK, P + h->off_b[0], d.EKp, V, W, s));
     for (int n = 0; n < c.n_ctx; ++n) KL_TRY(kl_launch_permute_gate_cols_f32(d.CtxK[n], nullptr, d.CtxKp[n], c.ctx_vocab, W, s));
+    // (every gate-input row of layer 0, for the eight-wave forward scan's table mode: 200 MiB written per update, ~0.06 ms)
+    if (d.comb && h->fwd8 && h->fwd8_tab) KL_TRY(kl_launch_comb_table(d.EKp, d.CtxKp[0], V, c.ctx_vocab, 4 * W, d.comb, s));
   }
   h->precision = precision;
   h->inc_ready = false;      // the incremental step's own operands are rebuilt on their first use (prepare_incremental,
@@ -536,8 +547,11 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
       // the eight-wave scan (lstm_scan_fwd8.hip) takes bf16 P rows only: layer 0's gate inputs are gathered in front of it
       // (layer 0 with one context variable stays on the 16-wave scan's table mode: gathering its P rows first costs more --
       //  1.25 ms at 3072 streams -- than the eight-wave scan saves; KL_FWD8=2 takes it for layer 0 as well)
+      // (layer 0 with one context variable: the eight-wave scan gathers its rows from the table of all sums -- d.comb)
+      const bool f8_tab = v2 && l == 0 && h->fwd8 && h->fwd8_tab && !h->fwd8_all && d.comb != nullptr && c.n_ctx == 1 && w.scan2_rows == 32 &&
+                          h->scan2_bf16 && h->sentinel_roll && T >= 3 && h->fwd8_ls;
       const bool f8 = v2 && h->fwd8 && w.scan2_rows == 32 && h->scan2_bf16 && h->sentinel_roll && T >= 3 &&
-                      (l > 0 || c.n_ctx > 1 || h->fwd8_all);
+                      (l > 0 || c.n_ctx > 1 || h->fwd8_all || f8_tab);
       if (l > 0) {
         const bool masked_in = masks != nullptr && (l - 1) > 0;
         const bf16_t* X = masked_in ? w.Hd[l - 1] : (const bf16_t*)w.H[l - 1] + BW;
@@ -552,6 +566,12 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
         KL_TRY(pe);
         a.P = w.P1;
         a.p_bf16 = v2 && h->scan2_bf16 ? 1 : 0;
+      } else if (f8_tab) {
+        KL_TRY(kl_launch_rows_tm(idx, ctx, c.n_ctx, B, T, c.ctx_vocab, w.ids_tm, s));
+        a.P = reinterpret_cast<const float*>(d.comb);
+        a.p_bf16 = 1;
+        a.ids_tm = w.ids_tm;      // (here: row numbers of d.comb, [T][B])
+        a.V = c.voc_size; a.ctx_vocab = c.ctx_vocab;
       } else if (v2 && (c.n_ctx > 1 || f8)) {
         // several context variables: the scan's table mode adds ONE context row to the character row, so the gate inputs
         // of layer 0 are gathered into P rows first (as the layers above get them from proj_ws_kernel)
@@ -603,6 +623,14 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
         const int e8 = kl_launch_scan_fwd8(a8, s, h->fwd8_ls);
         if (e8 != KL_ERR_SHAPE) KL_TRY(e8);
         took8 = e8 == 0;
+      }
+      if (!took8 && f8_tab) {      // (the eight-wave scan did not take the shape: the 16-wave scan's own table mode)
+        KL_TRY(kl_launch_ids_tm(idx, ctx, c.n_ctx, B, T, W, c.voc_size, c.ctx_vocab, w.ids_tm, s));
+        a.P = nullptr; a.p_bf16 = 0;
+        a.EK = d.EKp;
+        a.CtxK[0] = d.CtxKp[0];
+        a.n_ctx = c.n_ctx;
+        a.ids_tm = w.ids_tm;
       }
       if (took8) {}
       else if (v2) KL_TRY(kl_launch_scan_fwd_wide2(a, w.scan2_rows, s));
@@ -1116,6 +1144,8 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   if (env8mm) h->w128_multi = atoi(env8mm) != 0;
   const char* env8q = getenv("KL_W128_MIN");
   if (env8q) h->w128_min = atoi(env8q);
+  const char* env8tb = getenv("KL_FWD8_TAB");
+  if (env8tb) h->fwd8_tab = atoi(env8tb) != 0;
   const char* env8m = getenv("KL_FWD8");
   if (env8m) { h->fwd8 = atoi(env8m) != 0; h->fwd8_all = atoi(env8m) == 2; }
   const char* env8r = getenv("KL_FWD8_LS");

@@ -515,6 +515,43 @@ int kl_launch_f32_to_bf16_jobs(const KlConvJob* jobs, int n, hipStream_t stream)
   return ok();
 }
 
+// ---- table of all sums of a row of A and a row of B, bf16 (8 elements per thread) ----
+__global__ void comb_table_kernel(const float* __restrict__ A, const float* __restrict__ B, int R2, int N8, bf16_t* __restrict__ out, long total) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e % N8);
+    const long row = e / N8;
+    const int c = (int)(row % R2), v = (int)(row / R2);
+    const float4* pa = reinterpret_cast<const float4*>(A + ((long)v * N8 + j) * 8);
+    const float4* pb = reinterpret_cast<const float4*>(B + ((long)c * N8 + j) * 8);
+    const float4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+    uint4 o;
+    o.x = (unsigned)f2bf(a0.x + b0.x) | ((unsigned)f2bf(a0.y + b0.y) << 16);
+    o.y = (unsigned)f2bf(a0.z + b0.z) | ((unsigned)f2bf(a0.w + b0.w) << 16);
+    o.z = (unsigned)f2bf(a1.x + b1.x) | ((unsigned)f2bf(a1.y + b1.y) << 16);
+    o.w = (unsigned)f2bf(a1.z + b1.z) | ((unsigned)f2bf(a1.w + b1.w) << 16);
+    reinterpret_cast<uint4*>(out)[e] = o;
+  }
+}
+__global__ void rows_tm_kernel(const int* __restrict__ idx, const int* __restrict__ ctx, int n_ctx, int Bn, int T, int R2, int* __restrict__ out) {
+  const long total = (long)Bn * T;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(e % Bn), t = (int)(e / Bn);
+    const long src = (long)b * T + t;
+    out[e] = idx[src] * R2 + (n_ctx > 0 ? ctx[src * n_ctx] : 0);
+  }
+}
+
+int kl_launch_comb_table(const float* A, const float* B, int R1, int R2, int N, bf16_t* out, hipStream_t stream) {
+  if ((N & 7) || R1 < 1 || R2 < 1) return KL_ERR_SHAPE;
+  const long total = (long)R1 * R2 * (N / 8);
+  hipLaunchKernelGGL(comb_table_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, A, B, R2, N / 8, out, total);
+  return ok();
+}
+int kl_launch_rows_tm(const int* idx, const int* ctx, int n_ctx, int Bn, int T, int R2, int* out, hipStream_t stream) {
+  hipLaunchKernelGGL(rows_tm_kernel, dim3(grid_for((long)Bn * T, 256)), dim3(256), 0, stream, idx, ctx, n_ctx, Bn, T, R2, out);
+  return ok();
+}
+
 int kl_launch_softmax_ce(float* logits, long ld, int rows, int V, const int* tgt, int B, int T, float inv_count,
                          bf16_t* dlogits, long ld_dl, float* loss_acc, float* rowstat, int time_major,
                          hipStream_t stream, int last_only) {

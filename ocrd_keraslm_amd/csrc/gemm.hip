@@ -752,14 +752,9 @@ int launch_long_t(int out_mode, dim3 grid, hipStream_t stream, const bf16_t* A, 
   static const int remap = !(getenv("KL_GEMM_XCD") && getenv("KL_GEMM_XCD")[0] == '0');
 #define KL_LONG_CASE(O)                                                                                                  \
   do {                                                                                                                   \
-    static bool attr_set = false;                                                                                        \
-    if (!attr_set) {                                                                                                     \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<O, true, RF, WM, WN>),                      \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH; \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<O, false, RF, WM, WN>),                     \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH; \
-      attr_set = true;                                                                                                   \
-    }                                                                                                                    \
+    static KlLdsGrant grant_a, grant_b;      /* (per device: kl_kernels.h) */                                            \
+    if (kl_grant_lds(grant_a, reinterpret_cast<const void*>(&gemm_tn_long_kernel<O, true, RF, WM, WN>), lds)) return KL_ERR_LAUNCH;  \
+    if (kl_grant_lds(grant_b, reinterpret_cast<const void*>(&gemm_tn_long_kernel<O, false, RF, WM, WN>), lds)) return KL_ERR_LAUNCH; \
     if (ilv) hipLaunchKernelGGL((gemm_tn_long_kernel<O, true, RF, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, A, B, C,  \
                                 bias, M, N, K, lda, ldb, ldc, k_per_split, alpha, epi, remap, 0, KlGemmSecond{});                        \
     else hipLaunchKernelGGL((gemm_tn_long_kernel<O, false, RF, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, A, B, C,     \
@@ -820,12 +815,8 @@ int kl_launch_gemm_tn(const bf16_t* A, const bf16_t* B, void* C, const float* bi
     }
     const int tiles_n = (N + LBN - 1) / LBN, total = ((M + LBM - 1) / LBM) * tiles_n;
     const size_t lds = (size_t)LSTAGES * (LBM + LBN) * 128 + (bias ? (size_t)N * 4 : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_pers_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((size_t)LSTAGES * (LBM + LBN) * 128 + 2048 * 4)) != hipSuccess) return KL_ERR_LAUNCH;
-      attr_set = true;
-    }
+    static KlLdsGrant grant;
+    if (kl_grant_lds(grant, reinterpret_cast<const void*>(&gemm_tn_pers_kernel), (size_t)LSTAGES * (LBM + LBN) * 128 + 2048 * 4)) return KL_ERR_LAUNCH;
     hipLaunchKernelGGL(gemm_tn_pers_kernel, dim3(n_wg), dim3(512), lds, stream, A, B, (float*)C, bias, M, N, K, lda, ldb, ldc,
                        alpha, tiles_n, total, out_mode == 1 ? 1 : 0);
     return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
@@ -918,14 +909,9 @@ int kl_launch_gemm_an2(const bf16_t* A_km, const bf16_t* B, float* C, int M, int
   }
   const size_t lds = (size_t)LSTAGES * (LBM + LBN) * 128;
   static const int remap = !(getenv("KL_GEMM_XCD") && getenv("KL_GEMM_XCD")[0] == '0');
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<2, true, 4, 4, 2, true, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_long_kernel<2, true, 4, 4, 2, true, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KL_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static KlLdsGrant grant_a, grant_b;
+  if (kl_grant_lds(grant_a, reinterpret_cast<const void*>(&gemm_tn_long_kernel<2, true, 4, 4, 2, true, false>), lds)) return KL_ERR_LAUNCH;
+  if (kl_grant_lds(grant_b, reinterpret_cast<const void*>(&gemm_tn_long_kernel<2, true, 4, 4, 2, true, true>), lds)) return KL_ERR_LAUNCH;
   if (b_km)
     hipLaunchKernelGGL((gemm_tn_long_kernel<2, true, 4, 4, 2, true, true>), grid, dim3(512), lds, stream, A_km, B, (void*)C,
                        (const float*)nullptr, M, N, K, lda_km, ldb, ldc, kps, 1.f, epi, remap, c_transposed, second);

@@ -283,6 +283,10 @@ struct KlConvJob {
 };
 struct KlConvJobs { KlConvJob job[KL_CONV_MAX_JOBS]; };
 int kl_launch_f32_to_bf16_jobs(const KlConvJob* jobs, int n, hipStream_t stream);
+// out[(v * R2 + c)][j] = bf16(A[v][j] + B[c][j]) for all pairs of rows (N a multiple of 8): the table of every gate-input row of layer 0
+int kl_launch_comb_table(const float* A, const float* B, int R1, int R2, int N, bf16_t* out, hipStream_t stream);
+// rows_tm[t * Bn + b] = idx[b][t] * R2 + ctx[b][t][0]: the rows of that table a window asks for, time-major
+int kl_launch_rows_tm(const int* idx, const int* ctx, int n_ctx, int Bn, int T, int R2, int* out, hipStream_t stream);
 int kl_launch_f32_to_bf16_t(const float* in, long ld_in, int rows, int cols, bf16_t* out_hi, bf16_t* out_lo,
                             long ld_out, int transpose, hipStream_t stream);
 int kl_launch_softmax_ce(float* logits, long ld, int rows, int V, const int* tgt, int B, int T, float inv_count,

@@ -1911,12 +1911,6 @@ int kl_launch_proj_ws(const bf16_t* X, const bf16_t* KTp, const float* bp, bf16_
   KlProjWs a;
   a.X = X; a.KTp = KTp; a.bp = bp; a.P = P; a.M = (int)M; a.n_rg = 32; a.status = status;
   const size_t lds = (size_t)2 * 32 * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return KL_ERR_LAUNCH;
-    attr_set = true;
-  }
   // (eight waves of 32 columns: half the LDS reads per MFMA; KL_PROJ_WS8 = 0: the 16-wave form)
   static const int eight = [] { const char* e = getenv("KL_PROJ_WS8"); return e ? atoi(e) : 1; }();      // (0: the 16-wave form; 2: with staged stores -- measured equal, 23.73 ms per step both, 23.91 with 16 waves)
   if (eight == 2) {
@@ -1932,6 +1926,8 @@ int kl_launch_proj_ws(const bf16_t* X, const bf16_t* KTp, const float* bp, bf16_
     hipLaunchKernelGGL(proj_ws8_kernel<false>, dim3(8 * 8 * ((a.n_rg + 7) / 8)), dim3(512), lds, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
   }
+  static KlLdsGrant grant16;
+  if (kl_grant_lds(grant16, reinterpret_cast<const void*>(&proj_ws_kernel), lds)) return KL_ERR_LAUNCH;
   hipLaunchKernelGGL(proj_ws_kernel, dim3(8 * 8 * ((a.n_rg + 7) / 8)), dim3(1024), lds, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
@@ -1946,12 +1942,8 @@ int kl_launch_logits_ce_ws(const bf16_t* X, const bf16_t* E, const int* tgt, bf1
   a.X = X; a.E = E; a.tgt = tgt; a.dlogits = dlogits; a.rowstat = rowstat;
   a.M = (int)M; a.B = B; a.T = T; a.n_rg = 256; a.last_only = last_only; a.inv_count = inv_count;
   const size_t lds = (size_t)2 * 32 * 1024 + 32 * (256 + 4) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&logits_ce_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return KL_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static KlLdsGrant grant;
+  if (kl_grant_lds(grant, reinterpret_cast<const void*>(&logits_ce_ws_kernel), lds)) return KL_ERR_LAUNCH;
   hipLaunchKernelGGL(logits_ce_ws_kernel, dim3(a.n_rg), dim3(1024), lds, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }

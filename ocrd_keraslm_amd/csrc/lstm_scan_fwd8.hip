@@ -44,8 +44,9 @@ namespace {
 constexpr int F8_RING = 3;
 constexpr int F8_ST_LD = 144;       // bytes per row of a staging tile (128 + 16: the quads' writes fall on distinct banks)
 constexpr int F8_ST_TILE = 32 * F8_ST_LD, F8_ST_BUF = 3 * F8_ST_TILE;      // h (published) | c | masked h of one phase
-// LDS map (bytes): tile [3][32][1024] | zin [8 waves][2][1024] | staging [3 phases][3 tiles][32][144] | counters [16]
-constexpr int F8_TILE = 0, F8_ZIN = F8_RING * 32 * 1024, F8_ST = F8_ZIN + 8 * 2 * 1024, F8_CTR = F8_ST + F8_RING * F8_ST_BUF, F8_LDS = F8_CTR + 64;
+// LDS map (bytes): tile [3][32][1024] | zin [8 waves][2][1024] | staging [3 phases][3 tiles][32][144] | counters [16] | row numbers [8 waves][4][32]
+constexpr int F8_TILE = 0, F8_ZIN = F8_RING * 32 * 1024, F8_ST = F8_ZIN + 8 * 2 * 1024, F8_CTR = F8_ST + F8_RING * F8_ST_BUF, F8_IDS = F8_CTR + 64,
+              F8_LDS = F8_IDS + 8 * 4 * 128;      // (table mode: the row numbers of four phases per wave, 32 x 4 bytes each)
 // counters (words): [0, 3) released, [3] ok flag, [4, 7) landed, [8, 11) arrived at the publish, [11] XCD-local verdict
 
 // one LDS word, re-read on every call (as asm with the LDS byte address: a volatile access through a generic pointer becomes a
@@ -246,7 +247,40 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_fwd8_kernel(const KlScanFwdW
 #pragma unroll
     for (int s = 0; s < 2; ++s) arm16e(const_cast<unsigned char*>(my_zin) + s * 1024 + lane * 16);
   };
-  auto request_zin = [&](int t, int r0) __attribute__((always_inline)) {
+  // TABLE MODE (layer 0, a.ids_tm != null): a.P is the table of ALL gate-input rows layer 0 can ask for -- row v * ctx_vocab + c =
+  // EK[v] + CtxK[c] + bias, bf16, laid out like a P row -- and a.ids_tm [T][B] the row number of every position.  The 32 row
+  // numbers of a phase come into LDS by a 128-byte LDS-DMA three phases ahead (armed, polled like every landing zone here: nothing
+  // waits on vmcnt), each lane then asks for its row's 64 bytes of this wave's units.  (A gather kernel writing P rows first costs
+  // 1.25 ms per window at 3072 streams; the table is 200 MiB, rebuilt in 0.06 ms after every update.)
+  const bool tab = a.ids_tm != nullptr;
+  const __amdgpu_buffer_rsrc_t rs_ids = make_rsrc(a.ids_tm, tab ? (long)T * B * 4 : 0);
+  const __amdgpu_buffer_rsrc_t rs_comb = make_rsrc(a.P, tab ? (long)a.V * a.ctx_vocab * 4 * W * 2 : 0);
+  unsigned char* const my_ids = smem + F8_IDS + wave * 512;
+  const unsigned lds_ids = lds_base + (unsigned)(F8_IDS + wave * 512);
+  const unsigned z_piece = (unsigned)(uw * 4 * 2 + (lane & 3) * 16);
+  auto arm_ids = [&](int slot) __attribute__((always_inline)) {
+    if (lane < 32) *reinterpret_cast<unsigned*>(my_ids + slot * 128 + lane * 4) = F8_ARMED;
+  };
+  auto request_ids = [&](int slot, int t, int r0) __attribute__((always_inline)) {
+    if (lane < 32) glds4_plain_s(rs_ids, (unsigned)(lane * 4), (unsigned)(((long)t * B + r0) * 4), lds_ids + (unsigned)(slot * 128));
+  };
+  auto request_zin = [&](int t, int r0, int slot) __attribute__((always_inline)) {
+    if (tab) {
+      unsigned id[2] = {0u, 0u};
+      bool ok = false;
+      for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 2; ++s) id[s] = *reinterpret_cast<const unsigned*>(my_ids + slot * 128 + (s * 16 + (lane >> 2)) * 4);
+        if (!__any(id[0] == F8_ARMED || id[1] == F8_ARMED)) { ok = true; break; }
+        if ((spin & 255) == 255 && ctr_now(3) == 0) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!ok) { F8_GIVE_UP(); alive = false; return; }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) glds16_plain(rs_comb, id[s] * (unsigned)(4 * W * 2) + z_piece, lds_zin + (unsigned)(s * 1024));
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const __amdgpu_buffer_rsrc_t rs_p = make_rsrc(reinterpret_cast<const bf16_t*>(a.P) + ((long)t * B + r0 + s * 16) * 4 * W, (long)16 * 4 * W * 2);
@@ -283,7 +317,16 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_fwd8_kernel(const KlScanFwdW
     t = m / NP;
     r0 = (rg + (m - t * NP) * n_rg) * ROWS;
   };
-  // ---- prologue: the tiles of the first `ahead` phases, the gate inputs of the first
+  // ---- prologue: (table mode) the row numbers of the first three phases; the tiles of the first `ahead` phases, the gate inputs of the first
+  if (tab) {
+    for (int m = 0; m < 3 && m < n_phases; ++m) arm_ids(m);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int m = 0; m < 3 && m < n_phases; ++m) {
+      int t, r0;
+      phase_tr(m, t, r0);
+      request_ids(m, t, r0);
+    }
+  }
   for (int m = 0; m < ahead && m < n_phases; ++m) {
     int t, r0;
     phase_tr(m, t, r0);
@@ -291,7 +334,7 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_fwd8_kernel(const KlScanFwdW
     if (m == 0) arm_zin();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     request_tile(t, r0, m % F8_RING);
-    if (m == 0) request_zin(0, rg * ROWS);
+    if (m == 0) request_zin(0, rg * ROWS, 0);
   }
 
   bool mine = false;      // this wave's rows of the phase at hand have been seen valid (and counted) already
@@ -405,9 +448,16 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_fwd8_kernel(const KlScanFwdW
           arm_tile(bufa);
         }
         if (have_next) arm_zin();
+        const bool ids_next = tab && n + 3 < n_phases;      // (slot (n + 3) & 3 held phase n - 1's numbers, used a phase ago)
+        if (ids_next) arm_ids((n + 3) & 3);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(zi[0]), "+v"(zi[1])::"memory");
         if (ask_tile && alive) request_tile(ta, ra, bufa);
-        if (have_next) request_zin(t1, r1);
+        if (have_next && alive) request_zin(t1, r1, (n + 1) & 3);
+        if (ids_next && alive) {
+          int t3, r3;
+          phase_tr(n + 3, t3, r3);
+          request_ids((n + 3) & 3, t3, r3);
+        }
       }
       SSTAMP(3);
       // ---- epilogue on the accumulators: after the quad transpose lane = (row, unit pair), registers = gates
@@ -548,6 +598,7 @@ extern "C" int kl_test_fwd8_stamps(unsigned long long* out, int reset) {
 // KL_ERR_SHAPE = not applicable (the caller takes lstm_scan_fwd_wide2_kernel)
 int kl_launch_scan_fwd8(KlScanFwdWide a, hipStream_t stream, bool lockstep) {
   if (a.W != 512 || !a.P || !a.p_bf16 || a.sentinel != 2 || a.HT || a.HdT || !a.G || !a.H || !a.C) return KL_ERR_SHAPE;
+  if (a.ids_tm && (a.V < 1 || a.ctx_vocab < 1 || (long)a.V * a.ctx_vocab * 4 * a.W * 2 > 0xfffffff0L)) return KL_ERR_SHAPE;      // (table mode: a.P = the table of all rows)
   const int np = kl_scan_wide2_phases(a.B, a.T, a.W, 32, 4);
   if (np < 2) return KL_ERR_SHAPE;
   a.n_rb = a.B / 32;

@@ -719,8 +719,8 @@ bool kl_scan_w32_applicable(int B, int T, int W) {
 #define KL_W32_LAUNCH(KERNEL, RB, LDS0)                                                                              \
   do {                                                                                                               \
     const size_t lds = (size_t)(LDS0) + (size_t)((RB) > 1 ? (RB) : 0) * NT * sizeof(float);                          \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL<32, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            (int)lds) != hipSuccess) return KL_ERR_LAUNCH;                                           \
+    static KlLdsGrant grant;      /* (one per instantiation and launcher; per device: kl_kernels.h) */               \
+    if (kl_grant_lds(grant, reinterpret_cast<const void*>(&KERNEL<32, RB>), lds)) return KL_ERR_LAUNCH;                \
     hipLaunchKernelGGL((KERNEL<32, RB>), grid, block, lds, stream, a);                                               \
   } while (0)
 

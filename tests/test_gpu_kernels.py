@@ -600,6 +600,21 @@ def test_train_window_fwd8(monkeypatch, depth, width, voc, B, T, n_ctx, use_mask
     check_train_window_gradients(depth, width, voc, B, T, n_ctx, use_masks, want_kernel=want)
 
 
+@pytest.mark.parametrize("depth,B,T,use_masks,env", [
+    (1, 3072, 6, False, {}),                                   # one layer: the traced launch IS layer 0's -- three phases per step
+    (2, 3072, 9, True, {}),                                    # the ring of row numbers goes round twice
+    (2, 2048, 5, True, {"KL_SCAN2_ROWS": "32"}),               # two phases per step
+    (3, 3072, 3, True, {})])                                   # a window as short as the look-ahead of the row numbers
+def test_train_window_fwd8_table_mode(monkeypatch, depth, B, T, use_masks, env):
+    """Layer 0 on the eight-wave forward scan (round 4, KL_FWD8_TAB=1): its gate-input rows are gathered from the table of ALL (character,
+    context value) sums, the row numbers of a phase brought into LDS three phases ahead -- gradients, loss and carried state
+    against the f64 oracle with 200 context values in play."""
+    monkeypatch.setenv("KL_FWD8_TAB", "1")      # (opt-in: on the bench's batches it gains 0.03 ms per step, DESIGN.md section 10)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    check_train_window_gradients(depth, 512, 64, B, T, 1, use_masks, want_kernel="lstm_scan_fwd8_kernel")
+
+
 @pytest.mark.parametrize("depth,width,voc,B,T,n_ctx,ctx_values,want", [
     (2, 512, 20, 3072, 4, 2, 3, "lstm_scan_fwd_wide2_kernel"),      # 12288 positions onto 20 characters / 3 values per context
     (2, 512, 20, 1024, 5, 1, 2, "lstm_scan_fwd_wide2_kernel"),
