@@ -68,11 +68,18 @@ __device__ unsigned long long kl_w32_stamps[32];
     __syncthreads();                                                                          \
     if (blockIdx.x == 0 && threadIdx.x < 32 && wstamp_lds[threadIdx.x]) atomicAdd(&kl_w32_stamps[threadIdx.x], wstamp_lds[threadIdx.x]); \
   } while (0)
+__device__ unsigned long long kl_w32f_stamps[32];      // ... the same for the forward scan
+#define FSTAMP_FLUSH()                                                                        \
+  do {                                                                                        \
+    __syncthreads();                                                                          \
+    if (blockIdx.x == 0 && threadIdx.x < 32 && wstamp_lds[threadIdx.x]) atomicAdd(&kl_w32f_stamps[threadIdx.x], wstamp_lds[threadIdx.x]); \
+  } while (0)
 #else
 #define WSTAMP(i)
 #define WCOUNT(i)
 #define WSTAMP_INIT()
 #define WSTAMP_FLUSH()
+#define FSTAMP_FLUSH()
 #endif
 
 constexpr int UN = 32;         // hidden units per workgroup
@@ -459,17 +466,26 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
 #pragma unroll
     for (int j = 0; j < KQ; ++j) bu[g][j] = *reinterpret_cast<const uint4*>(a.UT[0] + wrow + j * 32);
   }
-  const int er = tid >> 5, eu = tid & 31;
+  // Roles (round 4, as the backward scan): waves 4-7 bring the tiles in and check them -- nothing else but the contraction --,
+  // waves 0-3 run the epilogue (two cells per lane: row 4 wave + (lane >> 4), units 2 (lane & 15) and the next) and store what they
+  // computed themselves from 2 KiB of staging per wave: two workgroup barriers per block instead of three.
+  const bool e_wave = wave < 4;
+  const int er = 4 * (wave & 3) + (lane >> 4), eu = 2 * (lane & 15);
   const float* maskl = a.mask[0];
   const float* P = a.P1;
   unsigned* status = a.status;
-  float c_one = 0.f;
+  float c_one[2] = {0.f, 0.f};
   for (int i = 0; i < MAXRB; ++i) {
     const int rb = rg + i * n_rg;
     const int row = min(rb * 16 + er, B - 1);
-    const float c0 = (rb < n_rb) ? a.C[0][(long)row * W + u0 + eu] : 0.f;
-    if (MAXRB > 1) c_slot[i * NT] = c0;
-    else c_one = c0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float c0 = (rb < n_rb) ? a.C[0][(long)row * W + u0 + eu + k] : 0.f;
+      if (e_wave) {
+        if (MAXRB > 1) c_slot[i * NT + k * 256] = c0;      // (an epilogue lane's two cells: slots tid and tid + 256)
+        else c_one[k] = c0;
+      }
+    }
   }
   const long BW = (long)B * W;
   const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(a.H[0], (long)(T + 1) * BW * 2);
@@ -492,7 +508,7 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
   // behind that request, so that a DMA wave's queue reads [tile n+1][inputs n+1] and the counted wait for the tile
   // (at most n_raw younger loads outstanding) is exact -- the compiler's own wait for the inputs, one block later,
   // finds them long arrived.
-  int cur = 0, pf_issued = 0;
+  int cur = 0;
   // (whole row blocks: the lane's part of the eight requests' addresses -- rows 2 j + (l >> 5), 2 KiB apart, piece (l & 31) ^ row)
   unsigned swz[8];
 #pragma unroll
@@ -539,78 +555,86 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
       }
     }
   };
-  // the first block's inputs
-  float zn0, zn1, zn2, zn3, mkn;
-  {
-    const int erow = min(rg * 16 + er, B - 1);
-    const float* p = P + (long)erow * 4 * W + u0 + eu;
-    zn0 = p[0]; zn1 = p[W]; zn2 = p[2 * W]; zn3 = p[3 * W];
-    mkn = maskl ? maskl[(long)erow * W + u0 + eu] : 1.f;
-  }
+  // ---- tile of a block: complete and free of sentinels?  (this wave's 8 KiB)
+  auto look_tile = [&](int buf, int bt) __attribute__((always_inline)) {
+    const unsigned char* frag = a_tile + buf * (KSTEPS * 1024) + (dq * KQ) * 1024 + lane * 16;
+    unsigned m[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < KQ; j += 4) {
+      uint4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const uint4*>(frag + (j + k) * 1024);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = sentinel_acc(m[k], v[k]);
+    }
+    return __all(bt == 0 || sentinel_acc_free(pk_max(pk_max(m[0], m[1]), pk_max(m[2], m[3]))));      // (block 0 is the carried-in state: never armed)
+  };
+  // ... fetched now (nothing requested ahead, or the look found sentinels): again until it is complete
+  auto fetch_tile = [&](int buf, int bt, int br0) __attribute__((always_inline)) {
+    bool ok = false;
+    if (alive) {
+      for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
+        request_tile(buf, bt, br0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (look_tile(buf, bt)) { ok = true; break; }
+        if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (!ok) {
+        __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok_flag = 0;
+      }
+    }
+    if (!ok) {
+      unsigned char* frag = a_tile + buf * (KSTEPS * 1024) + (dq * KQ) * 1024 + lane * 16;
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) *reinterpret_cast<uint4*>(frag + j * 1024) = uint4{0, 0, 0, 0};
+    }
+  };
+  // epilogue inputs of a block (waves 0-3 use them; every wave issues the loads: inside `if (epilogue wave)` they would be merged
+  // with the other branch's defaults right behind the loads, i.e. waited for at once): gate inputs of the lane's two units, keep-mask
+  struct Inputs { float2 z[4]; float2 mk; };
+  const __amdgpu_buffer_rsrc_t rs_mk = make_rsrc(maskl, maskl ? (long)B * W * 4 : 0);
+  auto load_inputs = [&](int bt, int br0) __attribute__((always_inline)) {
+    Inputs v;
+    const int erow = min(br0 + er, B - 1);
+    const float* p = P + ((long)bt * B + erow) * 4 * W + u0 + eu;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) v.z[g] = *reinterpret_cast<const float2*>(p + g * W);
+    // (the mask unconditionally, from a resource of zero records where there is none)
+    const unsigned vm = (unsigned)(((long)erow * W + u0 + eu) * 4);
+    v.mk = float2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_mk, (int)vm, 0, 0)),
+                  __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_mk, (int)(vm + 4), 0, 2))};
+    return v;
+  };
+  Inputs nxt = load_inputs(0, rg * 16);      // the first block's
+  int pf = 0;                                // this block's tile was requested and checked during the block before
+  unsigned char* const stage = reinterpret_cast<unsigned char*>(pub) + (wave & 3) * 2048;      // waves 0-3: h | masked h | gates | c of their four rows
 
+  WSTAMP_INIT();
   for (int t = 0; t < T; ++t) {
 #pragma unroll 1
     for (int i = 0; i < MAXRB; ++i) {
+      WSTAMP(0);
       const int rb = rg + i * n_rg;
       if (rb >= n_rb) continue;
       const int r0 = rb * 16;
-      float za0 = zn0, za1 = zn1, za2 = zn2, za3 = zn3, mk = mkn;
+      const Inputs in = nxt;
       unsigned char* tile = a_tile + cur * (KSTEPS * 1024);
-      if (dma_wave) {
-        // k-steps dq*KQ.. of the 16 x W tile of h[t-1] (block t; block 0 is the carried-in state: never armed)
-        unsigned char* frag = tile + (dq * KQ) * 1024 + lane * 16;
-        bool ok = false;
-        if (alive) {
-          bool issued = PREF && pf_issued;
-          for (unsigned spin = 0; spin < SPIN_LIMIT; ++spin) {
-            if (issued) {      // (at most the epilogue inputs are younger; the count as a constant)
-              if (maskl) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-              else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-              request_tile(cur, t, r0);
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            unsigned bits = 0;
-#pragma unroll
-            for (int j = 0; j < KQ; ++j) bits = sentinel_acc(bits, *reinterpret_cast<const uint4*>(frag + j * 1024));
-            if (__all(t == 0 || sentinel_acc_free(bits))) { ok = true; break; }
-            issued = false;
-            if ((spin & 63) == 63 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-            __builtin_amdgcn_s_sleep(2);
-          }
-          if (!ok) {
-            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok_flag = 0;
-          }
-        }
-        if (!ok) {
-#pragma unroll
-          for (int j = 0; j < KQ; ++j) *reinterpret_cast<uint4*>(frag + j * 1024) = uint4{0, 0, 0, 0};
-        }
-      }
-      __syncthreads();
+      if (dma_wave && !pf) fetch_tile(cur, t, r0);      // k-steps dq*KQ.. of the 16 x W tile of h[t-1] (block t)
+      WSTAMP(1);
+      __syncthreads();                // the tile is there and checked; the partial sums and the other buffer are free
       alive = ok_flag != 0;
-      // (this block's inputs were loaded a block ago: the wait the compiler puts here is free, and it keeps that wait in
-      //  front of the requests below)
-      asm volatile("" : "+v"(za0), "+v"(za1), "+v"(za2), "+v"(za3), "+v"(mk));
-      {
-        // the block this workgroup visits next: its tile (with several blocks per workgroup it was published at least
-        // a block ago; with one, it is being published right now: polled at its top) and its inputs
-        int ni = i + 1, nt = t;
-        if (ni >= MAXRB || rg + ni * n_rg >= n_rb) { ni = 0; nt = t + 1; }
-        const int nr0 = (rg + ni * n_rg) * 16;
-        pf_issued = 0;
-        if (PREF && dma_wave && pref_ok && alive && nt < T) {
-          request_tile(cur ^ 1, nt, nr0);
-          pf_issued = 1;
-        }
-        if (nt < T) {
-          const int nrow = min(nr0 + er, B - 1);
-          const float* p = P + ((long)nt * B + nrow) * 4 * W + u0 + eu;
-          zn0 = p[0]; zn1 = p[W]; zn2 = p[2 * W]; zn3 = p[3 * W];
-          mkn = maskl ? maskl[(long)nrow * W + u0 + eu] : 1.f;
-        }
-      }
+      WSTAMP(2);
+      // the block this workgroup visits next: its tile (with several blocks per workgroup it was published at least a block ago;
+      // with one, it is being published right now: fetched at its top) and its inputs
+      int ni = i + 1, nt = t;
+      if (ni >= MAXRB || rg + ni * n_rg >= n_rb) { ni = 0; nt = t + 1; }
+      const int nr0 = (rg + ni * n_rg) * 16;
+      const bool ahead = PREF && pref_ok && alive && nt < T;
+      // (waves 0-3 only; the others keep what they have -- nothing to merge, nothing to wait for)
+      if (e_wave && nt < T) nxt = load_inputs(nt, nr0);
+      WSTAMP(3);
       f32x4 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -630,57 +654,79 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
 #pragma unroll
         for (int r = 0; r < 4; ++r) zt[wave][g][(lane >> 4) * 4 + r][lane & 15] = acc[g][r];
       cur ^= 1;
-      __syncthreads();
-      const int wz = (eu >> 4) * 4, ec = eu & 15;
-      const float z0 = za0 + zt[wz][0][er][ec] + zt[wz + 1][0][er][ec] + zt[wz + 2][0][er][ec] + zt[wz + 3][0][er][ec];
-      const float z1 = za1 + zt[wz][1][er][ec] + zt[wz + 1][1][er][ec] + zt[wz + 2][1][er][ec] + zt[wz + 3][1][er][ec];
-      const float z2 = za2 + zt[wz][2][er][ec] + zt[wz + 1][2][er][ec] + zt[wz + 2][2][er][ec] + zt[wz + 3][2][er][ec];
-      const float z3 = za3 + zt[wz][3][er][ec] + zt[wz + 1][3][er][ec] + zt[wz + 2][3][er][ec] + zt[wz + 3][3][er][ec];
-      const float gi = fast_sigmoid(z0), gf = fast_sigmoid(z1), gg = fast_tanh(z2), go = fast_sigmoid(z3);
-      const float cprev = MAXRB > 1 ? c_slot[i * NT] : c_one;
-      const float c = gf * cprev + gi * gg;
-      if (MAXRB > 1) c_slot[i * NT] = c;
-      else c_one = c;
-      const float h = go * fast_tanh(c);
-      pub[er * UN + eu] = f2bf(h);
-      st_hd[er * UN + eu] = f2bf(h * mk);
-      st_g[(0 * 16 + er) * UN + eu] = f2bf(gi);
-      st_g[(1 * 16 + er) * UN + eu] = f2bf(gf);
-      st_g[(2 * 16 + er) * UN + eu] = f2bf(gg);
-      st_g[(3 * 16 + er) * UN + eu] = f2bf(go);
-      st_c[er * UN + eu] = c;
-      __syncthreads();
-      // waves 0-3 store: the publish of h first (write-through, or plain inside one XCD), then what only later launches read
-      if (wave < 4 && alive) {
-        if (tid < 64) {
-          const int prow = tid >> 2, seg = tid & 3;
-          if (r0 + prow < B) {
-            const uint4 v = *reinterpret_cast<const uint4*>(pub + prow * UN + seg * 8);
-            const unsigned off = (unsigned)((((long)(t + 1) * B + r0 + prow) * W + u0 + seg * 8) * 2);
-            if (local) store16(rs_h, off, 0u, v);
-            else store16_sc1(rs_h, off, v);
+      WSTAMP(4);
+      __syncthreads();                // the partial sums are there
+      WSTAMP(5);
+      pf = 0;
+      if (dma_wave) {
+        if (ahead) {                  // the next block's tile: requested, landed, checked -- under the epilogue of waves 0-3; this wave's
+          request_tile(cur, nt, nr0);       // queue holds nothing else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          pf = look_tile(cur, nt) ? 1 : 0;
+        }
+        WSTAMP(6);
+      } else {
+        float hv[2], hdv[2], cv[2];
+        unsigned gz[4] = {0u, 0u, 0u, 0u};
+        const float zin[2][4] = {{in.z[0].x, in.z[1].x, in.z[2].x, in.z[3].x}, {in.z[0].y, in.z[1].y, in.z[2].y, in.z[3].y}};
+        const float mkk[2] = {maskl ? in.mk.x : 1.f, maskl ? in.mk.y : 1.f};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int u = eu + k, wz = (u >> 4) * 4, ec = u & 15;
+          float z[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) z[g] = zin[k][g] + zt[wz][g][er][ec] + zt[wz + 1][g][er][ec] + zt[wz + 2][g][er][ec] + zt[wz + 3][g][er][ec];
+          const float gi = fast_sigmoid(z[0]), gf = fast_sigmoid(z[1]), gg = fast_tanh(z[2]), go = fast_sigmoid(z[3]);
+          const float cprev = MAXRB > 1 ? c_slot[i * NT + k * 256] : c_one[k];
+          const float c = gf * cprev + gi * gg;
+          if (MAXRB > 1) c_slot[i * NT + k * 256] = c;
+          else c_one[k] = c;
+          const float h = go * fast_tanh(c);
+          hv[k] = h; hdv[k] = h * mkk[k]; cv[k] = c;
+          gz[0] |= (unsigned)f2bf(gi) << (16 * k); gz[1] |= (unsigned)f2bf(gf) << (16 * k);
+          gz[2] |= (unsigned)f2bf(gg) << (16 * k); gz[3] |= (unsigned)f2bf(go) << (16 * k);
+        }
+        // staging of this wave's four rows: h [4][64 B] | masked h [4][64 B] | gates [4 rows][4 gates][64 B] | c [4][128 B]
+        const int rl = lane >> 4, ul = lane & 15;
+        *reinterpret_cast<unsigned*>(stage + rl * 64 + ul * 4) = (unsigned)f2bf(hv[0]) | ((unsigned)f2bf(hv[1]) << 16);
+        *reinterpret_cast<unsigned*>(stage + 256 + rl * 64 + ul * 4) = (unsigned)f2bf(hdv[0]) | ((unsigned)f2bf(hdv[1]) << 16);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<unsigned*>(stage + 512 + (rl * 4 + g) * 64 + ul * 4) = gz[g];
+        *reinterpret_cast<float2*>(stage + 1536 + rl * 128 + ul * 8) = float2{cv[0], cv[1]};
+        WSTAMP(6);
+        // stores: the publish of h first (write-through, or plain inside one XCD), then what only later launches read (same wave
+        // wrote the staging: ordered by the LDS counter)
+        if (alive) {
+          const int srow = 4 * wave;      // (waves 0-3)
+          if (lane < 16) {
+            const int prow = srow + (lane >> 2), seg = lane & 3;
+            if (r0 + prow < B) {
+              const uint4 v = *reinterpret_cast<const uint4*>(stage + lane * 16);
+              const unsigned off = (unsigned)((((long)(t + 1) * B + r0 + prow) * W + u0 + seg * 8) * 2);
+              if (local) store16(rs_h, off, 0u, v);
+              else store16_sc1(rs_h, off, v);
+            }
+          } else if (lane < 32) {
+            const int q = lane - 16, prow = srow + (q >> 2), seg = q & 3;
+            if (r0 + prow < B)
+              store16(rs_hd, (unsigned)((((long)t * B + r0 + prow) * W + u0 + seg * 8) * 2), 0u, *reinterpret_cast<const uint4*>(stage + 256 + q * 16));
+          } else {
+            const int q = lane - 32, prow = srow + (q >> 3), seg = q & 7;
+            if (r0 + prow < B)
+              store16(rs_c, (unsigned)((((long)(t + 1) * B + r0 + prow) * W + u0 + seg * 4) * 4), 0u, *reinterpret_cast<const uint4*>(stage + 1536 + q * 16));
+          }
+          {
+            const int prow = srow + (lane >> 4), g = (lane >> 2) & 3, seg = lane & 3;
+            if (r0 + prow < B)
+              store16(rs_g, (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2), 0u,
+                      *reinterpret_cast<const uint4*>(stage + 512 + lane * 16));
           }
         }
-        {
-          const int g = tid >> 6, prow = (tid >> 2) & 15, seg = tid & 3;
-          if (r0 + prow < B)
-            store16(rs_g, (unsigned)((((long)t * B + r0 + prow) * 4 * W + (long)g * W + u0 + seg * 8) * 2), 0u,
-                    *reinterpret_cast<const uint4*>(st_g + (g * 16 + prow) * UN + seg * 8));
-        }
-        if (tid >= 64 && tid < 192) {
-          const int q = tid - 64, prow = q >> 3, seg = q & 7;
-          if (r0 + prow < B)
-            store16(rs_c, (unsigned)((((long)(t + 1) * B + r0 + prow) * W + u0 + seg * 4) * 4), 0u,
-                    *reinterpret_cast<const uint4*>(st_c + prow * UN + seg * 4));
-        } else if (tid >= 192) {
-          const int q = tid - 192, prow = q >> 2, seg = q & 3;
-          if (r0 + prow < B)
-            store16(rs_hd, (unsigned)((((long)t * B + r0 + prow) * W + u0 + seg * 8) * 2), 0u,
-                    *reinterpret_cast<const uint4*>(st_hd + prow * UN + seg * 8));
-        }
+        WSTAMP(7);
       }
     }
   }
+  FSTAMP_FLUSH();
 }
 
 int w32_cus() {
@@ -749,6 +795,13 @@ int kl_launch_scan_fwd_w32(KlScanFwd a, hipStream_t stream) {
 }
 
 #ifdef KL_STAMP
+extern "C" int kl_test_w32f_stamps(unsigned long long* out, int reset) {
+  if (reset) {
+    unsigned long long zeros[32] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(kl_w32f_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : KL_ERR_LAUNCH;
+  }
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(kl_w32f_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : KL_ERR_LAUNCH;
+}
 extern "C" int kl_test_w32_stamps(unsigned long long* out, int reset) {
   if (reset) {
     unsigned long long zeros[32] = {0};

@@ -43,3 +43,15 @@ print(f"B={B}: width-1024 backward scan; cycles per block of workgroup 0 (clock6
 for k in range(10):
     print(f"  {names[k]:40s} {st[k] / blocks:9.0f} {st[16 + k] / blocks:9.0f}")
 print(f"  {'total':40s} {st[:14].sum() / blocks:9.0f} {st[16:30].sum() / blocks:9.0f}")
+
+# ---- the forward scan
+lib.kl_test_w32f_stamps.restype = C.c_int
+st = (C.c_ulonglong * 32)()
+lib.kl_test_w32f_stamps(st, 0)
+st = np.array(list(st), dtype=np.float64) / (1.0 + 2.0 / n)      # (the two warm-up windows counted too: never reset for this array)
+fnames = ['(stores +) loop top', 'tile fetched now (nothing requested ahead)', 'barrier: tile there', 'next tile requested (4-7), next inputs asked for',
+          'contraction + partial sums to LDS', 'barrier: partial sums', 'epilogue + staging (0-3) / next tile landed and checked (4-7)', 'stores (0-3)']
+print(f"B={B}: width-1024 forward scan; cycles per block of workgroup 0: wave 0 / wave 4")
+for k in range(8):
+    print(f"  {fnames[k]:40s} {st[k] / blocks:9.0f} {st[16 + k] / blocks:9.0f}")
+print(f"  {'total':40s} {st[:8].sum() / blocks:9.0f} {st[16:24].sum() / blocks:9.0f}")
