@@ -457,6 +457,9 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
   int* flags = reinterpret_cast<int*>(st_c + 16 * UN);
   int& ok_flag = flags[0];
   float* c_slot = reinterpret_cast<float*>(smem + KL_W32_FWD_LDS(KSTEPS)) + tid;                 // [MAXRB][512]
+  constexpr int IN_RING = MAXRB >= 8 ? 2 : 3;      // (buffers of gate inputs; three where the LDS has room: asked for TWO blocks ahead)
+  unsigned char* inp = smem + KL_W32_FWD_LDS(KSTEPS) + (MAXRB > 1 ? MAXRB : 0) * NT * 4;         // [IN_RING][16 rows][4 gates][32 units] f32: gate inputs
+  float* mkl = reinterpret_cast<float*>(inp + IN_RING * 8192);                                        // [MAXRB][16 rows][32 units] keep-masks of this workgroup's row blocks
 
   const int kq = (lane >> 4) * 8;
   uint4 bu[4][KQ];
@@ -591,24 +594,52 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
       for (int j = 0; j < KQ; ++j) *reinterpret_cast<uint4*>(frag + j * 1024) = uint4{0, 0, 0, 0};
     }
   };
-  // epilogue inputs of a block (waves 0-3 use them; every wave issues the loads: inside `if (epilogue wave)` they would be merged
-  // with the other branch's defaults right behind the loads, i.e. waited for at once): gate inputs of the lane's two units, keep-mask
-  struct Inputs { float2 z[4]; float2 mk; };
-  const __amdgpu_buffer_rsrc_t rs_mk = make_rsrc(maskl, maskl ? (long)B * W * 4 : 0);
-  auto load_inputs = [&](int bt, int br0) __attribute__((always_inline)) {
-    Inputs v;
-    const int erow = min(br0 + er, B - 1);
-    const float* p = P + ((long)bt * B + erow) * 4 * W + u0 + eu;
+  // Epilogue inputs through LDS (round 4): the gate inputs P1 of a block -- 16 rows x 4 gates x 128 bytes -- come with its tile, two
+  // requests per transport wave (a request = 8 segments of 128 bytes: 2 rows x 4 gates) -- TWO blocks ahead where the LDS has room
+  // for three buffers (they come from HBM: a block's time is not enough) --, and the keep-masks of this workgroup's row blocks
+  // are read once.  The epilogue waves then issue NO loads at all: their queues hold stores only, and nothing in their
+  // loop waits on vmcnt -- a wave that loads AND stores can only wait for everything (vmcnt is not in order across the two), i.e.
+  // for the write-through publish of the block before, ~3 us.
+  unsigned vin[2];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) v.z[g] = *reinterpret_cast<const float2*>(p + g * W);
-    // (the mask unconditionally, from a resource of zero records where there is none)
-    const unsigned vm = (unsigned)(((long)erow * W + u0 + eu) * 4);
-    v.mk = float2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_mk, (int)vm, 0, 0)),
-                  __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_mk, (int)(vm + 4), 0, 2))};
-    return v;
+  for (int j = 0; j < 2; ++j) {
+    const int seg = (dq * 2 + j) * 8 + (lane >> 3);      // segment = (row, gate)
+    vin[j] = (unsigned)(((seg >> 2) * 4 * W + (seg & 3) * W + u0) * 4 + (lane & 7) * 16);
+  }
+  const unsigned lds_inp = (unsigned)(size_t)(lds_void_t*)inp;
+  auto request_inputs = [&](int buf, int bt, int br0) __attribute__((always_inline)) {
+    const int rows = min(16, B - br0);
+    const __amdgpu_buffer_rsrc_t rs_p = make_rsrc(P + ((long)bt * B + br0) * 4 * W, (long)rows * 4 * W * 4);      // (rows beyond the batch: zeros)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16_plain(rs_p, vin[j], __builtin_amdgcn_readfirstlane(lds_inp + buf * 8192 + (dq * 2 + j) * 1024));
   };
-  Inputs nxt = load_inputs(0, rg * 16);      // the first block's
+  for (int i = 0; i < MAXRB; ++i) {      // keep-masks (1 where there is no mask)
+    const int rb = rg + i * n_rg;
+    const int row = min(rb * 16 + (tid >> 5), B - 1);
+    mkl[i * 512 + tid] = (maskl && rb < n_rb) ? maskl[(long)row * W + u0 + (tid & 31)] : 1.f;
+  }
   int pf = 0;                                // this block's tile was requested and checked during the block before
+  // blocks of this workgroup in the order it visits them: block m = (step m / nvalid, row block rg + (m % nvalid) n_rg)
+  int nvalid = 0;
+  for (int i = 0; i < MAXRB; ++i) nvalid += (rg + i * n_rg < n_rb) ? 1 : 0;
+  const int n_blocks = T * nvalid;
+  auto block_tr = [&](int m, int& bt, int& br0) __attribute__((always_inline)) {
+    bt = m / nvalid;
+    br0 = (rg + (m - bt * nvalid) * n_rg) * 16;
+  };
+  int nb = 0;                                // index of the block at hand
+  int in_req = -1;                           // the gate inputs of blocks 0 .. in_req have been asked for (transport waves)
+  auto inputs_upto = [&](int m) __attribute__((always_inline)) {      // returns how many blocks' inputs it asked for
+    int n_new = 0;
+    while (in_req < m && in_req + 1 < n_blocks) {
+      ++in_req;
+      int bt, br0;
+      block_tr(in_req, bt, br0);
+      request_inputs(in_req % IN_RING, bt, br0);
+      ++n_new;
+    }
+    return n_new;
+  };
   unsigned char* const stage = reinterpret_cast<unsigned char*>(pub) + (wave & 3) * 2048;      // waves 0-3: h | masked h | gates | c of their four rows
 
   WSTAMP_INIT();
@@ -619,9 +650,13 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
       const int rb = rg + i * n_rg;
       if (rb >= n_rb) continue;
       const int r0 = rb * 16;
-      const Inputs in = nxt;
       unsigned char* tile = a_tile + cur * (KSTEPS * 1024);
-      if (dma_wave && !pf) fetch_tile(cur, t, r0);      // k-steps dq*KQ.. of the 16 x W tile of h[t-1] (block t)
+      const unsigned char* inb = inp + (nb % IN_RING) * 8192;
+      if (dma_wave && !pf) {          // k-steps dq*KQ.. of the 16 x W tile of h[t-1] (block t), and the gate inputs of this block and the next
+        // (two buffers: only this block's -- the other one is still being read by the epilogue of the block before)
+        if (alive) inputs_upto(IN_RING >= 3 ? nb + 1 : nb);
+        fetch_tile(cur, t, r0);       // (waits for everything this wave has asked for)
+      }
       WSTAMP(1);
       __syncthreads();                // the tile is there and checked; the partial sums and the other buffer are free
       alive = ok_flag != 0;
@@ -632,8 +667,6 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
       if (ni >= MAXRB || rg + ni * n_rg >= n_rb) { ni = 0; nt = t + 1; }
       const int nr0 = (rg + ni * n_rg) * 16;
       const bool ahead = PREF && pref_ok && alive && nt < T;
-      // (waves 0-3 only; the others keep what they have -- nothing to merge, nothing to wait for)
-      if (e_wave && nt < T) nxt = load_inputs(nt, nr0);
       WSTAMP(3);
       f32x4 acc[4];
 #pragma unroll
@@ -660,16 +693,25 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
       pf = 0;
       if (dma_wave) {
         if (ahead) {                  // the next block's tile: requested, landed, checked -- under the epilogue of waves 0-3; this wave's
-          request_tile(cur, nt, nr0);       // queue holds nothing else
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          inputs_upto(nb + 1);              // queue holds loads only, in order: [inputs of the next block, normally asked for a block ago]
+          request_tile(cur, nt, nr0);       // [its tile] [the inputs of the block after, two requests]
+          const int later = IN_RING >= 3 ? inputs_upto(nb + 2) : 0;
+          if (later == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           pf = look_tile(cur, nt) ? 1 : 0;
         }
         WSTAMP(6);
       } else {
         float hv[2], hdv[2], cv[2];
         unsigned gz[4] = {0u, 0u, 0u, 0u};
-        const float zin[2][4] = {{in.z[0].x, in.z[1].x, in.z[2].x, in.z[3].x}, {in.z[0].y, in.z[1].y, in.z[2].y, in.z[3].y}};
-        const float mkk[2] = {maskl ? in.mk.x : 1.f, maskl ? in.mk.y : 1.f};
+        float zin[2][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float2 zz = *reinterpret_cast<const float2*>(inb + (er * 4 + g) * 128 + eu * 4);
+          zin[0][g] = zz.x; zin[1][g] = zz.y;
+        }
+        const float2 mk2 = *reinterpret_cast<const float2*>(mkl + i * 512 + er * 32 + eu);
+        const float mkk[2] = {mk2.x, mk2.y};
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const int u = eu + k, wz = (u >> 4) * 4, ec = u & 15;
@@ -724,6 +766,7 @@ __global__ __launch_bounds__(NT, 1) void lstm_scan_fwd_w32_kernel(const KlScanFw
         }
         WSTAMP(7);
       }
+      ++nb;
     }
   }
   FSTAMP_FLUSH();
@@ -762,9 +805,9 @@ bool kl_scan_w32_applicable(int B, int T, int W) {
   return w32_plan(B, T, W, &n_rb, &n_rg, &per_wg);
 }
 
-#define KL_W32_LAUNCH(KERNEL, RB, LDS0)                                                                              \
+#define KL_W32_LAUNCH(KERNEL, RB, LDS0, EXTRA0, EXTRA_RB)                                                                              \
   do {                                                                                                               \
-    const size_t lds = (size_t)(LDS0) + (size_t)((RB) > 1 ? (RB) : 0) * NT * sizeof(float);                          \
+    const size_t lds = (size_t)(LDS0) + (size_t)((RB) > 1 ? (RB) : 0) * NT * sizeof(float) + (size_t)(EXTRA0) + (size_t)(EXTRA_RB) * (RB);   \
     static KlLdsGrant grant;      /* (one per instantiation and launcher; per device: kl_kernels.h) */               \
     if (kl_grant_lds(grant, reinterpret_cast<const void*>(&KERNEL<32, RB>), lds)) return KL_ERR_LAUNCH;                \
     hipLaunchKernelGGL((KERNEL<32, RB>), grid, block, lds, stream, a);                                               \
@@ -775,10 +818,10 @@ int kl_launch_scan_bwd_w32(KlScanBwd a, hipStream_t stream) {
   int per_wg = 0;
   if (a.L != 1 || a.sentinel != 1 || !w32_plan(a.B, a.T, a.W, &a.n_rb, &a.n_rg, &per_wg)) return KL_ERR_SHAPE;
   dim3 grid(8 * (a.W / UN) * ((a.n_rg + 7) / 8)), block(NT);
-  if (per_wg == 1) KL_W32_LAUNCH(lstm_scan_bwd_w32_kernel, 1, KL_W32_BWD_LDS(32));
-  else if (per_wg == 2) KL_W32_LAUNCH(lstm_scan_bwd_w32_kernel, 2, KL_W32_BWD_LDS(32));
-  else if (per_wg <= 4) KL_W32_LAUNCH(lstm_scan_bwd_w32_kernel, 4, KL_W32_BWD_LDS(32));
-  else KL_W32_LAUNCH(lstm_scan_bwd_w32_kernel, 8, KL_W32_BWD_LDS(32));
+  if (per_wg == 1) KL_W32_LAUNCH(lstm_scan_bwd_w32_kernel, 1, KL_W32_BWD_LDS(32), 0, 0);
+  else if (per_wg == 2) KL_W32_LAUNCH(lstm_scan_bwd_w32_kernel, 2, KL_W32_BWD_LDS(32), 0, 0);
+  else if (per_wg <= 4) KL_W32_LAUNCH(lstm_scan_bwd_w32_kernel, 4, KL_W32_BWD_LDS(32), 0, 0);
+  else KL_W32_LAUNCH(lstm_scan_bwd_w32_kernel, 8, KL_W32_BWD_LDS(32), 0, 0);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 
@@ -787,10 +830,10 @@ int kl_launch_scan_fwd_w32(KlScanFwd a, hipStream_t stream) {
   int per_wg = 0;
   if (a.L != 1 || a.sentinel != 1 || !a.P1 || !w32_plan(a.B, a.T, a.W, &a.n_rb, &a.n_rg, &per_wg)) return KL_ERR_SHAPE;
   dim3 grid(8 * (a.W / UN) * ((a.n_rg + 7) / 8)), block(NT);
-  if (per_wg == 1) KL_W32_LAUNCH(lstm_scan_fwd_w32_kernel, 1, KL_W32_FWD_LDS(32));
-  else if (per_wg == 2) KL_W32_LAUNCH(lstm_scan_fwd_w32_kernel, 2, KL_W32_FWD_LDS(32));
-  else if (per_wg <= 4) KL_W32_LAUNCH(lstm_scan_fwd_w32_kernel, 4, KL_W32_FWD_LDS(32));
-  else KL_W32_LAUNCH(lstm_scan_fwd_w32_kernel, 8, KL_W32_FWD_LDS(32));
+  if (per_wg == 1) KL_W32_LAUNCH(lstm_scan_fwd_w32_kernel, 1, KL_W32_FWD_LDS(32), 3 * 8192, 2048);
+  else if (per_wg == 2) KL_W32_LAUNCH(lstm_scan_fwd_w32_kernel, 2, KL_W32_FWD_LDS(32), 3 * 8192, 2048);
+  else if (per_wg <= 4) KL_W32_LAUNCH(lstm_scan_fwd_w32_kernel, 4, KL_W32_FWD_LDS(32), 3 * 8192, 2048);
+  else KL_W32_LAUNCH(lstm_scan_fwd_w32_kernel, 8, KL_W32_FWD_LDS(32), 2 * 8192, 2048);
   return hipGetLastError() == hipSuccess ? 0 : KL_ERR_LAUNCH;
 }
 
