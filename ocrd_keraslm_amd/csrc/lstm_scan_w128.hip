@@ -134,15 +134,19 @@ __device__ __forceinline__ void fwd_w128_body(const KlScanFwdWide& a, const int 
     for (int n = 0; n < NCX; ++n) v.cx[n] = NC > 0 ? a.ctx[(g_src + t) * NC + n] : 0;
     return v;
   };
-  auto g_load = [&](const Ids& ids, int k) __attribute__((always_inline)) {
+  // (the character row's and the context rows' pieces stay apart until they are laid into LDS: summed where they are loaded,
+  //  the sum is a wait for the loads right behind them -- the whole round trip to L2 at the top of every step)
+  auto g_load = [&](const Ids& ids, int k, float4& ek, float4 (&ck)[NCX]) __attribute__((always_inline)) {
     const int seg = (tid & 31) + 32 * k;
-    float4 v = *reinterpret_cast<const float4*>(a.EK + (long)ids.id * 4 * W + seg * 4);
+    ek = *reinterpret_cast<const float4*>(a.EK + (long)ids.id * 4 * W + seg * 4);
+#pragma unroll
+    for (int n = 0; n < NCX; ++n)
+      ck[n] = n < NC ? *reinterpret_cast<const float4*>(a.CtxK[n] + (long)ids.cx[n] * 4 * W + seg * 4) : float4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto g_sum = [&](float4 v, const float4 (&ck)[NCX]) __attribute__((always_inline)) {
 #pragma unroll
     for (int n = 0; n < NCX; ++n) {
-      if (n < NC) {
-        const float4 q = *reinterpret_cast<const float4*>(a.CtxK[n] + (long)ids.cx[n] * 4 * W + seg * 4);
-        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-      }
+      if (n < NC) { v.x += ck[n].x; v.y += ck[n].y; v.z += ck[n].z; v.w += ck[n].w; }
     }
     return v;
   };
@@ -185,7 +189,11 @@ __device__ __forceinline__ void fwd_w128_body(const KlScanFwdWide& a, const int 
     const Ids i0 = ids_load(0);
     ids_nx = ids_load(min(1, T - 1));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) p_put(0, k, g_load(i0, k));
+    for (int k = 0; k < 4; ++k) {
+      float4 ek, ck[NCX];
+      g_load(i0, k, ek, ck);
+      p_put(0, k, g_sum(ek, ck));
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < 4; ++k) p_put(0, k, p_load(0, k));
@@ -197,13 +205,14 @@ __device__ __forceinline__ void fwd_w128_body(const KlScanFwdWide& a, const int 
     // the gate inputs of the next step are on their way while this one computes (two steps ahead measured the same: the step
     // is bound by its ~350 vector instructions per wave -- 4 cells per lane, 10 transcendentals each --, not by the loads)
     float4 pn[KIN ? 1 : 4];
+    float4 pc[GIN ? 4 : 1][NCX];      // (table mode: the context rows' pieces of the next step)
     uint4 xn = uint4{0u, 0u, 0u, 0u};
     if (t + 1 < T) {
       if (KIN) {
         xn = x_load(t + 1);
       } else if (GIN) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pn[k] = g_load(ids_nx, k);
+        for (int k = 0; k < 4; ++k) g_load(ids_nx, k, pn[k], pc[k]);
         ids_nx = ids_load(min(t + 2, T - 1));
       } else {
 #pragma unroll
@@ -267,7 +276,7 @@ __device__ __forceinline__ void fwd_w128_body(const KlScanFwdWide& a, const int 
         x_put(p ^ 1, x_await(t + 1, xn));
       } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) p_put(p ^ 1, k, pn[k]);
+        for (int k = 0; k < 4; ++k) p_put(p ^ 1, k, GIN ? g_sum(pn[k], pc[GIN ? k : 0]) : pn[k]);
       }
     }
     __syncthreads();
