@@ -1047,6 +1047,9 @@ kl_handle* kl_create(const kl_config* cfg) {
   kl_handle* h = new kl_handle();
   h->cfg = *cfg;
   layout(h);
+  // (read HERE, not with the other switches in kl_bind: it decides how large the derived workspace is -- kl_derived_bytes)
+  const char* env8tb = getenv("KL_FWD8_TAB");
+  if (env8tb) h->fwd8_tab = atoi(env8tb) != 0;
   return h;
 }
 
@@ -1144,8 +1147,6 @@ int kl_bind(kl_handle* h, float* params, void* derived, size_t derived_bytes) {
   if (env8mm) h->w128_multi = atoi(env8mm) != 0;
   const char* env8q = getenv("KL_W128_MIN");
   if (env8q) h->w128_min = atoi(env8q);
-  const char* env8tb = getenv("KL_FWD8_TAB");
-  if (env8tb) h->fwd8_tab = atoi(env8tb) != 0;
   const char* env8m = getenv("KL_FWD8");
   if (env8m) { h->fwd8 = atoi(env8m) != 0; h->fwd8_all = atoi(env8m) == 2; }
   const char* env8r = getenv("KL_FWD8_LS");
