@@ -932,51 +932,64 @@ __global__ __launch_bounds__(1024, 1) void logits_ce_ws_kernel(const KlLogitsCe 
 #pragma unroll
       for (int r = 0; r < 4; ++r) zl[(h * 16 + 4 * (lane >> 4) + r) * LDZ + 16 * wave + (lane & 15)] = acc[h][r];
     __syncthreads();
-    // rows 2 wave, 2 wave + 1: one row per pass, lane = characters 4 lane .. 4 lane + 3
-#pragma unroll 1
-    for (int k2 = 0; k2 < 2; ++k2) {
-      const int lr = 2 * wave + k2;
+    // Waves 0-7 take FOUR rows each in one pass (round 4): 16 lanes per row, 16 characters per lane (64 k + 4 (l & 15) .. + 3, k = 0 .. 3),
+    // the reductions are four DPP steps inside the 16-lane rows and serve four rows at once -- with a row per pass and wave-wide
+    // reductions every wave spent 150 vector instructions per row (the width-128 kernel's measurements, lstm_scan_w128.hip).
+    if (wave < 8) {
+      const int rs4 = lane >> 4, cl = lane & 15;
+      const int lr = 4 * wave + rs4;
       const long row = (long)(rg + (long)i * a.n_rg) * ROWS + lr;
-      const f32x4 z = *reinterpret_cast<const f32x4*>(zl + lr * LDZ + lane * 4);
-      float e[4] = {z[0], z[1], z[2], z[3]};
-      const int v0 = lane * 4;
-      const float mx = wave_max(fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3])));
-      // the first character that reaches the maximum (Keras' argmax)
-      const int first = e[0] == mx ? v0 : e[1] == mx ? v0 + 1 : e[2] == mx ? v0 + 2 : e[3] == mx ? v0 + 3 : 0x7fffffff;
-      const int amax = wave_min_i(first);
-      float sum = 0.f;
+      float e[16];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        e[k] = __expf(e[k] - mx);      // (exp2-based: the arguments are <= 0)
-        sum += e[k];
+        const f32x4 z = *reinterpret_cast<const f32x4*>(zl + lr * LDZ + 64 * k + 4 * cl);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[4 * k + j] = z[j];
       }
-      const float inv = 1.f / wave_sum(sum);
+      float mloc = e[0];
+#pragma unroll
+      for (int j = 1; j < 16; ++j) mloc = fmaxf(mloc, e[j]);
+      const float mx = row16_max(mloc);
+      // the first character that reaches the maximum (Keras' argmax); a lane's characters ascend with j
+      int first = 0x7fffffff;
+#pragma unroll
+      for (int j = 15; j >= 0; --j) first = e[j] == mx ? 64 * (j >> 2) + 4 * cl + (j & 3) : first;
+      const int amax = row16_min_i(first);
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        e[j] = __expf(e[j] - mx);      // (exp2-based: the arguments are <= 0)
+        sum += e[j];
+      }
+      const float inv = 1.f / row16_sum(sum);
       const int b = (int)(row % a.B), tt = (int)(row / a.B);
       int t = a.tgt[(long)b * a.T + tt];
       bool counts = true;
       if (a.last_only && tt != a.T - 1) { t = -1; counts = false; }
       if (t < -1) { t = -1; counts = false; }      // (a dummy stream added by the caller's padding: no accuracy either)
+      float ploc = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) e[k] *= inv;
-      // the target's probability sits in lane t / 4, register t % 4 (t is uniform: one row per pass)
-      float pt = 0.f;
-      if (t >= 0) {
-        const int tl = t >> 2, tk = t & 3;
-        const float cand = tk == 0 ? e[0] : tk == 1 ? e[1] : tk == 2 ? e[2] : e[3];
-        pt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand), tl));
+      for (int j = 0; j < 16; ++j) {
+        e[j] *= inv;
+        ploc = (64 * (j >> 2) + 4 * cl + (j & 3)) == t ? e[j] : ploc;
       }
+      const float pt = row16_sum(ploc);              // (one lane of the row holds the target's probability)
       const bool valid = t >= 0;
       const bool active = valid && pt >= 1e-7f && pt <= 1.f - 1e-7f;
-      unsigned short g[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float gk = active ? e[k] : 0.f;
-        if (active && v0 + k == t) gk -= 1.f;
-        g[k] = f2bf(gk * a.inv_count);
+        unsigned short g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float gk = active ? e[4 * k + j] : 0.f;
+          if (active && 64 * k + 4 * cl + j == t) gk -= 1.f;
+          g[j] = f2bf(gk * a.inv_count);
+        }
+        // (the row differs from lane to lane: all of the address in the vector offset)
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{(unsigned)g[0] | ((unsigned)g[1] << 16), (unsigned)g[2] | ((unsigned)g[3] << 16)}, rs_dl,
+                                              (int)(unsigned)(row * V * 2 + (64 * k + 4 * cl) * 2), 0, 0);
       }
-      __builtin_amdgcn_raw_buffer_store_b64(u32x2{(unsigned)g[0] | ((unsigned)g[1] << 16), (unsigned)g[2] | ((unsigned)g[3] << 16)}, rs_dl, lane * 8,
-                                            (int)(unsigned)(row * V * 2), 0);
-      if (lane == 0) {
+      if (cl == 0) {
         float l = 0.f;
         if (valid) {
           const float pc = fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f);
@@ -984,7 +997,7 @@ __global__ __launch_bounds__(1024, 1) void logits_ce_ws_kernel(const KlLogitsCe 
         }
         const int tsafe = valid ? t : 0;
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, l), __builtin_bit_cast(unsigned, (counts && amax == tsafe) ? a.inv_count : 0.f)},
-                                              rs_rs, 0, (int)(unsigned)(row * 8), 0);
+                                              rs_rs, (int)(unsigned)(row * 8), 0, 0);
       }
     }
   };
