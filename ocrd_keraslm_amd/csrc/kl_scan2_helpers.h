@@ -196,3 +196,13 @@ __device__ __forceinline__ int row16_min_i(int v) {
   v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x140, 0xF, 0xF, false));
   return v;
 }
+
+// one dword from LDS as it is NOW (a landing zone of an LDS-DMA request), by an LDS instruction.  NOT `*(volatile unsigned*)p` with a
+// generic pointer: that becomes a FLAT load, which counts on vmcnt as well, and the compiler follows it with `s_waitcnt vmcnt(0)` --
+// a wait for every load and store the wave has in flight, hand-counted ones included (found in the register-tile backward
+// scan in round 4: it drained the wave's queue at the top of every block).
+__device__ __forceinline__ unsigned lds_peek(unsigned lds_addr) {
+  unsigned v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr) : "memory");
+  return v;
+}

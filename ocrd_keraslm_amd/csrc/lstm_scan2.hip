@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(1024, 1) void lstm_scan_bwd_wide2_kernel(const KlSc
         if (alive && tF >= 0 && tF < T - 1) {
           // (unsigned distance: a word of this launch is at most T - 1 behind the epoch, one of an earlier launch at least T + 2)
           const unsigned far = (unsigned)(tF + 1);
-          bool ready = __all(epoch - *reinterpret_cast<const volatile unsigned*>(fl_l + lane) <= far);
+          bool ready = __all(epoch - lds_peek(lds_tile + (unsigned)(2 * NPIECE * 1024 + 16 * 16 * 17 * 4 + 4 * 16 * 64 * 2 + 16) + (unsigned)(lane * 4)) <= far);
           if (!ready) {      // not posted when the words were fetched, or the fetch itself still on its way: ask memory
 #ifdef KL_STAMP
             if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[28] += 1;
@@ -1607,7 +1607,7 @@ __global__ __launch_bounds__(512, 1) void lstm_scan_bwd_regtile_kernel(const KlS
     bool ready = t2 >= 0 && t2 < T - 1;
     if (ready) {
       const unsigned far = (unsigned)(t2 + 1);      // (a word of this launch is at most T - 1 behind the epoch, one of an earlier launch at least T + 2)
-      ready = __all(epoch - *reinterpret_cast<const volatile unsigned*>(fl_l + (n & 1) * 64 + lane) <= far);
+      ready = __all(epoch - lds_peek(lds_tile + (unsigned)(FL_OFF + (n & 1) * 256) + (unsigned)(lane * 4)) <= far);
       if (!ready) {      // not posted when the words were fetched: ask memory (rare; this wait drains the wave's queue)
 #ifdef KL_STAMP
         if (blockIdx.x == STAMP_WG && threadIdx.x == 0) stamp_lds[28] += 1;
