@@ -2,7 +2,7 @@
 N times and every run's loss, carried state and flat gradient vector are compared with the first run's.  The persistent
 scans hand tiles between workgroups through counted waits, sentinels and flags; a tile taken too early (stale data) would
 show up here as a run that differs by far more than the f32-atomics noise of the split-K weight-gradient GEMMs.
-Usage: python tools/check_repeat.py [cfg2|cfg5] [runs]      -> one JSON line"""
+Usage: python tools/check_repeat.py [cfg2|cfg5|w128] [runs]      -> one JSON line"""
 import json
 import sys
 
@@ -15,7 +15,8 @@ from ocrd_keraslm_amd.lib.engine import HipLM
 
 what = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-L, W, V, T, C, B = (2, 512, 256, 256, 1, 3072) if what == "cfg2" else (4, 1024, 256, 512, 2, 512)
+# (w128: the published model's size with both layers' scans in one launch, a layer polling its neighbour's rows)
+L, W, V, T, C, B = {"cfg2": (2, 512, 256, 256, 1, 3072), "cfg5": (4, 1024, 256, 512, 2, 512), "w128": (2, 128, 256, 256, 1, 1024)}[what]
 lm = HipLM(L, W, V, C)
 lm.init_weights(seed=1, emb_std=0.3)
 lm.prepare(hipabi.KL_PREC_BF16)
