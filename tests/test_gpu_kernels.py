@@ -658,6 +658,7 @@ def test_train_window_width_1024_scans(monkeypatch, depth, width, voc, B, T, n_c
     (2, 128, 50, 2064, 3, 1, True, {}, "single"),                      # 2 x 129 row blocks do not fit 256 CUs: one launch per layer
     (3, 128, 30, 20, 6, 1, True, {"KL_W128_MIN": "1", "KL_SENTINEL_ROLL": "0"}, "multi"),   # every polled row a sentinel from the start (default: rolling)
     (2, 128, 30, 20, 2, 1, True, {"KL_W128_MIN": "1"}, "multi"),       # two steps: nothing to roll
+    (3, 128, 30, 17, 1, 1, True, {}, "multi"),                         # a single step, ragged second row block
     (2, 128, 40, 40, 6, 0, True, {"KL_W128_MIN": "1"}, "multi"),       # no context variable: layer 0 from the embedding table alone
     (2, 128, 40, 24, 5, 3, True, {"KL_W128_MIN": "1"}, "multi"),       # three context variables: layer 0's gate inputs gathered into rows first
     (1, 128, 40, 24, 7, 1, False, {"KL_W128_MIN": "1", "KL_W128_TABLES": "0"}, "single"),    # ... also with one
