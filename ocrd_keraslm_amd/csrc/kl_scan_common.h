@@ -95,13 +95,38 @@ __device__ __forceinline__ void glds16_nt(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 // wait until at most k (wave-uniform; an under-estimate only waits longer) vector memory operations of
 // this wave are in flight
 __device__ __forceinline__ void wait_vm(int k) {
-#define KL_WAIT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
-  switch (k < 0 ? 0 : (k > 15 ? 15 : k)) {
-    KL_WAIT_CASE(0) KL_WAIT_CASE(1) KL_WAIT_CASE(2) KL_WAIT_CASE(3) KL_WAIT_CASE(4) KL_WAIT_CASE(5)
-    KL_WAIT_CASE(6) KL_WAIT_CASE(7) KL_WAIT_CASE(8) KL_WAIT_CASE(9) KL_WAIT_CASE(10) KL_WAIT_CASE(11)
-    KL_WAIT_CASE(12) KL_WAIT_CASE(13) KL_WAIT_CASE(14) KL_WAIT_CASE(15)
-  }
-#undef KL_WAIT_CASE
+  // A computed jump into a table of (s_waitcnt vmcnt(i); s_branch end) pairs: seven scalar instructions whatever k is.  As a C++
+  // switch the sixteen cases come out of the structuriser as a tree of compares FOLLOWED by a chain of flag tests -- ~25 scalar
+  // instructions and a handful of branches per call, four calls per phase of the 16-wave forward scan.
+  const unsigned kk = __builtin_amdgcn_readfirstlane((unsigned)(k < 0 ? 0 : (k > 15 ? 15 : k)));      // (wave-uniform by contract)
+  unsigned off;
+  asm volatile(
+      "s_getpc_b64 vcc\n\t"                      // = address of the next instruction (A); vcc as the 64-bit scratch pair
+      "s_lshl_b32 %0, %1, 3\n\t"                 // A + 0:  8 bytes per table entry
+      "s_add_u32 %0, %0, 20\n\t"                 // A + 4:  the table starts 20 bytes behind A
+      "s_add_u32 vcc_lo, vcc_lo, %0\n\t"         // A + 8
+      "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"         // A + 12
+      "s_setpc_b64 vcc\n\t"                      // A + 16
+      "s_waitcnt vmcnt(0)\n\ts_branch .Lwv_end_%=\n\t"
+      "s_waitcnt vmcnt(1)\n\ts_branch .Lwv_end_%=\n\t"
+      "s_waitcnt vmcnt(2)\n\ts_branch .Lwv_end_%=\n\t"
+      "s_waitcnt vmcnt(3)\n\ts_branch .Lwv_end_%=\n\t"
+      "s_waitcnt vmcnt(4)\n\ts_branch .Lwv_end_%=\n\t"
+      "s_waitcnt vmcnt(5)\n\ts_branch .Lwv_end_%=\n\t"
+      "s_waitcnt vmcnt(6)\n\ts_branch .Lwv_end_%=\n\t"
+      "s_waitcnt vmcnt(7)\n\ts_branch .Lwv_end_%=\n\t"
+      "s_waitcnt vmcnt(8)\n\ts_branch .Lwv_end_%=\n\t"
+      "s_waitcnt vmcnt(9)\n\ts_branch .Lwv_end_%=\n\t"
+      "s_waitcnt vmcnt(10)\n\ts_branch .Lwv_end_%=\n\t"
+      "s_waitcnt vmcnt(11)\n\ts_branch .Lwv_end_%=\n\t"
+      "s_waitcnt vmcnt(12)\n\ts_branch .Lwv_end_%=\n\t"
+      "s_waitcnt vmcnt(13)\n\ts_branch .Lwv_end_%=\n\t"
+      "s_waitcnt vmcnt(14)\n\ts_branch .Lwv_end_%=\n\t"
+      "s_waitcnt vmcnt(15)\n"
+      ".Lwv_end_%=:"
+      : "=&s"(off)
+      : "s"(kk)
+      : "memory", "scc", "vcc");
 }
 typedef __attribute__((address_space(3))) void lds_void_t;
 
