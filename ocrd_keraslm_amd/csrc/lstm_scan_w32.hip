@@ -26,21 +26,6 @@ namespace {
 
 #include "kl_scan2_helpers.h"
 
-// wait_vm for counts up to 31 (vmcnt has six bits on gfx9; an under-estimate only waits longer)
-__device__ __forceinline__ void wait_vm_wide(int k) {
-  if (k <= 15) {
-    wait_vm(k);
-    return;
-  }
-#define KL_WAIT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
-  switch (k > 31 ? 31 : k) {
-    KL_WAIT_CASE(16) KL_WAIT_CASE(17) KL_WAIT_CASE(18) KL_WAIT_CASE(19) KL_WAIT_CASE(20) KL_WAIT_CASE(21) KL_WAIT_CASE(22)
-    KL_WAIT_CASE(23) KL_WAIT_CASE(24) KL_WAIT_CASE(25) KL_WAIT_CASE(26) KL_WAIT_CASE(27) KL_WAIT_CASE(28) KL_WAIT_CASE(29)
-    KL_WAIT_CASE(30) KL_WAIT_CASE(31)
-  }
-#undef KL_WAIT_CASE
-}
-
 #ifdef KL_STAMP
 // diagnostic build: cycles per block of workgroup 0, thread 0 (a computing wave: slots 0..15) and thread 256 (a DMA wave: 16..31)
 __device__ unsigned long long kl_w32_stamps[32];
