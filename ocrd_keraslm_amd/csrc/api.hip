@@ -162,10 +162,9 @@ struct kl_handle {
   bool fwd8 = true;             // KL_FWD8 = 0: the 16-wave forward scan also for the layers above the first (default: the eight-wave scan of
                                 // lstm_scan_fwd8.hip there -- 3.06 against 3.36 ms per launch at 3072 streams)
   bool fwd8_all = false;        // KL_FWD8 = 2: ... also for layer 0 (its gate inputs gathered into P rows first)
-  bool fwd8_tab = false;        // KL_FWD8_TAB = 1: layer 0 (one context variable) on the eight-wave scan too, its gate-input rows gathered from the
-                                // table of all (character, context value) sums (200 MiB more of derived operands).  Off: measured 3.43 ms per launch
-                                // against 3.53 on the 16-wave scan's table mode, minus 0.06 ms for the table -- with 200 context values in a batch the
-                                // gathers leave the L2 that the two small tables stay in
+  bool fwd8_tab = true;         // KL_FWD8_TAB = 0: layer 0 (one context variable) stays on the 16-wave scan's table mode (default: the eight-wave scan,
+                                // its gate-input rows gathered from the table of all (character, context value) sums -- 200 MiB more of derived operands;
+                                // 23.03 / 23.20 against 23.21 / 23.28 ms per step with 200 context values in the batch, where its gathers leave the L2)
   bool fwd8_ls = true;          // KL_FWD8_LS = 0: the counter form of the eight-wave forward scan instead of the two-barrier form
   bool fwd8_local = true;       // KL_FWD8_LOCAL = 0: write-through publishes in the eight-wave forward scan even where its partners share an XCD
   int fwd8_pf = -1;             // KL_FWD8_PF = 0..3: where it requests its tiles (default by phases per step)
@@ -433,8 +432,6 @@ int prepare_impl(kl_handle* h, int precision, hipStream_t s) {
     }
     KL_TRY(kl_launch_permute_gate_cols_f32(d.EK, P + h->off_b[0], d.EKp, V, W, s));
     for (int n = 0; n < c.n_ctx; ++n) KL_TRY(kl_launch_permute_gate_cols_f32(d.CtxK[n], nullptr, d.CtxKp[n], c.ctx_vocab, W, s));
-    // (every gate-input row of layer 0, for the eight-wave forward scan's table mode: 200 MiB written per update, ~0.06 ms)
-    if (d.comb && h->fwd8 && h->fwd8_tab) KL_TRY(kl_launch_comb_table(d.EKp, d.CtxKp[0], V, c.ctx_vocab, 4 * W, d.comb, s));
   }
   h->precision = precision;
   h->inc_ready = false;      // the incremental step's own operands are rebuilt on their first use (prepare_incremental,
@@ -567,6 +564,9 @@ int forward_impl(kl_handle* h, int B, int T, const int* idx, const int* ctx, flo
         a.P = w.P1;
         a.p_bf16 = v2 && h->scan2_bf16 ? 1 : 0;
       } else if (f8_tab) {
+        // every gate-input row layer 0 can ask for: 200 MiB, ~0.05 ms -- built by every window that gathers from it (no "already
+        // built" flag: a captured window is replayed after later updates of the operands, and must then build it again)
+        KL_TRY(kl_launch_comb_table(d.EKp, d.CtxKp[0], c.voc_size, c.ctx_vocab, 4 * W, d.comb, s));
         KL_TRY(kl_launch_rows_tm(idx, ctx, c.n_ctx, B, T, c.ctx_vocab, w.ids_tm, s));
         a.P = reinterpret_cast<const float*>(d.comb);
         a.p_bf16 = 1;

@@ -604,10 +604,9 @@ def test_train_window_fwd8(monkeypatch, depth, width, voc, B, T, n_ctx, use_mask
     (2, 2048, 9, True, {"KL_SCAN2_ROWS": "32"}),               # two phases per step; the ring of row numbers goes round four times
     (3, 3072, 3, True, {})])                                   # a window as short as the look-ahead of the row numbers
 def test_train_window_fwd8_table_mode(monkeypatch, depth, B, T, use_masks, env):
-    """Layer 0 on the eight-wave forward scan (round 4, KL_FWD8_TAB=1): its gate-input rows are gathered from the table of ALL (character,
+    """Layer 0 on the eight-wave forward scan (round 4; KL_FWD8_TAB=0 switches it off): its gate-input rows are gathered from the table of ALL (character,
     context value) sums, the row numbers of a phase brought into LDS three phases ahead -- gradients, loss and carried state
     against the f64 oracle with 200 context values in play."""
-    monkeypatch.setenv("KL_FWD8_TAB", "1")      # (opt-in: on the bench's batches it gains 0.03 ms per step, DESIGN.md section 10)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     check_train_window_gradients(depth, 512, 64, B, T, 1, use_masks, want_kernel="lstm_scan_fwd8_kernel")
